@@ -1,0 +1,202 @@
+/*
+ * scg_rollout.h -- C ABI of the MI355X-native vectorised rollout engine that replaces the
+ * env.step() hot path of ekumenlabs/safe-control-gym.
+ *
+ * The reference is 100 % Python: it has no FFI for this path.  The entry points
+ * below are what a binding for the path would bind; each cites the reference interface it
+ * replaces (file:line relative to /root/reference/safe_control_gym).  INTEGRATION.md shows the
+ * ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every array argument of scg_step/scg_reset/scg_rollout is a
+ *     DEVICE pointer owned by the caller (e.g. torch.Tensor.data_ptr() of a ROCm tensor);
+ *     the handle owns only its constant tables (reference trajectory, constraint rows).
+ *   - struct-of-arrays layout: a "plane" is N consecutive values of one state/action/constraint
+ *     component; plane j of an array starts at base + j*ld elements (ld >= n, the plane stride).
+ *   - every launch is asynchronous on the hipStream_t passed in; no implicit synchronisation.
+ *   - return value: 0 on success, negative scg_status on error; nothing throws across the ABI;
+ *     scg_last_error() returns a thread-local message for the last failing call.
+ *   - a handle is not thread-safe; distinct handles are.  One handle per device.
+ */
+#ifndef SCG_ROLLOUT_H
+#define SCG_ROLLOUT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCG_ABI_VERSION 1
+#define SCG_MAX_NX 12        /* quadrotor.py:625  (3-D: nx = 12) */
+#define SCG_MAX_NU 4         /* quadrotor.py:625  (3-D: nu = 4)  */
+#define SCG_MAX_NV 16        /* constrained variable: [state ; raw action], constraints.py:58-63 */
+#define SCG_MAX_CONSTRAINT_ROWS 64
+#define SCG_MAX_QUADRATIC 4
+#define SCG_MAX_GOAL_HORIZON 8
+
+typedef enum scg_status {
+    SCG_OK = 0,
+    SCG_ERR_INVALID = -1,       /* bad argument / config (the Python side raises ValueError first) */
+    SCG_ERR_HIP = -2,           /* a HIP runtime call failed; see scg_last_error() */
+    SCG_ERR_NOMEM = -3,
+    SCG_ERR_UNSUPPORTED = -4
+} scg_status;
+
+/* QuadType, envs/gym_pybullet_drones/quadrotor_utils.py:11-18; CARTPOLE per benchmark_env.py:43 */
+typedef enum scg_system { SCG_QUAD_1D = 1, SCG_QUAD_2D = 2, SCG_QUAD_3D = 3, SCG_CARTPOLE = 4 } scg_system;
+/* controllers/mpc/mpc_utils.py:79-101 (RK4); explicit Euler as the cheap alternative */
+typedef enum scg_integrator { SCG_RK4 = 0, SCG_EULER = 1 } scg_integrator;
+/* envs/benchmark_env.py:29-35 */
+typedef enum scg_task { SCG_STABILIZATION = 0, SCG_TRAJ_TRACKING = 1 } scg_task;
+/* envs/benchmark_env.py:19-26 (COMPETITION needs contact queries: out of scope) */
+typedef enum scg_cost { SCG_RL_REWARD = 0, SCG_QUADRATIC = 1 } scg_cost;
+
+typedef struct scg_handle scg_handle;
+
+/* Everything Quadrotor.__init__ / BenchmarkEnv.__init__ fix for the lifetime of an env
+ * (quadrotor.py:148-329, benchmark_env.py:63-218, base_aviary.py:66-147).  Doubles on purpose:
+ * derived constants (1/m, l/sqrt2/Iyy, KM/KF ...) are formed in double and rounded to float once. */
+typedef struct scg_config {
+    uint32_t struct_size;            /* = sizeof(scg_config) */
+    uint32_t abi_version;            /* = SCG_ABI_VERSION */
+    int32_t system;                  /* scg_system */
+    int32_t integrator;              /* scg_integrator */
+    int32_t substeps;                /* fixed steps of dt/substeps per step(); 1 = mpc.py:163 usage,
+                                        PYB_STEPS_PER_CTRL mirrors base_aviary.py:278 */
+    int32_t task;                    /* scg_task */
+    int32_t cost;                    /* scg_cost */
+    int32_t ctrl_steps;              /* CTRL_STEPS, benchmark_env.py:161 (time limit :460) */
+    double dt;                       /* CTRL_TIMESTEP, benchmark_env.py:157 */
+    /* quadrotor physical constants: assets/cf2x.urdf:5,12,13; base_aviary.py:90 */
+    double mass, gravity, arm, ixx, iyy, izz, kf, km;
+    double pwm2rpm_scale, pwm2rpm_const, pwm_min, pwm_max;
+    /* cartpole (not in the reference fork; names from tests/scripts/verbose_api.yaml:32-39) */
+    double pole_length, pole_mass, cart_mass;
+    /* action preprocessing: quadrotor.py:815-842, quadrotor_utils.py:21-67 */
+    int32_t normalized_action;       /* NORMALIZED_RL_ACTION_SPACE */
+    int32_t motor_map;               /* apply cmd2pwm -> pwm2rpm -> KF rpm^2 */
+    double norm_act_scale, hover_thrust, action_scale;
+    double act_low[SCG_MAX_NU], act_high[SCG_MAX_NU];   /* action_space bounds (float32-rounded) */
+    /* goals and cost: quadrotor.py:262-329,886-930, benchmark_env.py:190-192 */
+    double u_goal[SCG_MAX_NU];
+    double x_goal[SCG_MAX_NX];       /* stabilisation goal; tracking uses scg_set_reference() */
+    double rew_state_weight[SCG_MAX_NX], rew_act_weight[SCG_MAX_NU];
+    int32_t rew_exponential;
+    int32_t reserved0;
+    double Q[SCG_MAX_NX * SCG_MAX_NX];   /* row-major nx*nx in the top-left corner of a 12-wide matrix */
+    double R[SCG_MAX_NU * SCG_MAX_NU];   /* row-major, 4-wide */
+    double mse_weight[SCG_MAX_NX];       /* info_mse_metric_state_weight, quadrotor.py:185-200 */
+    /* termination: quadrotor.py:956-993, benchmark_env.py:435-462 */
+    int32_t done_on_out_of_bound, done_on_violation;
+    double oob_low[SCG_MAX_NX], oob_high[SCG_MAX_NX];   /* +-inf on dims the mask (:981-985) excludes */
+    double goal_tolerance;           /* stabilization_goal_tolerance, quadrotor.py:138,965 */
+    int32_t use_constraint_penalty;  /* benchmark_env.py:454-456 */
+    int32_t obs_goal_horizon;        /* benchmark_env.py:406-420 */
+    double constraint_penalty;
+    /* reset: quadrotor.py:478-493, benchmark_env.py:277-308 (uniform draws only) */
+    int32_t randomized_init;
+    int32_t auto_reset;              /* dummy_vec_env.py:41-47 fused into step */
+    double init_state[SCG_MAX_NX];
+    double init_rand_low[SCG_MAX_NX], init_rand_high[SCG_MAX_NX];  /* low == high == 0: dim not randomised */
+    uint64_t seed;                   /* Philox key */
+    int64_t env_index_base;          /* global index of this shard's env 0 (seed + rank analogue,
+                                        env_wrappers/vectorized_env/__init__.py:29) */
+} scg_config;
+
+/* One scalar constraint g(v) <= 0 over v = [state ; RAW action] (constraints.py:160-172).
+ * LinearConstraint / BoundedConstraint / DefaultConstraint (constraints.py:226-368) compile to
+ * kind 0 rows with coef = (A @ filter) scattered to v's index space;
+ * QuadraticContstraint (constraints.py:179-223) to one kind 1 row with P = filter' P filter. */
+typedef struct scg_constraint_row {
+    int32_t kind;                    /* 0: c = coef . v - b     1: c = v' P[p_index] v - b */
+    int32_t strict;                  /* constraints.py:137-141 */
+    int32_t has_tolerance;           /* constraints.py:153-158 */
+    int32_t p_index;
+    double tolerance;
+    double b;
+    double coef[SCG_MAX_NV];
+} scg_constraint_row;
+
+/* Device buffers of one step() call.  Nullable members are skipped (their bytes are not moved). */
+typedef struct scg_step_io {
+    uint32_t struct_size;            /* = sizeof(scg_step_io) */
+    uint32_t reserved;
+    int64_t ld;                      /* plane stride in elements (>= n) of every multi-plane array */
+    /* in */
+    const float* action;             /* [nu][ld] raw action as passed to step() */
+    const float* action_disturbance; /* nullable [nu][ld], added after clipping (quadrotor.py:835-838) */
+    const float* dynamics_force;     /* nullable [3][ld] world-frame force (quadrotor.py:526-548) */
+    const float* obs_noise;          /* nullable [nx][ld] added to obs only (quadrotor.py:879-880) */
+    const float* reset_state;        /* nullable [nx][ld] per-env nominal reset state (overrides cfg.init_state) */
+    /* in/out */
+    float* state;                    /* [nx][ld] */
+    float* state_lo;                 /* nullable [nx][ld] compensation residual (state = hi + lo) */
+    int32_t* step_count;             /* [n] ctrl_step_counter */
+    float* ep_return;                /* nullable [n] running episode return (record_episode_statistics.py:145) */
+    int32_t* ep_length;              /* nullable [n] */
+    /* out */
+    float* obs;                      /* nullable [obs_dim][ld]; NULL when obs aliases state */
+    float* reward;                   /* [n] */
+    uint8_t* done;                   /* [n] */
+    float* constraint_values;        /* nullable [nc][ld] */
+    uint8_t* constraint_violation;   /* nullable [n] */
+    uint8_t* truncated;              /* nullable [n] info["TimeLimit.truncated"] */
+    uint8_t* goal_reached;           /* nullable [n] */
+    float* mse;                      /* nullable [n] */
+    float* terminal_obs;             /* nullable [nx][ld], written for done lanes only */
+    float* last_ep_return;           /* nullable [n], written for done lanes only (info['episode']['r']) */
+    int32_t* last_ep_length;         /* nullable [n] */
+    double* stats;                   /* nullable [8] batch sums, atomically accumulated:
+                                        0 sum reward, 1 #done, 2 #violation, 3 sum finished returns,
+                                        4 sum finished lengths, 5 #truncated, 6-7 reserved */
+    uint32_t reset_serial;           /* Philox counter word for resets happening in this call */
+    uint32_t reserved1;
+} scg_step_io;
+
+/* Replaces Quadrotor.__init__ (quadrotor.py:148) for a batch: copies constants to the device. */
+int scg_create(const scg_config* cfg, scg_handle** out);
+int scg_destroy(scg_handle* h);
+
+/* X_GOAL table for Task.TRAJ_TRACKING (quadrotor.py:280-325): host pointer, row-major [rows][nx]. */
+int scg_set_reference(scg_handle* h, const double* x_goal, int32_t rows);
+
+/* Compiled ConstraintList (constraints.py:426-583, factory :594-612): host pointers.
+ * p_mats is [n_p][SCG_MAX_NV][SCG_MAX_NV] row-major. */
+int scg_set_constraints(scg_handle* h, const scg_constraint_row* rows, int32_t n_rows,
+                        const double* p_mats, int32_t n_p);
+
+/* Replaces Quadrotor.reset (quadrotor.py:356-504) + RecordEpisodeStatistics.reset
+ * (record_episode_statistics.py:132-140) for the lanes where mask != 0 (all lanes if mask NULL).
+ * Writes state (nominal + Philox uniform offsets), zeroes step_count / ep_return / ep_length, and
+ * if obs != NULL the extended observation; if c_val != NULL the state-only constraint values are
+ * NOT produced here (reset-time only_state values come from scg_eval_constraints). */
+int scg_reset(scg_handle* h, float* state, float* state_lo, int32_t* step_count, float* ep_return,
+              int32_t* ep_length, float* obs, const uint8_t* mask, const float* reset_state,
+              uint32_t reset_serial, int64_t ld, int64_t n, void* stream);
+
+/* Replaces Quadrotor.step (quadrotor.py:507-558) + BenchmarkEnv.after_step
+ * (benchmark_env.py:422-463) + the DummyVecEnv auto-reset (dummy_vec_env.py:34-49) +
+ * VecRecordEpisodeStatistics.step_wait (record_episode_statistics.py:142-169) for n envs. */
+int scg_step(scg_handle* h, const scg_step_io* io, int64_t n, void* stream);
+
+/* ConstraintList.get_values (constraints.py:503-520) on explicit buffers: state [nx][ld],
+ * action [nu][ld] (nullable -> only_state semantics: input rows are written as NaN), out [nc][ld]. */
+int scg_eval_constraints(scg_handle* h, const float* state, const float* action, float* c_val,
+                         uint8_t* violation, int64_t ld, int64_t n, void* stream);
+
+/* Introspection */
+int scg_num_constraints(const scg_handle* h);
+int scg_obs_dim(const scg_handle* h);
+int scg_kernel_info(const scg_handle* h, int32_t* block, int32_t* grid_for_n, int32_t* lds_bytes, int64_t n);
+const char* scg_last_error(void);
+int scg_version(void);
+/* sizeof() of the ABI structs as compiled, so a binding can verify its own layout */
+int scg_sizeof_config(void);
+int scg_sizeof_step_io(void);
+int scg_sizeof_constraint_row(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCG_ROLLOUT_H */

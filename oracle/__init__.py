@@ -1,0 +1,32 @@
+"""CPU oracle for the safe-control-gym ``env.step()`` hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``safe_control_gym_amd/`` may import,
+call, link or execute anything in this package: only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` do, and
+there only as the checker, never as the thing being measured or shipped.
+
+What it is
+----------
+A float64, one-environment-at-a-time restatement (plain Python / NumPy) of the
+reference's step path, function for function, each citing the reference
+``file:line`` it follows (paths relative to ``/root/reference``).  The batched
+"vector env" here is a Python ``for`` over single-env objects, exactly like the
+reference's ``DummyVecEnv``.
+
+Pinning status
+--------------
+* The reference cannot be imported in the build container (``casadi``,
+  ``pybullet`` and ``gym`` are not installed; ordinary ``ModuleNotFoundError``,
+  nothing was denied) and its test-suite holds **no** golden vectors or
+  known-answer tests.
+* The oracle is therefore pinned by (a) the analytic known-answer tests listed
+  in SURVEY.md section 8(c) (hover fixed point, free fall, pure yaw / pitch couples,
+  action-bound constants, the competition ``BoundedConstraint`` numbers ...),
+  (b) an independent re-derivation of the dynamics with sympy and a
+  high-accuracy ``scipy.integrate.solve_ivp`` integration
+  (``oracle/independent.py``), and (c) the one importable reference module,
+  ``safe_control_gym.envs.disturbances`` (used when generating fixtures).
+* PyBullet and CVODES numerics: **parity unpinned** (third-party native code,
+  absent here, no reference fixture covers them).  CartPole: **parity
+  unpinned** (no CartPole environment exists in this fork of the reference).
+"""

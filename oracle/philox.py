@@ -1,0 +1,67 @@
+"""Oracle: Philox4x32-10 counter-based RNG in NumPy integer arithmetic (bit-exact).
+
+Test infrastructure -- see ``oracle/__init__.py``.
+
+The reference draws reset randomisation from ``gym.utils.seeding.np_random`` (MT19937 behind a
+SHA-512 seed hash; envs/benchmark_env.py:231,297-307), one RandomState per env with
+``seed + rank`` (envs/env_wrappers/vectorized_env/__init__.py:28-33).  A per-env Mersenne Twister
+is 2.5 KB of state per env and is not reproducible without gym; the device engine instead uses
+the published Philox4x32-10 generator (Salmon et al., SC'11 -- Random123), keyed by the seed and
+countered by (global env index, reset serial).  This file restates that algorithm so that parity
+tests can give the float64 oracle the *same* reset draws as the HIP kernel.  Pinned by the
+Random123 known-answer vectors (tests/test_oracle_philox.py).
+
+Draw layout (shared with safe_control_gym_amd/csrc/scg_kernels.hip):
+    key = (seed & 0xffffffff, seed >> 32)
+    ctr = (env_index & 0xffffffff, env_index >> 32, reset_serial, j)     j = 0,1,2
+    words 4j .. 4j+3 -> state dims 4j .. 4j+3
+    u = (word >> 8) * 2**-24  in [0, 1);  offset = low + (high - low) * u
+"""
+import numpy as np
+
+_M0 = np.uint64(0xD2511F53)
+_M1 = np.uint64(0xCD9E8D57)
+_W0 = np.uint32(0x9E3779B9)
+_W1 = np.uint32(0xBB67AE85)
+_MASK = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(ctr, key):
+    """ctr: (..., 4) uint32, key: (..., 2) uint32 -> (..., 4) uint32."""
+    c = [np.asarray(ctr[..., i], dtype=np.uint32) for i in range(4)]
+    k0 = np.asarray(key[..., 0], dtype=np.uint32)
+    k1 = np.asarray(key[..., 1], dtype=np.uint32)
+    with np.errstate(over='ignore'):
+        for r in range(10):
+            p0 = _M0 * c[0].astype(np.uint64)
+            p1 = _M1 * c[2].astype(np.uint64)
+            hi0, lo0 = (p0 >> np.uint64(32)).astype(np.uint32), (p0 & _MASK).astype(np.uint32)
+            hi1, lo1 = (p1 >> np.uint64(32)).astype(np.uint32), (p1 & _MASK).astype(np.uint32)
+            c = [hi1 ^ c[1] ^ k0, lo1, hi0 ^ c[3] ^ k1, lo0]
+            if r < 9:
+                k0 = (k0 + _W0).astype(np.uint32)
+                k1 = (k1 + _W1).astype(np.uint32)
+    return np.stack(c, axis=-1)
+
+
+def uniform01(words):
+    """(word >> 8) * 2^-24, exactly representable in float32 and float64."""
+    return (np.asarray(words, dtype=np.uint32) >> np.uint32(8)).astype(np.float64) * (2.0 ** -24)
+
+
+def reset_offsets(seed, env_index, reset_serial, low, high):
+    """Uniform reset offsets for one env: (nx,) float64, low/high are (nx,) arrays."""
+    low = np.asarray(low, dtype=np.float64)
+    high = np.asarray(high, dtype=np.float64)
+    nx = low.shape[0]
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)
+    out = np.zeros(nx)
+    for j in range((nx + 3) // 4):
+        ctr = np.array([env_index & 0xFFFFFFFF, (env_index >> 32) & 0xFFFFFFFF,
+                        reset_serial & 0xFFFFFFFF, j], dtype=np.uint32)
+        u = uniform01(philox4x32_10(ctr, key))
+        for w in range(4):
+            d = 4 * j + w
+            if d < nx:
+                out[d] = low[d] + (high[d] - low[d]) * u[w]
+    return out

@@ -1,0 +1,145 @@
+"""ctypes binding of ``include/scg_rollout.h`` (the C ABI of the HIP rollout engine).
+
+The product path has NO fallback: if ``lib/libscg_rollout.so`` is missing or a call fails, this
+module raises.  Struct layouts mirror the header field for field; ``load()`` cross-checks
+``ctypes.sizeof`` against the ``scg_sizeof_*`` exports of the library it opened.
+"""
+import ctypes as C
+import os
+
+SCG_ABI_VERSION = 1
+SCG_MAX_NX = 12
+SCG_MAX_NU = 4
+SCG_MAX_NV = 16
+SCG_MAX_CONSTRAINT_ROWS = 64
+SCG_MAX_QUADRATIC = 4
+SCG_MAX_GOAL_HORIZON = 8
+
+SCG_QUAD_1D, SCG_QUAD_2D, SCG_QUAD_3D, SCG_CARTPOLE = 1, 2, 3, 4
+SCG_RK4, SCG_EULER = 0, 1
+SCG_STABILIZATION, SCG_TRAJ_TRACKING = 0, 1
+SCG_RL_REWARD, SCG_QUADRATIC = 0, 1
+
+_dbl = C.c_double
+_i32 = C.c_int32
+_fp = C.c_void_p          # device pointers travel as plain addresses
+
+
+class ScgConfig(C.Structure):
+    _fields_ = [
+        ('struct_size', C.c_uint32), ('abi_version', C.c_uint32),
+        ('system', _i32), ('integrator', _i32), ('substeps', _i32), ('task', _i32), ('cost', _i32),
+        ('ctrl_steps', _i32),
+        ('dt', _dbl),
+        ('mass', _dbl), ('gravity', _dbl), ('arm', _dbl), ('ixx', _dbl), ('iyy', _dbl), ('izz', _dbl),
+        ('kf', _dbl), ('km', _dbl),
+        ('pwm2rpm_scale', _dbl), ('pwm2rpm_const', _dbl), ('pwm_min', _dbl), ('pwm_max', _dbl),
+        ('pole_length', _dbl), ('pole_mass', _dbl), ('cart_mass', _dbl),
+        ('normalized_action', _i32), ('motor_map', _i32),
+        ('norm_act_scale', _dbl), ('hover_thrust', _dbl), ('action_scale', _dbl),
+        ('act_low', _dbl * SCG_MAX_NU), ('act_high', _dbl * SCG_MAX_NU),
+        ('u_goal', _dbl * SCG_MAX_NU),
+        ('x_goal', _dbl * SCG_MAX_NX),
+        ('rew_state_weight', _dbl * SCG_MAX_NX), ('rew_act_weight', _dbl * SCG_MAX_NU),
+        ('rew_exponential', _i32), ('reserved0', _i32),
+        ('Q', _dbl * (SCG_MAX_NX * SCG_MAX_NX)),
+        ('R', _dbl * (SCG_MAX_NU * SCG_MAX_NU)),
+        ('mse_weight', _dbl * SCG_MAX_NX),
+        ('done_on_out_of_bound', _i32), ('done_on_violation', _i32),
+        ('oob_low', _dbl * SCG_MAX_NX), ('oob_high', _dbl * SCG_MAX_NX),
+        ('goal_tolerance', _dbl),
+        ('use_constraint_penalty', _i32), ('obs_goal_horizon', _i32),
+        ('constraint_penalty', _dbl),
+        ('randomized_init', _i32), ('auto_reset', _i32),
+        ('init_state', _dbl * SCG_MAX_NX),
+        ('init_rand_low', _dbl * SCG_MAX_NX), ('init_rand_high', _dbl * SCG_MAX_NX),
+        ('seed', C.c_uint64),
+        ('env_index_base', C.c_int64),
+    ]
+
+
+class ScgConstraintRow(C.Structure):
+    _fields_ = [
+        ('kind', _i32), ('strict', _i32), ('has_tolerance', _i32), ('p_index', _i32),
+        ('tolerance', _dbl), ('b', _dbl),
+        ('coef', _dbl * SCG_MAX_NV),
+    ]
+
+
+class ScgStepIO(C.Structure):
+    _fields_ = [
+        ('struct_size', C.c_uint32), ('reserved', C.c_uint32),
+        ('ld', C.c_int64),
+        ('action', _fp), ('action_disturbance', _fp), ('dynamics_force', _fp), ('obs_noise', _fp),
+        ('reset_state', _fp),
+        ('state', _fp), ('state_lo', _fp), ('step_count', _fp), ('ep_return', _fp), ('ep_length', _fp),
+        ('obs', _fp), ('reward', _fp), ('done', _fp), ('constraint_values', _fp),
+        ('constraint_violation', _fp), ('truncated', _fp), ('goal_reached', _fp), ('mse', _fp),
+        ('terminal_obs', _fp), ('last_ep_return', _fp), ('last_ep_length', _fp), ('stats', _fp),
+        ('reset_serial', C.c_uint32), ('reserved1', C.c_uint32),
+    ]
+
+
+EXPORTS = (
+    'scg_create', 'scg_destroy', 'scg_set_reference', 'scg_set_constraints', 'scg_reset', 'scg_step',
+    'scg_eval_constraints', 'scg_num_constraints', 'scg_obs_dim', 'scg_kernel_info', 'scg_last_error',
+    'scg_version', 'scg_sizeof_config', 'scg_sizeof_step_io', 'scg_sizeof_constraint_row',
+)
+
+
+class ScgError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+
+_LIB = None
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libscg_rollout.so')
+
+
+def load():
+    """Open the in-tree HIP library (once).  Raises if it is absent: there is no CPU fallback."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise ScgError('HIP extension %s is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                       '(or safe_control_gym_amd/csrc/build.sh).  The engine has no CPU fallback.' % path)
+    lib = C.CDLL(path)
+    lib.scg_last_error.restype = C.c_char_p
+    lib.scg_create.argtypes = [C.POINTER(ScgConfig), C.POINTER(C.c_void_p)]
+    lib.scg_destroy.argtypes = [C.c_void_p]
+    lib.scg_set_reference.argtypes = [C.c_void_p, C.POINTER(_dbl), _i32]
+    lib.scg_set_constraints.argtypes = [C.c_void_p, C.POINTER(ScgConstraintRow), _i32, C.POINTER(_dbl), _i32]
+    lib.scg_reset.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_uint32, C.c_int64,
+                              C.c_int64, C.c_void_p]
+    lib.scg_step.argtypes = [C.c_void_p, C.POINTER(ScgStepIO), C.c_int64, C.c_void_p]
+    lib.scg_eval_constraints.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, C.c_int64, C.c_int64, C.c_void_p]
+    lib.scg_num_constraints.argtypes = [C.c_void_p]
+    lib.scg_obs_dim.argtypes = [C.c_void_p]
+    lib.scg_kernel_info.argtypes = [C.c_void_p, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.c_int64]
+    for name in EXPORTS:
+        if name not in ('scg_last_error',):
+            getattr(lib, name).restype = C.c_int
+    if lib.scg_version() != SCG_ABI_VERSION:
+        raise ScgError('libscg_rollout.so ABI %d != binding ABI %d' % (lib.scg_version(), SCG_ABI_VERSION))
+    for struct, fn in ((ScgConfig, lib.scg_sizeof_config), (ScgStepIO, lib.scg_sizeof_step_io),
+                       (ScgConstraintRow, lib.scg_sizeof_constraint_row)):
+        if C.sizeof(struct) != fn():
+            raise ScgError('%s layout mismatch: ctypes %d bytes, library %d bytes'
+                           % (struct.__name__, C.sizeof(struct), fn()))
+    _LIB = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().scg_last_error()
+        raise ScgError('%s failed (status %d): %s' % (what, status, msg.decode() if msg else ''))
+
+
+def ptr(t):
+    """Device address of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())

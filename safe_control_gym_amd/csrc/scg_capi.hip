@@ -1,0 +1,406 @@
+// C ABI of the rollout engine (include/scg_rollout.h).  Host side only: validates arguments,
+// derives the fp32 constant block from the double-precision config, owns the device-resident
+// constant tables and forwards to the kernel launchers.  Never throws across the boundary.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <vector>
+
+#include "scg_device.h"
+
+using namespace scg;
+
+struct scg_handle {
+    scg_config cfg;
+    KParams kp;
+    int system, nx, nu, obs_dim;
+    int device, num_cus;
+    int max_lds_bytes;
+    ConTable* d_con;       // device
+    KTables* d_tb;         // device
+    float* d_ref;          // device, [rows][nx]
+    int ref_rows;
+    int n_con_rows;
+};
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail(SCG_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),   \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+static bool dims_of(int system, int& nx, int& nu) {
+    switch (system) {
+        case SCG_QUAD_1D: nx = 2; nu = 1; return true;
+        case SCG_QUAD_2D: nx = 6; nu = 2; return true;
+        case SCG_QUAD_3D: nx = 12; nu = 4; return true;
+        case SCG_CARTPOLE: nx = 4; nu = 1; return true;
+        default: return false;
+    }
+}
+
+static float f32_clamped(double v) {
+    // +-inf bounds stay infinite; finite doubles beyond float range saturate (f32max bounds of
+    // quadrotor.py:752-785 are exactly representable).
+    if (std::isinf(v)) return v > 0 ? std::numeric_limits<float>::infinity() : -std::numeric_limits<float>::infinity();
+    const double m = (double)std::numeric_limits<float>::max();
+    if (v > m) return std::numeric_limits<float>::max();
+    if (v < -m) return -std::numeric_limits<float>::max();
+    return (float)v;
+}
+
+static bool matrix_is_diag(const double* M, int n, int stride) {
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b)
+            if (a != b && M[a * stride + b] != 0.0) return false;
+    return true;
+}
+
+static void derive_params(scg_handle* h) {
+    const scg_config& c = h->cfg;
+    KParams& k = h->kp;
+    std::memset(&k, 0, sizeof(k));
+    const int nx = h->nx, nu = h->nu;
+    uint32_t f = 0;
+    if (c.normalized_action) f |= F_NORMALIZED;
+    if (c.motor_map && c.system != SCG_CARTPOLE) f |= F_MOTOR_MAP;
+    if (c.rew_exponential) f |= F_REW_EXP;
+    if (c.done_on_out_of_bound) f |= F_DONE_OOB;
+    if (c.done_on_violation) f |= F_DONE_VIOL;
+    if (c.use_constraint_penalty) f |= F_PENALTY;
+    if (c.randomized_init) f |= F_RAND_INIT;
+    if (c.auto_reset) f |= F_AUTO_RESET;
+    if (c.task == SCG_TRAJ_TRACKING) f |= F_TRACKING;
+    if (c.cost == SCG_QUADRATIC) f |= F_QUADRATIC;
+    if (c.integrator == SCG_EULER) f |= F_EULER;
+    if (c.cost != SCG_QUADRATIC || (matrix_is_diag(c.Q, nx, SCG_MAX_NX) && matrix_is_diag(c.R, nu, SCG_MAX_NU)))
+        f |= F_Q_DIAG;
+    k.flags = f;
+    k.substeps = c.substeps;
+    k.ctrl_steps = c.ctrl_steps;
+    k.ref_rows = 0;
+    k.obs_goal_horizon = (c.cost == SCG_RL_REWARD) ? c.obs_goal_horizon : 0;
+    if (c.task == SCG_STABILIZATION && k.obs_goal_horizon > 1) k.obs_goal_horizon = 1;
+    k.n_con_rows = 0;
+    k.seed_lo = (uint32_t)(c.seed & 0xffffffffull);
+    k.seed_hi = (uint32_t)(c.seed >> 32);
+    k.env_base = c.env_index_base;
+    k.h = (float)(c.dt / (double)c.substeps);
+    if (c.system != SCG_CARTPOLE) {
+        const double n_motor = 4.0 / nu;
+        k.inv_m = (float)(1.0 / c.mass);
+        k.g = (float)c.gravity;
+        k.arm_s2 = (float)(c.arm / std::sqrt(2.0));
+        k.gamma = (float)(c.km / c.kf);
+        k.inv_ixx = (float)(1.0 / c.ixx);
+        k.inv_iyy = (float)(1.0 / c.iyy);
+        k.inv_izz = (float)(1.0 / c.izz);
+        k.cxx = (float)((c.izz - c.iyy) / c.ixx);
+        k.cyy = (float)((c.ixx - c.izz) / c.iyy);
+        k.czz = (float)((c.iyy - c.ixx) / c.izz);
+        k.l_s2_iyy = (float)(c.arm / c.iyy / std::sqrt(2.0));
+        k.inv_nmotor_kf = (float)(1.0 / (n_motor * c.kf));
+        k.nmotor_kf = (float)(n_motor * c.kf);
+        k.pwm_scale = (float)c.pwm2rpm_scale;
+        k.inv_pwm_scale = (float)(1.0 / c.pwm2rpm_scale);
+        k.pwm_const = (float)c.pwm2rpm_const;
+        k.pwm_min = (float)c.pwm_min;
+        k.pwm_max = (float)c.pwm_max;
+    } else {
+        k.cp_l = (float)c.pole_length;
+        k.cp_m = (float)c.pole_mass;
+        k.cp_inv_Mm = (float)(1.0 / (c.pole_mass + c.cart_mass));
+        k.cp_ml = (float)(c.pole_mass * c.pole_length);
+        k.cp_g = (float)c.gravity;
+    }
+    k.norm_act_scale = (float)c.norm_act_scale;
+    k.hover_thrust = (float)c.hover_thrust;
+    k.action_scale = (float)c.action_scale;
+    k.goal_tol2 = (float)(c.goal_tolerance * c.goal_tolerance);
+    k.constraint_penalty = (float)c.constraint_penalty;
+    k.cost_scale = (c.cost == SCG_QUADRATIC) ? -0.5f : -1.0f;
+}
+
+static void derive_tables(const scg_handle* h, KTables& t) {
+    const scg_config& c = h->cfg;
+    std::memset(&t, 0, sizeof(t));
+    const int nx = h->nx, nu = h->nu;
+    const bool quad_cost = (c.cost == SCG_QUADRATIC);
+    for (int j = 0; j < nu; ++j) {
+        t.act_low[j] = f32_clamped(c.act_low[j]);
+        t.act_high[j] = f32_clamped(c.act_high[j]);
+        t.u_goal[j] = (float)c.u_goal[j];
+        t.w_act[j] = (float)(quad_cost ? c.R[j * SCG_MAX_NU + j] : c.rew_act_weight[j]);
+    }
+    for (int j = 0; j < nx; ++j) {
+        t.x_goal[j] = (float)c.x_goal[j];
+        t.w_state[j] = (float)(quad_cost ? c.Q[j * SCG_MAX_NX + j] : c.rew_state_weight[j]);
+        t.mse_w[j] = (float)c.mse_weight[j];
+        t.oob_low[j] = f32_clamped(c.oob_low[j]);
+        t.oob_high[j] = f32_clamped(c.oob_high[j]);
+        t.init_state[j] = (float)c.init_state[j];
+        t.init_lo[j] = (float)c.init_rand_low[j];
+        t.init_span[j] = (float)(c.init_rand_high[j] - c.init_rand_low[j]);
+    }
+    for (int a = 0; a < SCG_MAX_NX * SCG_MAX_NX; ++a) t.Q[a] = (float)c.Q[a];
+    for (int a = 0; a < SCG_MAX_NU * SCG_MAX_NU; ++a) t.R[a] = (float)c.R[a];
+}
+
+extern "C" {
+
+int scg_version(void) { return SCG_ABI_VERSION; }
+
+const char* scg_last_error(void) { return g_err; }
+
+int scg_sizeof_config(void) { return (int)sizeof(scg_config); }
+int scg_sizeof_step_io(void) { return (int)sizeof(scg_step_io); }
+int scg_sizeof_constraint_row(void) { return (int)sizeof(scg_constraint_row); }
+
+int scg_create(const scg_config* cfg, scg_handle** out) {
+    if (!cfg || !out) return fail(SCG_ERR_INVALID, "scg_create: null argument");
+    if (cfg->struct_size != sizeof(scg_config))
+        return fail(SCG_ERR_INVALID, "scg_create: struct_size %u != %zu", cfg->struct_size, sizeof(scg_config));
+    if (cfg->abi_version != SCG_ABI_VERSION)
+        return fail(SCG_ERR_INVALID, "scg_create: abi_version %u != %d", cfg->abi_version, SCG_ABI_VERSION);
+    int nx, nu;
+    if (!dims_of(cfg->system, nx, nu)) return fail(SCG_ERR_INVALID, "scg_create: unknown system %d", cfg->system);
+    if (cfg->integrator != SCG_RK4 && cfg->integrator != SCG_EULER)
+        return fail(SCG_ERR_INVALID, "scg_create: unknown integrator %d", cfg->integrator);
+    if (cfg->task != SCG_STABILIZATION && cfg->task != SCG_TRAJ_TRACKING)
+        return fail(SCG_ERR_INVALID, "scg_create: unknown task %d", cfg->task);
+    if (cfg->cost != SCG_RL_REWARD && cfg->cost != SCG_QUADRATIC)
+        return fail(SCG_ERR_UNSUPPORTED, "scg_create: cost %d is not on the hot path", cfg->cost);
+    if (cfg->substeps < 1 || cfg->substeps > 64) return fail(SCG_ERR_INVALID, "scg_create: substeps %d out of [1,64]", cfg->substeps);
+    if (!(cfg->dt > 0.0)) return fail(SCG_ERR_INVALID, "scg_create: dt must be positive");
+    if (cfg->ctrl_steps < 1) return fail(SCG_ERR_INVALID, "scg_create: ctrl_steps must be >= 1");
+    if (cfg->obs_goal_horizon < 0 || cfg->obs_goal_horizon > SCG_MAX_GOAL_HORIZON)
+        return fail(SCG_ERR_INVALID, "scg_create: obs_goal_horizon %d out of [0,%d]", cfg->obs_goal_horizon, SCG_MAX_GOAL_HORIZON);
+    if (cfg->system != SCG_CARTPOLE) {
+        if (!(cfg->mass > 0 && cfg->ixx > 0 && cfg->iyy > 0 && cfg->izz > 0 && cfg->kf > 0 && cfg->pwm2rpm_scale > 0))
+            return fail(SCG_ERR_INVALID, "scg_create: non-positive physical constant");
+    } else if (!(cfg->pole_length > 0 && cfg->pole_mass > 0 && cfg->cart_mass > 0)) {
+        return fail(SCG_ERR_INVALID, "scg_create: non-positive cartpole constant");
+    }
+
+    scg_handle* h = new (std::nothrow) scg_handle();
+    if (!h) return fail(SCG_ERR_NOMEM, "scg_create: out of host memory");
+    std::memset(h, 0, sizeof(*h));
+    h->cfg = *cfg;
+    h->system = cfg->system;
+    h->nx = nx;
+    h->nu = nu;
+    hipError_t e = hipGetDevice(&h->device);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, h->device);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(SCG_ERR_HIP, "scg_create: no usable HIP device: %s", hipGetErrorString(e));
+    }
+    h->num_cus = prop.multiProcessorCount;
+    h->max_lds_bytes = (int)prop.sharedMemPerBlock;
+    derive_params(h);
+    h->obs_dim = nx * (1 + h->kp.obs_goal_horizon);
+
+    // constant tables: the per-dimension vectors and an empty constraint table
+    std::vector<char> zero(sizeof(ConTable), 0);
+    ConTable* ct = reinterpret_cast<ConTable*>(zero.data());
+    ct->n_state_dims = nx;
+    KTables tb;
+    derive_tables(h, tb);
+    e = hipMalloc(&h->d_con, sizeof(ConTable));
+    if (e == hipSuccess) e = hipMalloc(&h->d_tb, sizeof(KTables));
+    if (e == hipSuccess) e = hipMemcpy(h->d_con, ct, sizeof(ConTable), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(h->d_tb, &tb, sizeof(KTables), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (h->d_con) (void)hipFree(h->d_con);
+        if (h->d_tb) (void)hipFree(h->d_tb);
+        delete h;
+        return fail(SCG_ERR_HIP, "scg_create: device table setup failed: %s", hipGetErrorString(e));
+    }
+    *out = h;
+    return SCG_OK;
+}
+
+int scg_destroy(scg_handle* h) {
+    if (!h) return SCG_OK;
+    if (h->d_con) (void)hipFree(h->d_con);
+    if (h->d_tb) (void)hipFree(h->d_tb);
+    if (h->d_ref) (void)hipFree(h->d_ref);
+    delete h;
+    return SCG_OK;
+}
+
+int scg_set_reference(scg_handle* h, const double* x_goal, int32_t rows) {
+    if (!h || !x_goal) return fail(SCG_ERR_INVALID, "scg_set_reference: null argument");
+    if (rows < 1) return fail(SCG_ERR_INVALID, "scg_set_reference: rows must be >= 1");
+    if (h->cfg.task != SCG_TRAJ_TRACKING) return fail(SCG_ERR_INVALID, "scg_set_reference: task is not traj_tracking");
+    if (h->cfg.cost == SCG_QUADRATIC && rows < h->cfg.ctrl_steps)
+        return fail(SCG_ERR_INVALID, "scg_set_reference: quadratic cost indexes X_GOAL[t] for t < %d but only %d rows given",
+                    h->cfg.ctrl_steps, rows);
+    const size_t count = (size_t)rows * h->nx;
+    std::vector<float> tmp(count);
+    for (size_t a = 0; a < count; ++a) tmp[a] = (float)x_goal[a];
+    if (h->d_ref) { (void)hipFree(h->d_ref); h->d_ref = nullptr; }
+    // padded to a multiple of 16 bytes: the LDS staging loop copies float4
+    const size_t bytes = ((count * sizeof(float) + 15) / 16) * 16;
+    HIP_TRY(hipMalloc(&h->d_ref, bytes));
+    HIP_TRY(hipMemset(h->d_ref, 0, bytes));
+    HIP_TRY(hipMemcpy(h->d_ref, tmp.data(), count * sizeof(float), hipMemcpyHostToDevice));
+    h->ref_rows = rows;
+    h->kp.ref_rows = rows;
+    // stage in LDS when it leaves room for >= 2 workgroups per CU; otherwise read through L1/L2
+    const int lds_budget = h->max_lds_bytes > 0 ? h->max_lds_bytes / 2 : 32768;
+    if ((int64_t)bytes <= lds_budget) h->kp.flags |= F_REF_IN_LDS; else h->kp.flags &= ~F_REF_IN_LDS;
+    return SCG_OK;
+}
+
+int scg_set_constraints(scg_handle* h, const scg_constraint_row* rows, int32_t n_rows, const double* p_mats,
+                        int32_t n_p) {
+    if (!h) return fail(SCG_ERR_INVALID, "scg_set_constraints: null handle");
+    if (n_rows < 0 || n_rows > SCG_MAX_CONSTRAINT_ROWS)
+        return fail(SCG_ERR_INVALID, "scg_set_constraints: %d rows (max %d)", n_rows, SCG_MAX_CONSTRAINT_ROWS);
+    if (n_rows > 0 && !rows) return fail(SCG_ERR_INVALID, "scg_set_constraints: null rows");
+    if (n_p < 0 || n_p > SCG_MAX_QUADRATIC) return fail(SCG_ERR_INVALID, "scg_set_constraints: %d quadratic forms (max %d)", n_p, SCG_MAX_QUADRATIC);
+    const int nv = h->nx + h->nu;
+    std::vector<char> buf(sizeof(ConTable), 0);
+    ConTable* ct = reinterpret_cast<ConTable*>(buf.data());
+    ct->n_rows = n_rows;
+    ct->n_state_dims = h->nx;
+    // classify: a linear row with a single +-1 coefficient is a bound row
+    std::vector<int> bound_dim(n_rows, -1);
+    for (int r = 0; r < n_rows; ++r) {
+        const scg_constraint_row& row = rows[r];
+        if (row.kind == 1) {
+            if (row.p_index < 0 || row.p_index >= n_p || !p_mats)
+                return fail(SCG_ERR_INVALID, "scg_set_constraints: row %d has a bad p_index", r);
+            continue;
+        }
+        if (row.kind != 0) return fail(SCG_ERR_INVALID, "scg_set_constraints: row %d has unknown kind %d", r, row.kind);
+        int nnz = 0, dim = -1;
+        for (int k = 0; k < SCG_MAX_NV; ++k) {
+            if (row.coef[k] != 0.0) {
+                if (k >= nv) return fail(SCG_ERR_INVALID, "scg_set_constraints: row %d reads v[%d] but nv = %d", r, k, nv);
+                ++nnz; dim = k;
+            }
+        }
+        if (nnz == 1 && (row.coef[dim] == 1.0 || row.coef[dim] == -1.0)) bound_dim[r] = dim;
+    }
+    int nb = 0;
+    for (int k = 0; k < SCG_MAX_NV; ++k) {
+        ct->bound_start[k] = nb;
+        for (int r = 0; r < n_rows; ++r) {
+            if (rows[r].kind == 0 && bound_dim[r] == k) {
+                BoundEntry& be = ct->bound[nb++];
+                be.sign = (float)rows[r].coef[k];
+                be.b = f32_clamped(rows[r].b);
+                be.tol = (float)rows[r].tolerance;
+                be.out_row = r;
+                be.flags = (rows[r].strict ? RF_STRICT : 0) | (rows[r].has_tolerance ? RF_HAS_TOL : 0);
+            }
+        }
+    }
+    ct->bound_start[SCG_MAX_NV] = nb;
+    ct->n_bound = nb;
+    int nd = 0, nq = 0;
+    for (int r = 0; r < n_rows; ++r) {
+        const scg_constraint_row& row = rows[r];
+        const int flags = (row.strict ? RF_STRICT : 0) | (row.has_tolerance ? RF_HAS_TOL : 0);
+        if (row.kind == 0 && bound_dim[r] < 0) {
+            DenseRow& dr = ct->dense[nd++];
+            for (int k = 0; k < SCG_MAX_NV; ++k) dr.coef[k] = (float)row.coef[k];
+            dr.b = f32_clamped(row.b);
+            dr.tol = (float)row.tolerance;
+            dr.out_row = r;
+            dr.flags = flags;
+        } else if (row.kind == 1) {
+            if (nq >= SCG_MAX_QUADRATIC) return fail(SCG_ERR_INVALID, "scg_set_constraints: too many quadratic rows");
+            QuadRow& q = ct->quad[nq++];
+            const double* P = p_mats + (size_t)row.p_index * SCG_MAX_NV * SCG_MAX_NV;
+            for (int a = 0; a < SCG_MAX_NV * SCG_MAX_NV; ++a) q.P[a] = (float)P[a];
+            q.b = f32_clamped(row.b);
+            q.tol = (float)row.tolerance;
+            q.out_row = r;
+            q.flags = flags;
+        }
+    }
+    ct->n_dense = nd;
+    ct->n_quad = nq;
+    HIP_TRY(hipMemcpy(h->d_con, ct, sizeof(ConTable), hipMemcpyHostToDevice));
+    h->n_con_rows = n_rows;
+    h->kp.n_con_rows = n_rows;
+    return SCG_OK;
+}
+
+int scg_reset(scg_handle* h, float* state, float* state_lo, int32_t* step_count, float* ep_return,
+              int32_t* ep_length, float* obs, const uint8_t* mask, const float* reset_state,
+              uint32_t reset_serial, int64_t ld, int64_t n, void* stream) {
+    if (!h || !state || !step_count) return fail(SCG_ERR_INVALID, "scg_reset: null argument");
+    if (n < 0 || ld < n) return fail(SCG_ERR_INVALID, "scg_reset: need 0 <= n <= ld (n=%lld ld=%lld)", (long long)n, (long long)ld);
+    if (n == 0) return SCG_OK;
+    if (n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_reset: n > 2^30 envs per device (32-bit lane offsets)");
+    if ((h->kp.flags & F_TRACKING) && h->kp.obs_goal_horizon > 0 && obs && !h->d_ref)
+        return fail(SCG_ERR_INVALID, "scg_reset: traj_tracking needs scg_set_reference() first");
+    HIP_TRY(launch_reset(h->system, h->kp, h->d_tb, state, state_lo, step_count, ep_return, ep_length, obs, mask,
+                         reset_state, h->d_ref, reset_serial, ld, n, (hipStream_t)stream));
+    return SCG_OK;
+}
+
+int scg_step(scg_handle* h, const scg_step_io* io, int64_t n, void* stream) {
+    if (!h || !io) return fail(SCG_ERR_INVALID, "scg_step: null argument");
+    if (io->struct_size != sizeof(scg_step_io))
+        return fail(SCG_ERR_INVALID, "scg_step: struct_size %u != %zu", io->struct_size, sizeof(scg_step_io));
+    if (n < 0 || io->ld < n) return fail(SCG_ERR_INVALID, "scg_step: need 0 <= n <= ld (n=%lld ld=%lld)", (long long)n, (long long)io->ld);
+    if (!io->action || !io->state || !io->step_count || !io->reward || !io->done)
+        return fail(SCG_ERR_INVALID, "scg_step: action, state, step_count, reward and done are mandatory");
+    if ((h->kp.flags & F_TRACKING) && !h->d_ref)
+        return fail(SCG_ERR_INVALID, "scg_step: traj_tracking needs scg_set_reference() first");
+    if (h->kp.obs_goal_horizon > 0 && !io->obs)
+        return fail(SCG_ERR_INVALID, "scg_step: obs_goal_horizon > 0 needs an obs buffer (obs does not alias state)");
+    if (io->obs_noise && !io->obs)
+        return fail(SCG_ERR_INVALID, "scg_step: obs_noise needs an obs buffer");
+    if (n == 0) return SCG_OK;
+    if (n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_step: n > 2^30 envs per device (32-bit lane offsets)");
+    HIP_TRY(launch_step(h->system, h->kp, *io, h->d_tb, h->d_con, h->d_ref, n, h->num_cus, (hipStream_t)stream));
+    return SCG_OK;
+}
+
+int scg_eval_constraints(scg_handle* h, const float* state, const float* action, float* c_val,
+                         uint8_t* violation, int64_t ld, int64_t n, void* stream) {
+    if (!h || !state) return fail(SCG_ERR_INVALID, "scg_eval_constraints: null argument");
+    if (n < 0 || ld < n) return fail(SCG_ERR_INVALID, "scg_eval_constraints: need 0 <= n <= ld");
+    if (n == 0 || h->n_con_rows == 0) return SCG_OK;
+    if (n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_eval_constraints: n > 2^30 envs per device");
+    HIP_TRY(launch_eval_constraints(h->system, h->d_con, state, action, c_val, violation, ld, n, (hipStream_t)stream));
+    return SCG_OK;
+}
+
+int scg_num_constraints(const scg_handle* h) { return h ? h->n_con_rows : 0; }
+
+int scg_obs_dim(const scg_handle* h) { return h ? h->obs_dim : 0; }
+
+int scg_kernel_info(const scg_handle* h, int32_t* block, int32_t* grid_for_n, int32_t* lds_bytes, int64_t n) {
+    if (!h) return fail(SCG_ERR_INVALID, "scg_kernel_info: null handle");
+    LaunchGeom g = step_geometry(h->kp, h->system, n, h->num_cus);
+    if (block) *block = g.block;
+    if (grid_for_n) *grid_for_n = g.grid;
+    if (lds_bytes) *lds_bytes = g.lds_bytes;
+    return SCG_OK;
+}
+
+}  // extern "C"

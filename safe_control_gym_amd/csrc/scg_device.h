@@ -1,0 +1,122 @@
+// Internal device-side parameter blocks of the rollout engine (not part of the C ABI).
+// Everything here is float: the kernel computes in fp32; the host forms derived constants in
+// double (scg_capi.hip) and rounds once.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/scg_rollout.h"
+
+namespace scg {
+
+enum Flags : uint32_t {
+    F_NORMALIZED = 1u << 0,     // NORMALIZED_RL_ACTION_SPACE
+    F_MOTOR_MAP = 1u << 1,      // cmd2pwm -> pwm2rpm -> KF rpm^2 round trip
+    F_REW_EXP = 1u << 2,        // rew_exponential
+    F_Q_DIAG = 1u << 3,         // Q and R are diagonal (fast path)
+    F_DONE_OOB = 1u << 4,       // done_on_out_of_bound
+    F_DONE_VIOL = 1u << 5,      // done_on_violation
+    F_PENALTY = 1u << 6,        // use_constraint_penalty (rl_reward only)
+    F_RAND_INIT = 1u << 7,      // randomized_init
+    F_AUTO_RESET = 1u << 8,     // fused DummyVecEnv auto-reset
+    F_TRACKING = 1u << 9,       // Task.TRAJ_TRACKING
+    F_QUADRATIC = 1u << 10,     // Cost.QUADRATIC (else RL_REWARD)
+    F_EULER = 1u << 11,         // explicit Euler instead of RK4
+    F_REF_IN_LDS = 1u << 12,    // reference table staged in LDS (else read through L1/L2)
+};
+
+// Scalars: travel in the kernarg block (SGPRs).
+struct KParams {
+    uint32_t flags;
+    int32_t substeps;
+    int32_t ctrl_steps;
+    int32_t ref_rows;           // rows of the X_GOAL table (tracking)
+    int32_t obs_goal_horizon;
+    int32_t n_con_rows;         // total constraint rows (c_val planes)
+    uint32_t seed_lo, seed_hi;
+    int64_t env_base;
+    float h;                    // dt / substeps
+    // quadrotor
+    float inv_m, g;
+    float arm_s2;               // l / sqrt(2)
+    float gamma;                // KM / KF
+    float inv_ixx, inv_iyy, inv_izz;
+    float cxx, cyy, czz;        // (Izz-Iyy)/Ixx, (Ixx-Izz)/Iyy, (Iyy-Ixx)/Izz
+    float l_s2_iyy;             // l / sqrt(2) / Iyy  (2-D)
+    // motor map
+    float inv_nmotor_kf;        // 1 / (n_motor KF)
+    float nmotor_kf;            // n_motor KF
+    float pwm_scale, inv_pwm_scale, pwm_const, pwm_min, pwm_max;
+    // cartpole
+    float cp_l, cp_m, cp_inv_Mm, cp_ml, cp_g;
+    // action
+    float norm_act_scale, hover_thrust, action_scale;
+    float goal_tol2;
+    float constraint_penalty;
+    float cost_scale;           // -1 (rl_reward: rew = -dist) or -0.5 (quadratic: rew = -l/2 ... see w_state)
+};
+
+// Per-dimension constant vectors: live in device memory, read through a wave-uniform pointer with
+// scalar loads right where they are used (keeping them out of the kernarg block keeps them out of
+// the SGPR file for the whole kernel -- 100+ SGPRs of pressure otherwise).
+struct KTables {
+    float act_low[SCG_MAX_NU], act_high[SCG_MAX_NU];
+    float u_goal[SCG_MAX_NU];
+    float x_goal[SCG_MAX_NX];
+    // diagonal cost weights: rl_reward -> rew_state_weight / rew_act_weight (quadrotor.py:902-908);
+    // quadratic with diagonal Q, R -> diag(Q) / diag(R) (quadrotor.py:682)
+    float w_state[SCG_MAX_NX], w_act[SCG_MAX_NU];
+    float mse_w[SCG_MAX_NX];
+    float oob_low[SCG_MAX_NX], oob_high[SCG_MAX_NX];
+    float init_state[SCG_MAX_NX], init_lo[SCG_MAX_NX], init_span[SCG_MAX_NX];
+    // full Q / R (only read when F_Q_DIAG is clear)
+    float Q[SCG_MAX_NX * SCG_MAX_NX];
+    float R[SCG_MAX_NU * SCG_MAX_NU];
+};
+
+enum RowFlags : int32_t { RF_STRICT = 1, RF_HAS_TOL = 2 };
+
+struct BoundEntry {            // c = sign * v[dim] - b   (dim is implied by the grouping below)
+    float sign, b, tol;
+    int32_t out_row, flags;
+};
+struct DenseRow {              // c = coef . v - b
+    float coef[SCG_MAX_NV];
+    float b, tol;
+    int32_t out_row, flags;
+};
+struct QuadRow {               // c = v' P v - b
+    float P[SCG_MAX_NV * SCG_MAX_NV];
+    float b, tol;
+    int32_t out_row, flags;
+};
+
+// Compiled ConstraintList.  Bound entries (rows of +-I: BoundedConstraint / DefaultConstraint)
+// are grouped by the v-dimension they read, so the kernel indexes its register-resident v[]
+// with compile-time indices only.
+struct ConTable {
+    int32_t n_rows, n_bound, n_dense, n_quad;
+    int32_t n_state_dims;                       // nx: v[k] with k >= nx is the raw action
+    int32_t bound_start[SCG_MAX_NV + 1];
+    BoundEntry bound[SCG_MAX_CONSTRAINT_ROWS];
+    DenseRow dense[SCG_MAX_CONSTRAINT_ROWS];
+    QuadRow quad[SCG_MAX_QUADRATIC];
+};
+
+struct LaunchGeom {
+    int32_t block, grid, lds_bytes;
+};
+
+}  // namespace scg
+
+// Kernel launchers (scg_kernels.hip)
+namespace scg {
+LaunchGeom step_geometry(const KParams& p, int system, int64_t n, int num_cus);
+hipError_t launch_step(int system, const KParams& p, const scg_step_io& io, const KTables* tb,
+                       const ConTable* ct, const float* ref, int64_t n, int num_cus, hipStream_t s);
+hipError_t launch_reset(int system, const KParams& p, const KTables* tb, float* state, float* state_lo, int32_t* step_count,
+                        float* ep_return, int32_t* ep_length, float* obs, const uint8_t* mask,
+                        const float* reset_state, const float* ref, uint32_t reset_serial, int64_t ld,
+                        int64_t n, hipStream_t s);
+hipError_t launch_eval_constraints(int system, const ConTable* ct, const float* state, const float* action,
+                                   float* c_val, uint8_t* violation, int64_t ld, int64_t n, hipStream_t s);
+}  // namespace scg

@@ -1,0 +1,842 @@
+// Fused env.step() kernel for gfx950 (MI355X / CDNA4): one wavefront lane per environment.
+//
+// One launch = Quadrotor.step (quadrotor.py:507-558) + BenchmarkEnv.after_step
+// (benchmark_env.py:422-463) + the DummyVecEnv auto-reset (dummy_vec_env.py:34-49) +
+// VecRecordEpisodeStatistics.step_wait (record_episode_statistics.py:142-169) for N envs.
+// (file:line relative to /root/reference/safe_control_gym)
+//
+// Data layout: struct-of-arrays planes ([component][env]) so that every load/store of a
+// wavefront is one fully coalesced 256-byte transaction (64 lanes x 4 B).  All per-step
+// constants are wave-uniform: they arrive in the kernarg block / constant tables and are read
+// with scalar loads into SGPRs; the per-step reference table X_GOAL (indexed by each lane's own
+// step counter, since envs de-synchronise after auto-reset) is staged once per workgroup into
+// LDS.  Batch reductions (reward sum, done / violation counts, finished-episode returns) use
+// wavefront shuffles and one atomic per wave.  No MFMA: a 12-state ODE per lane has no
+// contraction worth a matrix core; the kernel is HBM-bandwidth bound.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "scg_device.h"
+
+namespace scg {
+
+constexpr int kBlock = 256;
+
+template <int SYS> struct Dim;
+template <> struct Dim<SCG_QUAD_1D> { static constexpr int NX = 2, NU = 1; };
+template <> struct Dim<SCG_QUAD_2D> { static constexpr int NX = 6, NU = 2; };
+template <> struct Dim<SCG_QUAD_3D> { static constexpr int NX = 12, NU = 4; };
+template <> struct Dim<SCG_CARTPOLE> { static constexpr int NX = 4, NU = 1; };
+
+// ------------------------------------------------------------------------------------------
+// math helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rcp_f(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32, 1 ulp
+__device__ __forceinline__ float sqrt_f(float x) { return __builtin_amdgcn_sqrtf(x); }    // v_sqrt_f32, 1 ulp
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+// Plane access with a wave-uniform base and a 32-bit per-lane BYTE offset: lowers to the
+// `global_load_dword v, v_off, s[base:base+1]` (saddr) form -- one VGPR of address for every plane
+// instead of a 64-bit VGPR pair per plane.  n <= 2^30 (checked on the host) keeps 4*i in 32 bits.
+template <class T>
+__device__ __forceinline__ T* uptr(T* p) {       // pin a wave-uniform pointer into SGPRs
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    typedef __attribute__((address_space(1))) T* global_ptr;   // keep it a global (not flat) pointer
+    return (T*)(global_ptr)(((uint64_t)hi << 32) | lo);
+}
+template <class T>
+__device__ __forceinline__ T ldp(const T* base, uint32_t boff) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + boff);
+}
+template <class T>
+__device__ __forceinline__ void stp(T* base, uint32_t boff, T v) {
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + boff) = v;
+}
+
+// sin and cos together.  Cody-Waite reduction by pi/2 (two fp32 pieces, each applied with one
+// exact-product FMA; the neglected third piece is 1.7e-15 per quadrant) followed by minimax
+// polynomials on [-pi/4, pi/4] fitted for this kernel (max abs error 9.3e-8 = 0.8 ulp(1) for
+// |x| <= 1000, measured against float64 sin/cos over 2e6 points: DESIGN.md section 5).
+// ~20 VALU ops for the pair instead of two libm calls with their slow-path range reduction.
+__device__ __forceinline__ void sincos_f(float x, float& s, float& c) {
+    const float kf = rintf(x * 0.636619772367581343f);          // x * 2/pi
+    const int k = (int)kf;
+    float r = fmaf(kf, -1.5707963705062866f, x);                // fl32(pi/2)
+    r = fmaf(kf, 4.371138828673793e-08f, r);                    // pi/2 - fl32(pi/2)
+    const float r2 = r * r;
+    // sin(r) = r + r^3 S(r2)
+    float ps = fmaf(r2, 2.716089966270374e-06f, -0.0001983909896807745f);
+    ps = fmaf(ps, r2, 0.008333329111337662f);
+    ps = fmaf(ps, r2, -0.1666666716337204f);
+    const float sr = fmaf(r * r2, ps, r);
+    // cos(r) = 1 - r2/2 + r2^2 C(r2)
+    float pc = fmaf(r2, 2.4417491658823565e-05f, -0.0013887188397347927f);
+    pc = fmaf(pc, r2, 0.04166664183139801f);
+    const float cr = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.0f));
+    const float ss = (k & 1) ? cr : sr;
+    const float cc = (k & 1) ? sr : cr;
+    s = (k & 2) ? -ss : ss;
+    c = ((k + 1) & 2) ? -cc : cc;
+}
+
+// Philox4x32-10 (Salmon et al., SC'11).  Counter layout shared with oracle/philox.py.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// nominal (+ uniform Philox offsets) reset state of env i -- quadrotor.py:478-493 with
+// benchmark_env.py:297-307 restricted to 'uniform' draws.
+template <int NX>
+__device__ __forceinline__ void reset_state_of(const KParams& p, const KTables* __restrict__ tb,
+                                               const float* __restrict__ reset_state, int64_t ld, uint32_t i,
+                                               uint32_t serial, float (&x)[NX]) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) x[j] = reset_state ? ldp(uptr(reset_state + j * ld), i * 4u) : tb->init_state[j];
+    if (p.flags & F_RAND_INIT) {
+        const uint64_t g = (uint64_t)(p.env_base + (int64_t)i);
+#pragma unroll
+        for (int b = 0; b < (NX + 3) / 4; ++b) {
+            uint32_t w[4];
+            philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), serial, (uint32_t)b, p.seed_lo, p.seed_hi, w);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int d = 4 * b + q;
+                if (d < NX) {
+                    const float u = (float)(w[q] >> 8) * 5.9604644775390625e-8f;   // 2^-24
+                    x[d] += fmaf(tb->init_span[d], u, tb->init_lo[d]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// continuous dynamics  x_dot = f(x, u)   (quadrotor.py:594-676; cartpole: DESIGN.md A16)
+// ------------------------------------------------------------------------------------------
+template <int SYS> struct Inputs;
+
+template <> struct Inputs<SCG_QUAD_1D> { float acc; };                       // T/m - g (+ Fz/m)
+template <> struct Inputs<SCG_QUAD_2D> { float Tm, ax, az, thdd; };
+template <> struct Inputs<SCG_QUAD_3D> { float Tm, ax, ay, az, mx, my, mz; };
+template <> struct Inputs<SCG_CARTPOLE> { float F; };
+
+template <int SYS>
+__device__ __forceinline__ void make_inputs(const KParams& p, const float* u, float fx, float fy, float fz,
+                                            Inputs<SYS>& in);
+
+template <>
+__device__ __forceinline__ void make_inputs<SCG_QUAD_1D>(const KParams& p, const float* u, float fx, float fy,
+                                                         float fz, Inputs<SCG_QUAD_1D>& in) {
+    in.acc = fmaf(u[0] + fz, p.inv_m, -p.g);                                // quadrotor.py:602
+}
+template <>
+__device__ __forceinline__ void make_inputs<SCG_QUAD_2D>(const KParams& p, const float* u, float fx, float fy,
+                                                         float fz, Inputs<SCG_QUAD_2D>& in) {
+    in.Tm = (u[0] + u[1]) * p.inv_m;                                        // quadrotor.py:619-620
+    in.ax = fx * p.inv_m;
+    in.az = fmaf(fz, p.inv_m, -p.g);
+    in.thdd = p.l_s2_iyy * (u[1] - u[0]);                                   // quadrotor.py:621
+}
+template <>
+__device__ __forceinline__ void make_inputs<SCG_QUAD_3D>(const KParams& p, const float* u, float fx, float fy,
+                                                         float fz, Inputs<SCG_QUAD_3D>& in) {
+    in.Tm = ((u[0] + u[1]) + (u[2] + u[3])) * p.inv_m;                      // quadrotor.py:664
+    in.ax = fx * p.inv_m;
+    in.ay = fy * p.inv_m;
+    in.az = fmaf(fz, p.inv_m, -p.g);
+    in.mx = p.arm_s2 * ((u[0] + u[1]) - (u[2] + u[3])) * p.inv_ixx;         // quadrotor.py:667
+    in.my = p.arm_s2 * ((u[1] + u[2]) - (u[0] + u[3])) * p.inv_iyy;         // quadrotor.py:668
+    in.mz = p.gamma * ((u[0] + u[2]) - (u[1] + u[3])) * p.inv_izz;          // quadrotor.py:669
+}
+template <>
+__device__ __forceinline__ void make_inputs<SCG_CARTPOLE>(const KParams& p, const float* u, float fx, float fy,
+                                                          float fz, Inputs<SCG_CARTPOLE>& in) {
+    in.F = u[0] + fx;
+}
+
+template <int SYS>
+__device__ __forceinline__ void f_eval(const KParams& p, const Inputs<SYS>& in,
+                                       const float (&x)[Dim<SYS>::NX], float (&d)[Dim<SYS>::NX]);
+
+template <>
+__device__ __forceinline__ void f_eval<SCG_QUAD_1D>(const KParams& p, const Inputs<SCG_QUAD_1D>& in,
+                                                    const float (&x)[2], float (&d)[2]) {
+    d[0] = x[1];
+    d[1] = in.acc;
+}
+
+template <>
+__device__ __forceinline__ void f_eval<SCG_QUAD_2D>(const KParams& p, const Inputs<SCG_QUAD_2D>& in,
+                                                    const float (&x)[6], float (&d)[6]) {
+    float s, c;
+    sincos_f(x[4], s, c);
+    d[0] = x[1];
+    d[1] = fmaf(s, in.Tm, in.ax);
+    d[2] = x[3];
+    d[3] = fmaf(c, in.Tm, in.az);
+    d[4] = x[5];
+    d[5] = in.thdd;
+}
+
+template <>
+__device__ __forceinline__ void f_eval<SCG_QUAD_3D>(const KParams& p, const Inputs<SCG_QUAD_3D>& in,
+                                                    const float (&x)[12], float (&d)[12]) {
+    float sph, cph, sth, cth, sps, cps;
+    sincos_f(x[6], sph, cph);
+    sincos_f(x[7], sth, cth);
+    sincos_f(x[8], sps, cps);
+    const float P = x[9], Q = x[10], R = x[11];
+    // third column of R = Rz(psi) Ry(theta) Rx(phi)  (transformations.py:125-182)
+    const float sthcph = sth * cph;
+    d[0] = x[1];
+    d[1] = fmaf(fmaf(cps, sthcph, sps * sph), in.Tm, in.ax);
+    d[2] = x[3];
+    d[3] = fmaf(fmaf(sps, sthcph, -(cps * sph)), in.Tm, in.ay);
+    d[4] = x[5];
+    d[5] = fmaf(cth * cph, in.Tm, in.az);
+    // Euler-angle rates (quadrotor.py:671-673)
+    const float rcth = rcp_f(cth);
+    const float w = fmaf(sph, Q, cph * R);               // sin(phi) q + cos(phi) r
+    d[6] = fmaf(sth * rcth, w, P);
+    d[7] = fmaf(cph, Q, -(sph * R));
+    d[8] = w * rcth;
+    // body rates: Jinv (Mb - w x J w)  (quadrotor.py:670)
+    d[9] = fmaf(-p.cxx, Q * R, in.mx);
+    d[10] = fmaf(-p.cyy, R * P, in.my);
+    d[11] = fmaf(-p.czz, P * Q, in.mz);
+}
+
+template <>
+__device__ __forceinline__ void f_eval<SCG_CARTPOLE>(const KParams& p, const Inputs<SCG_CARTPOLE>& in,
+                                                     const float (&x)[4], float (&d)[4]) {
+    float s, c;
+    sincos_f(x[2], s, c);
+    const float thd = x[3];
+    const float tmp = fmaf(p.cp_ml * thd * thd, s, in.F) * p.cp_inv_Mm;
+    const float den = p.cp_l * fmaf(-p.cp_m * p.cp_inv_Mm, c * c, 4.0f / 3.0f);
+    const float thdd = fmaf(p.cp_g, s, -(c * tmp)) * rcp_f(den);
+    d[0] = x[1];
+    d[1] = fmaf(-p.cp_ml * p.cp_inv_Mm, thdd * c, tmp);
+    d[2] = thd;
+    d[3] = thdd;
+}
+
+// One fixed step; returns the increment (so the caller can add it with compensation).
+template <int SYS>
+__device__ __forceinline__ void integrate(const KParams& p, const Inputs<SYS>& in,
+                                          const float (&x)[Dim<SYS>::NX], float (&inc)[Dim<SYS>::NX]) {
+    constexpr int NX = Dim<SYS>::NX;
+    const float h = p.h;
+    float k[NX];
+    f_eval<SYS>(p, in, x, k);
+    if (p.flags & F_EULER) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) inc[j] = h * k[j];
+        return;
+    }
+    // RK4, zero-order-hold input (controllers/mpc/mpc_utils.py:93-97)
+    float xt[NX], acc[NX];
+    const float hh = 0.5f * h;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) { acc[j] = k[j]; xt[j] = fmaf(hh, k[j], x[j]); }
+    f_eval<SYS>(p, in, xt, k);
+#pragma unroll
+    for (int j = 0; j < NX; ++j) { acc[j] = fmaf(2.0f, k[j], acc[j]); xt[j] = fmaf(hh, k[j], x[j]); }
+    f_eval<SYS>(p, in, xt, k);
+#pragma unroll
+    for (int j = 0; j < NX; ++j) { acc[j] = fmaf(2.0f, k[j], acc[j]); xt[j] = fmaf(h, k[j], x[j]); }
+    f_eval<SYS>(p, in, xt, k);
+    const float h6 = h * (1.0f / 6.0f);
+#pragma unroll
+    for (int j = 0; j < NX; ++j) inc[j] = h6 * (acc[j] + k[j]);
+}
+
+// ------------------------------------------------------------------------------------------
+// constraints: c = g([state ; raw action])   (constraints.py:106-119,226-304)
+// ------------------------------------------------------------------------------------------
+struct ConFlags { bool violated, almost; };
+
+template <int NV, bool ONLY_STATE>
+__device__ __forceinline__ ConFlags eval_constraints(const ConTable* __restrict__ ct, const float (&v)[NV],
+                                                     float* __restrict__ c_val, int64_t ld, uint32_t i) {
+    ConFlags f{false, false};
+    const uint32_t i4 = i * 4u;
+    const int nxs = ct->n_state_dims;
+    // (a) bound rows, grouped by the dimension they read: compile-time register index k.
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int e0 = ct->bound_start[k], e1 = ct->bound_start[k + 1];
+        for (int e = e0; e < e1; ++e) {
+            const BoundEntry& be = ct->bound[e];
+            float c = fmaf(be.sign, v[k], -be.b);
+            if (ONLY_STATE && k >= nxs) c = __builtin_nanf("");
+            if (c_val) stp(uptr(c_val + (int64_t)be.out_row * ld), i4, c);
+            f.violated |= (be.flags & RF_STRICT) ? (c >= 0.0f) : (c > 0.0f);
+            if (be.flags & RF_HAS_TOL) f.almost |= (c + be.tol > 0.0f);
+        }
+    }
+    // (b) general linear rows: dense dot product with wave-uniform coefficients.
+    for (int r = 0; r < ct->n_dense; ++r) {
+        const DenseRow& dr = ct->dense[r];
+        float c = -dr.b;
+        bool uses_input = false;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            c = fmaf(dr.coef[k], v[k], c);
+            if (ONLY_STATE && k >= nxs && dr.coef[k] != 0.0f) uses_input = true;
+        }
+        if (ONLY_STATE && uses_input) c = __builtin_nanf("");
+        if (c_val) stp(uptr(c_val + (int64_t)dr.out_row * ld), i4, c);
+        f.violated |= (dr.flags & RF_STRICT) ? (c >= 0.0f) : (c > 0.0f);
+        if (dr.flags & RF_HAS_TOL) f.almost |= (c + dr.tol > 0.0f);
+    }
+    // (c) quadratic rows v' P v - b.
+    for (int r = 0; r < ct->n_quad; ++r) {
+        const QuadRow& qr = ct->quad[r];
+        float c = -qr.b;
+#pragma unroll
+        for (int a = 0; a < NV; ++a) {
+            float t = 0.0f;
+#pragma unroll
+            for (int b = 0; b < NV; ++b) t = fmaf(qr.P[a * SCG_MAX_NV + b], v[b], t);
+            c = fmaf(v[a], t, c);
+        }
+        if (c_val) stp(uptr(c_val + (int64_t)qr.out_row * ld), i4, c);
+        f.violated |= (qr.flags & RF_STRICT) ? (c >= 0.0f) : (c > 0.0f);
+        if (qr.flags & RF_HAS_TOL) f.almost |= (c + qr.tol > 0.0f);
+    }
+    return f;
+}
+
+// ------------------------------------------------------------------------------------------
+// wavefront reduction (64 lanes) -> one atomic per wave
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// goal row for a lane-local step index; read from the LDS-staged table when it is staged.
+template <int NX>
+__device__ __forceinline__ void load_goal(const KParams& p, const float* __restrict__ ref_glb, int row,
+                                          float (&g)[NX]) {
+    extern __shared__ __align__(16) float s_ref[];
+    row = min(max(row, 0), p.ref_rows - 1);
+    if (p.flags & F_REF_IN_LDS) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) g[j] = s_ref[row * NX + j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) g[j] = ref_glb[row * NX + j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// the fused step kernel
+// ------------------------------------------------------------------------------------------
+// Addressing: the env index is a 32-bit lane value and every plane base (array + j*ld) is
+// wave-uniform, so each access is `global_load_dword v, v_off, s[base:base+1]` -- one VGPR of
+// address for all ~30 planes instead of a 64-bit VGPR pair per plane.
+#define PL(ptr, j) uptr((ptr) + (int64_t)(j) * ld)
+
+// Compile-time feature tiers.  Every optional part of step() is wave-uniform, but leaving all
+// of them as run-time branches costs ~200 scalar branches, 300+ spilled SGPRs and 160 VGPRs
+// (2-3 waves/SIMD).  The launcher picks the smallest instantiation that covers the call.
+enum Feat : uint32_t {
+    FT_TRACK = 1u,   // Task.TRAJ_TRACKING: LDS-staged X_GOAL table (else the constant stabilisation goal)
+    FT_CON = 2u,     // a ConstraintList is attached
+    FT_EXTRA = 4u,   // everything else: disturbance planes, separate obs buffer (+noise, +goal horizon),
+                     // mse / goal_reached / truncated / terminal_obs / last_ep_* / stats outputs,
+                     // non-diagonal Q or R, normalised action space.  In this tier FT_TRACK / FT_CON
+                     // are run-time decisions again.
+};
+
+template <int SYS, bool COMP, uint32_t FT>
+__global__ __launch_bounds__(kBlock) void scg_step_kernel(const KParams p, const scg_step_io io,
+                                                          const KTables* __restrict__ tb,
+                                                          const ConTable* __restrict__ ct,
+                                                          const float* __restrict__ ref, const uint32_t n) {
+    constexpr int NX = Dim<SYS>::NX, NU = Dim<SYS>::NU, NV = NX + NU;
+    constexpr bool EXTRA = (FT & FT_EXTRA) != 0;
+    extern __shared__ __align__(16) float s_ref[];
+
+    const bool tracking = EXTRA ? ((p.flags & F_TRACKING) != 0) : ((FT & FT_TRACK) != 0);
+    const bool has_con = EXTRA ? (p.n_con_rows > 0) : ((FT & FT_CON) != 0);
+
+    if (tracking && (p.flags & F_REF_IN_LDS)) {
+        // stage X_GOAL (quadrotor.py:280-325) once per workgroup; rows*NX floats, 16-B vector copies
+        const int total4 = (p.ref_rows * NX + 3) >> 2;                      // buffer is padded to 16 B
+        const float4* src4 = reinterpret_cast<const float4*>(ref);
+        float4* dst4 = reinterpret_cast<float4*>(s_ref);
+        for (int e = threadIdx.x; e < total4; e += kBlock) dst4[e] = src4[e];
+        __syncthreads();
+    }
+
+    const int64_t ld = io.ld;
+    float st_rew = 0.f, st_done = 0.f, st_viol = 0.f, st_fret = 0.f, st_flen = 0.f, st_trunc = 0.f;
+
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const uint32_t i4 = i * 4u;
+        // ---- loads (issued together: NX+NU+1 independent 256-B wave transactions in flight)
+        float x[NX], a_raw[NU];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) x[j] = ldp(PL(io.state, j), i4);
+#pragma unroll
+        for (int j = 0; j < NU; ++j) a_raw[j] = ldp(PL(io.action, j), i4);
+        const int t = ldp(io.step_count, i4);                               // ctrl_step_counter (pre-increment)
+        float xlo[NX];
+        if (COMP) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) xlo[j] = ldp(PL(io.state_lo, j), i4);
+        }
+        float epr = 0.f; int epl = 0;
+        if (io.ep_return) epr = ldp(io.ep_return, i4);
+        if (io.ep_length) epl = ldp(io.ep_length, i4);
+        float fx = 0.f, fy = 0.f, fz = 0.f;
+        if (EXTRA && io.dynamics_force) {
+            fx = ldp(PL(io.dynamics_force, 0), i4); fy = ldp(PL(io.dynamics_force, 1), i4);
+            fz = ldp(PL(io.dynamics_force, 2), i4);
+        }
+
+        // ---- before_step / _preprocess_control (benchmark_env.py:394-404, quadrotor.py:815-842)
+        float a_clip[NU], u[NU];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            float a = clampf(a_raw[j], tb->act_low[j], tb->act_high[j]);
+            if (EXTRA && (p.flags & F_NORMALIZED)) {
+                if (SYS == SCG_CARTPOLE) a *= p.action_scale;
+                else a = fmaf(p.norm_act_scale, a, 1.0f) * p.hover_thrust;  // quadrotor.py:828
+            }
+            a_clip[j] = a;                                                  // current_preprocessed_action (:833)
+            float th = a;
+            if (EXTRA && io.action_disturbance) th += ldp(PL(io.action_disturbance, j), i4);   // :835-838
+            if (SYS != SCG_CARTPOLE && (p.flags & F_MOTOR_MAP)) {
+                // cmd2pwm / pwm2rpm / KF rpm^2  (quadrotor_utils.py:38-50,66; base_aviary.py:420)
+                float pwm = (sqrt_f(fmaxf(th, 0.0f) * p.inv_nmotor_kf) - p.pwm_const) * p.inv_pwm_scale;
+                pwm = clampf(pwm, p.pwm_min, p.pwm_max);
+                const float rpm = fmaf(p.pwm_scale, pwm, p.pwm_const);
+                th = p.nmotor_kf * rpm * rpm;
+            }
+            u[j] = th;
+        }
+
+        // ---- _advance_simulation replaced by fixed-step integration of the prior model
+        Inputs<SYS> in;
+        make_inputs<SYS>(p, u, fx, fy, fz, in);
+        for (int s = 0; s < p.substeps; ++s) {
+            float inc[NX];
+            integrate<SYS>(p, in, x, inc);
+            if (COMP) {
+                // compensated accumulation: (x + xlo) += inc with an error-free TwoSum
+#pragma unroll
+                for (int j = 0; j < NX; ++j) {
+                    const float sum = x[j] + inc[j];
+                    const float bb = sum - x[j];
+                    const float err = (x[j] - (sum - bb)) + (inc[j] - bb);
+                    const float lo = xlo[j] + err;
+                    const float hi = sum + lo;
+                    xlo[j] = lo - (hi - sum);
+                    x[j] = hi;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NX; ++j) x[j] += inc[j];
+            }
+        }
+
+        // ---- error to the goal of this step: X_GOAL (stabilisation) or X_GOAL[min(t, T-1)]
+        //      (quadrotor.py:905,1021; the quadratic cost's unclamped X_GOAL[t] (:926) is the same row
+        //      because t < CTRL_STEPS <= rows)
+        float e[NX];
+        if (tracking) {
+            load_goal<NX>(p, ref, t, e);
+#pragma unroll
+            for (int j = 0; j < NX; ++j) e[j] = x[j] - e[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) e[j] = x[j] - tb->x_goal[j];
+        }
+
+        // ---- _get_info: mse (quadrotor.py:1015-1025)
+        if (EXTRA && io.mse) {
+            float m = 0.f;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) { const float w = e[j] * tb->mse_w[j]; m = fmaf(w, w, m); }
+            stp(io.mse, i4, m);
+        }
+
+        // ---- _get_done (quadrotor.py:956-993)
+        bool done = false, goal_reached = false;
+        if (!tracking && (p.flags & F_QUADRATIC)) {
+            float d2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) d2 = fmaf(e[j], e[j], d2);
+            goal_reached = d2 < p.goal_tol2;                                // ||x - X_GOAL|| < tol (:965)
+            done = goal_reached;
+        }
+        if (p.flags & F_DONE_OOB) {
+            bool inb = true;                                                // NaN compares false -> out of bounds
+#pragma unroll
+            for (int j = 0; j < NX; ++j) inb &= (x[j] >= tb->oob_low[j]) & (x[j] <= tb->oob_high[j]);
+            done |= !inb;
+        }
+        if (EXTRA && io.goal_reached) stp(io.goal_reached, i, (uint8_t)(goal_reached ? 1 : 0));
+
+        // ---- _get_reward (quadrotor.py:886-930)
+        float rew;
+        {
+            float ea[NU];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) ea[j] = a_clip[j] - tb->u_goal[j];
+            float l = 0.f;
+            if (!EXTRA || (p.flags & F_Q_DIAG)) {
+                // rl_reward: sum w_s e^2 + sum w_a ea^2 (:902-908); quadratic with diagonal Q, R (:682)
+#pragma unroll
+                for (int j = 0; j < NX; ++j) l = fmaf(tb->w_state[j] * e[j], e[j], l);
+#pragma unroll
+                for (int j = 0; j < NU; ++j) l = fmaf(tb->w_act[j] * ea[j], ea[j], l);
+            } else {
+#pragma unroll
+                for (int a = 0; a < NX; ++a) {
+                    float tq = 0.f;
+#pragma unroll
+                    for (int b = 0; b < NX; ++b) tq = fmaf(tb->Q[a * SCG_MAX_NX + b], e[b], tq);
+                    l = fmaf(e[a], tq, l);
+                }
+#pragma unroll
+                for (int a = 0; a < NU; ++a) {
+                    float tr = 0.f;
+#pragma unroll
+                    for (int b = 0; b < NU; ++b) tr = fmaf(tb->R[a * SCG_MAX_NU + b], ea[b], tr);
+                    l = fmaf(ea[a], tr, l);
+                }
+            }
+            rew = p.cost_scale * l;                                         // -dist (:909) or -l/2 (:682,918-930)
+            if (!(p.flags & F_QUADRATIC) && (p.flags & F_REW_EXP)) rew = expf(rew);   // :911-912
+        }
+
+        // ---- after_step (benchmark_env.py:422-463)
+        const int t1 = t + 1;
+        bool violated = false;
+        if (has_con) {
+            float v[NV];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) v[j] = x[j];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) v[NX + j] = a_raw[j];              // RAW action (constraints.py:167-168)
+            const ConFlags cf = eval_constraints<NV, false>(ct, v, io.constraint_values, ld, i);
+            violated = cf.violated;
+            if (violated && (p.flags & F_DONE_VIOL)) done = true;           // :444-445
+            if (!(p.flags & F_QUADRATIC) && (p.flags & F_PENALTY) && cf.almost)
+                rew += p.constraint_penalty;                                // :454-456
+            if (io.constraint_violation) stp(io.constraint_violation, i, (uint8_t)(violated ? 1 : 0));
+        }
+        bool truncated = false;
+        if (t1 >= p.ctrl_steps) { truncated = !done; done = true; }         // :460-462
+        if (EXTRA && io.truncated) stp(io.truncated, i, (uint8_t)(truncated ? 1 : 0));
+
+        // ---- VecRecordEpisodeStatistics (record_episode_statistics.py:144-160)
+        epr += rew;
+        epl += 1;
+
+        stp(io.reward, i4, rew);
+        stp(io.done, i, (uint8_t)(done ? 1 : 0));
+
+        if (EXTRA && io.stats) {
+            st_rew += rew; st_done += done ? 1.f : 0.f; st_viol += violated ? 1.f : 0.f;
+            st_trunc += truncated ? 1.f : 0.f;
+            if (done) { st_fret += epr; st_flen += (float)epl; }
+        }
+
+        // ---- auto-reset (dummy_vec_env.py:41-47): returned obs is the reset obs; the terminal one is stashed
+        int t_out = t1;
+        if (done) {
+            if (EXTRA) {
+                if (io.terminal_obs) {
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) stp(PL(io.terminal_obs, j), i4, x[j]);
+                }
+                if (io.last_ep_return) stp(io.last_ep_return, i4, epr);
+                if (io.last_ep_length) stp(io.last_ep_length, i4, epl);
+            }
+            if (p.flags & F_AUTO_RESET) {
+                reset_state_of<NX>(p, tb, io.reset_state, ld, i, io.reset_serial, x);
+                if (COMP) {
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) xlo[j] = 0.f;
+                }
+                t_out = 0;
+                epr = 0.f; epl = 0;
+            }
+        }
+
+        // ---- stores
+#pragma unroll
+        for (int j = 0; j < NX; ++j) stp(PL(io.state, j), i4, x[j]);
+        if (COMP) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) stp(PL(io.state_lo, j), i4, xlo[j]);
+        }
+        stp(io.step_count, i4, t_out);
+        if (io.ep_return) stp(io.ep_return, i4, epr);
+        if (io.ep_length) stp(io.ep_length, i4, epl);
+
+        // ---- _get_observation + extend_obs (quadrotor.py:878-884, benchmark_env.py:406-420)
+        if (EXTRA && io.obs) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                float o = x[j];
+                if (io.obs_noise) o += ldp(PL(io.obs_noise, j), i4);
+                stp(PL(io.obs, j), i4, o);
+            }
+            if (p.obs_goal_horizon > 0) {
+                if (tracking) {
+                    // extend_obs(obs, ctrl_step_counter + 1) is evaluated before the counter increment:
+                    // rows min(t + 1 + k, T-1); a lane that auto-reset reports the reset observation, whose
+                    // counter is 0: rows min(1 + k, T-1) (quadrotor.py:883 via reset :497).
+                    const int base = (done && (p.flags & F_AUTO_RESET)) ? 1 : t + 1;
+                    for (int k = 0; k < p.obs_goal_horizon; ++k) {
+                        float g[NX];
+                        load_goal<NX>(p, ref, base + k, g);
+#pragma unroll
+                        for (int j = 0; j < NX; ++j) stp(PL(io.obs, NX * (1 + k) + j), i4, g[j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) stp(PL(io.obs, NX + j), i4, tb->x_goal[j]);
+                }
+            }
+        }
+    }
+
+    if (EXTRA && io.stats) {
+        st_rew = wave_sum(st_rew); st_done = wave_sum(st_done); st_viol = wave_sum(st_viol);
+        st_fret = wave_sum(st_fret); st_flen = wave_sum(st_flen); st_trunc = wave_sum(st_trunc);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&io.stats[0], (double)st_rew);
+            atomicAdd(&io.stats[1], (double)st_done);
+            atomicAdd(&io.stats[2], (double)st_viol);
+            atomicAdd(&io.stats[3], (double)st_fret);
+            atomicAdd(&io.stats[4], (double)st_flen);
+            atomicAdd(&io.stats[5], (double)st_trunc);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// reset kernel  (quadrotor.py:356-504 minus PyBullet; record_episode_statistics.py:132-140)
+// ------------------------------------------------------------------------------------------
+template <int SYS>
+__global__ __launch_bounds__(kBlock) void scg_reset_kernel(const KParams p, const KTables* __restrict__ tb,
+                                                           float* __restrict__ state,
+                                                           float* __restrict__ state_lo,
+                                                           int32_t* __restrict__ step_count,
+                                                           float* __restrict__ ep_return,
+                                                           int32_t* __restrict__ ep_length, float* __restrict__ obs,
+                                                           const uint8_t* __restrict__ mask,
+                                                           const float* __restrict__ reset_state,
+                                                           const float* __restrict__ ref, uint32_t serial,
+                                                           int64_t ld, uint32_t n) {
+    constexpr int NX = Dim<SYS>::NX;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const uint32_t i4 = i * 4u;
+        if (mask && !ldp(mask, i)) continue;
+        float x[NX];
+        reset_state_of<NX>(p, tb, reset_state, ld, i, serial, x);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) stp(PL(state, j), i4, x[j]);
+        if (state_lo) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) stp(PL(state_lo, j), i4, 0.f);
+        }
+        stp(step_count, i4, 0);
+        if (ep_return) stp(ep_return, i4, 0.f);
+        if (ep_length) stp(ep_length, i4, 0);
+        if (obs) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) stp(PL(obs, j), i4, x[j]);
+            if (p.obs_goal_horizon > 0) {
+                if (p.flags & F_TRACKING) {
+                    for (int k = 0; k < p.obs_goal_horizon; ++k) {
+                        const int row = min(1 + k, p.ref_rows - 1);         // extend_obs(obs, 0 + 1)
+#pragma unroll
+                        for (int j = 0; j < NX; ++j) stp(PL(obs, NX * (1 + k) + j), i4, ref[row * NX + j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) stp(PL(obs, NX + j), i4, tb->x_goal[j]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// stand-alone ConstraintList.get_values (constraints.py:503-520)
+// ------------------------------------------------------------------------------------------
+template <int SYS>
+__global__ __launch_bounds__(kBlock) void scg_constraints_kernel(const ConTable* __restrict__ ct,
+                                                                 const float* __restrict__ state,
+                                                                 const float* __restrict__ action,
+                                                                 float* __restrict__ c_val,
+                                                                 uint8_t* __restrict__ violation, int64_t ld,
+                                                                 uint32_t n) {
+    constexpr int NX = Dim<SYS>::NX, NU = Dim<SYS>::NU, NV = NX + NU;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const uint32_t i4 = i * 4u;
+        float v[NV];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) v[j] = ldp(PL(state, j), i4);
+#pragma unroll
+        for (int j = 0; j < NU; ++j) v[NX + j] = action ? ldp(PL(action, j), i4) : 0.f;
+        ConFlags cf = action ? eval_constraints<NV, false>(ct, v, c_val, ld, i)
+                             : eval_constraints<NV, true>(ct, v, c_val, ld, i);
+        if (violation) stp(violation, i, (uint8_t)(cf.violated ? 1 : 0));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static int nx_of(int system) {
+    switch (system) {
+        case SCG_QUAD_1D: return 2;
+        case SCG_QUAD_2D: return 6;
+        case SCG_QUAD_3D: return 12;
+        default: return 4;
+    }
+}
+
+LaunchGeom step_geometry(const KParams& p, int system, int64_t n, int num_cus) {
+    LaunchGeom g;
+    g.block = kBlock;
+    int64_t blocks = (n + kBlock - 1) / kBlock;
+    g.lds_bytes = 0;
+    if ((p.flags & F_TRACKING) && (p.flags & F_REF_IN_LDS)) {
+        g.lds_bytes = p.ref_rows * nx_of(system) * (int)sizeof(float);
+        g.lds_bytes = (g.lds_bytes + 15) & ~15;
+        // amortise the LDS fill: a few resident workgroups per CU, grid-stride over the envs
+        const int64_t cap = (int64_t)num_cus * 8;
+        if (blocks > cap) blocks = cap;
+    }
+    if (blocks < 1) blocks = 1;
+    if (blocks > 0x7fffffff) blocks = 0x7fffffff;
+    g.grid = (int)blocks;
+    return g;
+}
+
+// Which instantiation covers this call.
+static uint32_t features_needed(const KParams& p, const scg_step_io& io) {
+    const bool extra = io.action_disturbance || io.dynamics_force || io.obs_noise || io.obs || io.truncated ||
+                       io.goal_reached || io.mse || io.terminal_obs || io.last_ep_return || io.last_ep_length ||
+                       io.stats || (p.flags & F_NORMALIZED) || !(p.flags & F_Q_DIAG);
+    if (extra) return FT_TRACK | FT_CON | FT_EXTRA;
+    uint32_t ft = 0;
+    if (p.flags & F_TRACKING) ft |= FT_TRACK;
+    if (p.n_con_rows > 0) ft |= FT_CON;
+    return ft;
+}
+
+template <int SYS, bool COMP>
+static void launch_step_ft(uint32_t ft, const LaunchGeom& g, const KParams& p, const scg_step_io& io,
+                           const KTables* tb, const ConTable* ct, const float* ref, uint32_t n, hipStream_t s) {
+#define SCG_LAUNCH(FTV)                                                                                   \
+    hipLaunchKernelGGL((scg_step_kernel<SYS, COMP, (FTV)>), dim3(g.grid), dim3(g.block), g.lds_bytes, s, \
+                       p, io, tb, ct, ref, n)
+    switch (ft) {
+        case 0: SCG_LAUNCH(0u); break;
+        case FT_TRACK: SCG_LAUNCH(FT_TRACK); break;
+        case FT_CON: SCG_LAUNCH(FT_CON); break;
+        case FT_TRACK | FT_CON: SCG_LAUNCH(FT_TRACK | FT_CON); break;
+        default: SCG_LAUNCH(FT_TRACK | FT_CON | FT_EXTRA); break;
+    }
+#undef SCG_LAUNCH
+}
+
+template <int SYS>
+static void launch_step_sys(const LaunchGeom& g, const KParams& p, const scg_step_io& io, const KTables* tb,
+                            const ConTable* ct, const float* ref, uint32_t n, hipStream_t s) {
+    const uint32_t ft = features_needed(p, io);
+    if (io.state_lo) launch_step_ft<SYS, true>(ft, g, p, io, tb, ct, ref, n, s);
+    else launch_step_ft<SYS, false>(ft, g, p, io, tb, ct, ref, n, s);
+}
+
+hipError_t launch_step(int system, const KParams& p, const scg_step_io& io, const KTables* tb,
+                       const ConTable* ct, const float* ref, int64_t n, int num_cus, hipStream_t s) {
+    const LaunchGeom g = step_geometry(p, system, n, num_cus);
+    switch (system) {
+        case SCG_QUAD_1D: launch_step_sys<SCG_QUAD_1D>(g, p, io, tb, ct, ref, (uint32_t)n, s); break;
+        case SCG_QUAD_2D: launch_step_sys<SCG_QUAD_2D>(g, p, io, tb, ct, ref, (uint32_t)n, s); break;
+        case SCG_QUAD_3D: launch_step_sys<SCG_QUAD_3D>(g, p, io, tb, ct, ref, (uint32_t)n, s); break;
+        case SCG_CARTPOLE: launch_step_sys<SCG_CARTPOLE>(g, p, io, tb, ct, ref, (uint32_t)n, s); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_reset(int system, const KParams& p, const KTables* tb, float* state, float* state_lo,
+                        int32_t* step_count, float* ep_return, int32_t* ep_length, float* obs,
+                        const uint8_t* mask, const float* reset_state, const float* ref, uint32_t serial,
+                        int64_t ld, int64_t n64, hipStream_t s) {
+    const uint32_t n = (uint32_t)n64;
+    int64_t blocks = (n64 + kBlock - 1) / kBlock;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 65536) blocks = 65536;
+    dim3 grid((unsigned)blocks), block(kBlock);
+    switch (system) {
+        case SCG_QUAD_1D:
+            hipLaunchKernelGGL(scg_reset_kernel<SCG_QUAD_1D>, grid, block, 0, s, p, tb, state, state_lo, step_count, ep_return, ep_length, obs, mask, reset_state, ref, serial, ld, n);
+            break;
+        case SCG_QUAD_2D:
+            hipLaunchKernelGGL(scg_reset_kernel<SCG_QUAD_2D>, grid, block, 0, s, p, tb, state, state_lo, step_count, ep_return, ep_length, obs, mask, reset_state, ref, serial, ld, n);
+            break;
+        case SCG_QUAD_3D:
+            hipLaunchKernelGGL(scg_reset_kernel<SCG_QUAD_3D>, grid, block, 0, s, p, tb, state, state_lo, step_count, ep_return, ep_length, obs, mask, reset_state, ref, serial, ld, n);
+            break;
+        case SCG_CARTPOLE:
+            hipLaunchKernelGGL(scg_reset_kernel<SCG_CARTPOLE>, grid, block, 0, s, p, tb, state, state_lo, step_count, ep_return, ep_length, obs, mask, reset_state, ref, serial, ld, n);
+            break;
+        default:
+            return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_eval_constraints(int system, const ConTable* ct, const float* state, const float* action,
+                                   float* c_val, uint8_t* violation, int64_t ld, int64_t n64, hipStream_t s) {
+    const uint32_t n = (uint32_t)n64;
+    int64_t blocks = (n64 + kBlock - 1) / kBlock;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 65536) blocks = 65536;
+    dim3 grid((unsigned)blocks), block(kBlock);
+    switch (system) {
+        case SCG_QUAD_1D:
+            hipLaunchKernelGGL(scg_constraints_kernel<SCG_QUAD_1D>, grid, block, 0, s, ct, state, action, c_val, violation, ld, n);
+            break;
+        case SCG_QUAD_2D:
+            hipLaunchKernelGGL(scg_constraints_kernel<SCG_QUAD_2D>, grid, block, 0, s, ct, state, action, c_val, violation, ld, n);
+            break;
+        case SCG_QUAD_3D:
+            hipLaunchKernelGGL(scg_constraints_kernel<SCG_QUAD_3D>, grid, block, 0, s, ct, state, action, c_val, violation, ld, n);
+            break;
+        case SCG_CARTPOLE:
+            hipLaunchKernelGGL(scg_constraints_kernel<SCG_CARTPOLE>, grid, block, 0, s, ct, state, action, c_val, violation, ld, n);
+            break;
+        default:
+            return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace scg

@@ -1,0 +1,586 @@
+"""Batched, device-resident base environment -- host-side mirror of ``BenchmarkEnv``.
+
+Keeps the reference's constructor keywords, attribute names, exception types and
+``reset()`` / ``step()`` protocol (/root/reference/safe_control_gym/envs/benchmark_env.py:47-463) but
+represents ``num_envs`` independent environments at once: the state of all of them lives in
+struct-of-arrays PyTorch-ROCm tensors and one fused HIP kernel launch advances the whole batch
+(``csrc/scg_kernels.hip`` through the C ABI in ``include/scg_rollout.h``).
+
+What differs from the reference, by necessity of batching:
+  * ``step(action)`` takes ``[N, nu]`` and returns ``obs [N, obs_dim]``, ``rew [N]``, ``done [N]``
+    and an ``info`` dict whose values are ``[N, ...]`` tensors under the reference's key names
+    (``mse``, ``goal_reached``, ``constraint_values``, ``constraint_violation``,
+    ``TimeLimit.truncated``; plus the vector-env keys ``terminal_observation`` and ``episode``).
+    ``info['n'][i]`` materialises the reference's per-env dict lazily.
+  * environments auto-reset when done, as the reference's vector envs do
+    (env_wrappers/vectorized_env/dummy_vec_env.py:41-47); pass ``auto_reset=False`` for the plain
+    single-env behaviour.
+  * the physics is the reference's own prior model integrated with its own RK4,
+    not PyBullet; reset randomisation draws from a counter-based Philox stream, not MT19937.
+"""
+import math
+import os
+from enum import Enum
+
+import numpy as np
+import torch
+
+from safe_control_gym_amd import _capi
+from safe_control_gym_amd.envs.constraints import create_constraint_list
+from safe_control_gym_amd.envs.engine import Engine
+
+
+class Cost(str, Enum):
+    """benchmark_env.py:19-26."""
+    RL_REWARD = 'rl_reward'
+    QUADRATIC = 'quadratic'
+    COMPETITION = 'competition'     # needs contact / ray queries: not on the analytic hot path
+
+
+class Task(str, Enum):
+    """benchmark_env.py:29-35."""
+    STABILIZATION = 'stabilization'
+    TRAJ_TRACKING = 'traj_tracking'
+
+
+class Environment(str, Enum):
+    """benchmark_env.py:38-44."""
+    CARTPOLE = 'cartpole'
+    QUADROTOR = 'quadrotor'
+
+
+_INTEGRATORS = {'rk4': _capi.SCG_RK4, 'euler': _capi.SCG_EULER}
+# the reference's Physics enum values (base_aviary.py:34-43) all map to the analytic model here
+_PHYSICS_ALIASES = {'pyb': 'rk4', 'dyn': 'euler', 'pyb_gnd': 'rk4', 'pyb_drag': 'rk4', 'pyb_dw': 'rk4',
+                    'pyb_gnd_drag_dw': 'rk4', 'rk4': 'rk4', 'euler': 'euler'}
+
+
+class LazyInfoList:
+    """``info['n']``: the reference's tuple of per-env dicts (dummy_vec_env.py:49), built on demand."""
+
+    def __init__(self, info, done):
+        self._info, self._done = info, done
+
+    def __len__(self):
+        return int(self._done.shape[0])
+
+    def __getitem__(self, i):
+        info, out = self._info, {}
+        for k in ('mse', 'goal_reached', 'constraint_values', 'constraint_violation'):
+            if k in info:
+                v = info[k][i]
+                out[k] = v.cpu().numpy() if v.ndim else v.item()
+        done = bool(self._done[i])
+        if 'TimeLimit.truncated' in info and bool(info['TimeLimit.truncated'][i]):
+            out['TimeLimit.truncated'] = True       # benchmark_env.py:460-462 (key absent before the limit)
+        if done:
+            if 'terminal_observation' in info:
+                out['terminal_observation'] = info['terminal_observation'][i].cpu().numpy()
+            if 'episode' in info:
+                out['episode'] = {'r': float(info['episode']['r'][i]), 'l': float(info['episode']['l'][i])}
+        return out
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+class BenchmarkEnv:
+    """Batched base class.  Subclasses provide the system-specific pieces (spaces, constants)."""
+    _count = 0
+    NAME = 'base'
+    AVAILABLE_CONSTRAINTS = None
+    DISTURBANCE_MODES = None
+    INERTIAL_PROP_RAND_INFO = None
+    INIT_STATE_RAND_INFO = None
+    TASK_INFO = None
+    SYSTEM = None               # scg_system id
+
+    def __init__(self,
+                 output_dir=None, seed=None, info_in_reset=False, gui=False, verbose=False,
+                 normalized_rl_action_space=False,
+                 task=Task.STABILIZATION, task_info=None, cost=Cost.RL_REWARD,
+                 pyb_freq=50, ctrl_freq=50, episode_len_sec=5,
+                 init_state=None, randomized_init=True, init_state_randomization_info=None,
+                 prior_prop=None, inertial_prop=None, randomized_inertial_prop=False,
+                 inertial_prop_randomization_info=None,
+                 constraints=None, done_on_violation=False, use_constraint_penalty=False, constraint_penalty=-1,
+                 disturbances=None, adversary_disturbance=None, adversary_disturbance_offset=0.0,
+                 adversary_disturbance_scale=0.01,
+                 # ---- batched-engine arguments (new) ----
+                 num_envs=1, device='cuda', physics='rk4', integration_substeps=1, motor_map=True,
+                 auto_reset=True, info_level='full', compensated_state=False, track_episode_stats=True,
+                 env_index_base=0,
+                 **kwargs):
+        self.id = self.__class__._count
+        self.__class__._count += 1
+        self.output_dir = os.getcwd() if output_dir is None else output_dir
+        self.GUI, self.VERBOSE = gui, verbose
+        if gui:
+            raise ValueError('[ERROR] the batched engine has no GUI (gui=True is not supported).')
+        self.num_envs = int(num_envs)
+        if self.num_envs < 1:
+            raise ValueError('[ERROR] num_envs must be >= 1.')
+        self.device = torch.device(device)
+        self.TASK = Task(task)
+        if task_info is not None:
+            self.TASK_INFO = task_info
+        # timing constants (benchmark_env.py:151-161)
+        self.CTRL_FREQ, self.PYB_FREQ = ctrl_freq, pyb_freq
+        if self.PYB_FREQ % self.CTRL_FREQ != 0:
+            raise ValueError('[ERROR] in BenchmarkEnv.__init__(), pyb_freq is not divisible by env_freq.')
+        self.PYB_STEPS_PER_CTRL = int(self.PYB_FREQ / self.CTRL_FREQ)
+        self.CTRL_TIMESTEP = 1. / self.CTRL_FREQ
+        self.PYB_TIMESTEP = 1. / self.PYB_FREQ
+        self.EPISODE_LEN_SEC = episode_len_sec
+        self.CTRL_STEPS = self.EPISODE_LEN_SEC * self.CTRL_FREQ
+        # integrator selection
+        phys = str(getattr(physics, 'value', physics)).lower()
+        if phys not in _PHYSICS_ALIASES:
+            raise ValueError('[ERROR] unknown physics %r (use rk4 | euler, or a reference Physics value).' % physics)
+        self.PHYSICS = phys
+        self.INTEGRATOR = _PHYSICS_ALIASES[phys]
+        if integration_substeps == 'pyb':
+            integration_substeps = self.PYB_STEPS_PER_CTRL
+        self.INTEGRATION_SUBSTEPS = int(integration_substeps)
+        self.MOTOR_MAP = bool(motor_map)
+        self.AUTO_RESET = bool(auto_reset)
+        if info_level not in ('full', 'minimal'):
+            raise ValueError("[ERROR] info_level must be 'full' or 'minimal'.")
+        self.INFO_LEVEL = info_level
+        self.COMPENSATED_STATE = bool(compensated_state)
+        self.TRACK_EPISODE_STATS = bool(track_episode_stats)
+        self.ENV_INDEX_BASE = int(env_index_base)
+        # initial state / randomisation
+        self.INIT_STATE = init_state
+        self.RANDOMIZED_INIT = randomized_init
+        if init_state_randomization_info is not None:
+            self.INIT_STATE_RAND_INFO = init_state_randomization_info
+        self.PRIOR_PROP = prior_prop
+        self.INERTIAL_PROP = inertial_prop
+        self.RANDOMIZED_INERTIAL_PROP = randomized_inertial_prop
+        if randomized_inertial_prop:
+            raise NotImplementedError('[ERROR] randomized_inertial_prop: per-env inertial randomisation is a '
+                                      '"next" row of the scope table (SURVEY.md 8f rank 3).')
+        if inertial_prop_randomization_info is not None:
+            self.INERTIAL_PROP_RAND_INFO = inertial_prop_randomization_info
+        self.NORMALIZED_RL_ACTION_SPACE = normalized_rl_action_space
+        self.COST = Cost(cost)
+        if self.COST == Cost.COMPETITION:
+            raise NotImplementedError('[ERROR] cost=competition needs PyBullet contact/ray queries (out of scope).')
+        self._set_action_space()
+        self._set_observation_space()
+        self.action_dim = self.action_space.shape[0]
+        self.obs_dim = self.observation_space.shape[0]
+        self.state_dim = self.state_space.shape[0] if hasattr(self, 'state_space') else self.obs_dim
+        if self.COST == Cost.QUADRATIC:
+            self.Q = np.eye(self.state_dim)          # benchmark_env.py:190-192 (obs == state for quadratic cost)
+            self.R = np.eye(self.action_dim)
+        self.CONSTRAINTS = constraints
+        self.DONE_ON_VIOLATION = done_on_violation
+        self.use_constraint_penalty = use_constraint_penalty
+        self.constraint_penalty = constraint_penalty
+        self._engine = None
+        self._setup_constraints()
+        self.DISTURBANCES = disturbances
+        self.adversary_disturbance = adversary_disturbance
+        self.adversary_disturbance_offset = adversary_disturbance_offset
+        self.adversary_disturbance_scale = adversary_disturbance_scale
+        self._setup_disturbances()
+        self.seed(seed)
+        self.initial_reset = False
+        self.INFO_IN_RESET = info_in_reset
+        self.RND_SEED = seed
+        self.RESEED_ON_RESET = kwargs.get('reseed_on_reset', False)
+        self._bufs = None
+        self._serial = 0
+        self.current_raw_input_action = None
+
+    # ------------------------------------------------------------------ seeding
+    def seed(self, seed=None):
+        """benchmark_env.py:220-235.  The device stream is Philox keyed by this seed; ``None`` draws one."""
+        if seed is None:
+            seed = int(np.random.SeedSequence().entropy % (2 ** 63))
+        self._seed = int(seed)
+        self.np_random = np.random.RandomState(self._seed % (2 ** 32))
+        self.action_space.seed(self._seed % (2 ** 32))
+        for disturbs in getattr(self, 'disturbances', {}).values():
+            disturbs.seed(self)
+        self._engine_dirty = True
+        return [seed]
+
+    def set_cost_function_param(self, Q, R):
+        """benchmark_env.py:237-254."""
+        if not self.initial_reset:
+            self.Q = np.asarray(Q, dtype=np.float64)
+            self.R = np.asarray(R, dtype=np.float64)
+            self._engine_dirty = True
+        else:
+            raise RuntimeError('[ERROR] env.set_cost_function_param() cannot be called after the first reset of the environment.')
+
+    def set_adversary_control(self, action):
+        """benchmark_env.py:256-266."""
+        if self.adversary_disturbance is not None:
+            a = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(self.num_envs, -1)
+            a = a.clamp(-1.0, 1.0)
+            self.adv_action = a * self.adversary_disturbance_scale + self.adversary_disturbance_offset
+        else:
+            raise RuntimeError('[ERROR] adversary_disturbance does not exist, env.set_adversary_control() cannot be called.')
+
+    def _check_initial_reset(self):
+        if not self.initial_reset:
+            raise RuntimeError('[ERROR] You must call env.reset() at least once before using env.step().')
+
+    # ------------------------------------------------------------------ setup hooks
+    def _setup_disturbances(self):
+        """benchmark_env.py:314-330."""
+        from safe_control_gym_amd.envs.disturbances import create_disturbance_list
+        self.disturbances = {}
+        if self.DISTURBANCES is not None:
+            for mode, specs in self.DISTURBANCES.items():
+                assert mode in self.DISTURBANCE_MODES, '[ERROR] in BenchmarkEnv._setup_disturbances(), disturbance mode not available.'
+                self.disturbances[mode] = create_disturbance_list(specs, self.DISTURBANCE_MODES[mode], self)
+        self.adv_action = None
+        if self.adversary_disturbance is not None:
+            assert self.adversary_disturbance in self.DISTURBANCE_MODES, '[ERROR] in _setup_disturbances()'
+            from safe_control_gym_amd.envs.spaces import Box
+            dim = self.DISTURBANCE_MODES[self.adversary_disturbance]['dim']
+            self.adversary_action_space = Box(low=-np.ones(dim), high=np.ones(dim))
+            self.adversary_observation_space = self.observation_space
+
+    def _setup_constraints(self):
+        """benchmark_env.py:332-338."""
+        self.constraints = None
+        self.num_constraints = 0
+        if self.CONSTRAINTS is not None:
+            self.constraints = create_constraint_list(self.CONSTRAINTS, self.AVAILABLE_CONSTRAINTS, self)
+            self.num_constraints = self.constraints.num_constraints
+
+    def _set_action_space(self):
+        raise NotImplementedError
+
+    def _set_observation_space(self):
+        raise NotImplementedError
+
+    def _fill_system_config(self, cfg):
+        """Subclass: physical constants, action bounds, goals, out-of-bound box, init state."""
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ engine
+    def _x_goal_table(self):
+        return np.asarray(self.X_GOAL, dtype=np.float64) if self.TASK == Task.TRAJ_TRACKING else None
+
+    def _make_engine(self, constraint_list=None):
+        cfg = _capi.ScgConfig()
+        cfg.struct_size = _capi.C.sizeof(_capi.ScgConfig)
+        cfg.abi_version = _capi.SCG_ABI_VERSION
+        cfg.system = self.SYSTEM
+        cfg.integrator = _INTEGRATORS[self.INTEGRATOR]
+        cfg.substeps = self.INTEGRATION_SUBSTEPS
+        cfg.task = _capi.SCG_TRAJ_TRACKING if self.TASK == Task.TRAJ_TRACKING else _capi.SCG_STABILIZATION
+        cfg.cost = _capi.SCG_QUADRATIC if self.COST == Cost.QUADRATIC else _capi.SCG_RL_REWARD
+        cfg.ctrl_steps = int(self.CTRL_STEPS)
+        cfg.dt = self.CTRL_TIMESTEP
+        cfg.normalized_action = int(bool(self.NORMALIZED_RL_ACTION_SPACE))
+        cfg.motor_map = int(self.MOTOR_MAP)
+        nx, nu = self.state_dim, self.action_dim
+        for j in range(nu):
+            cfg.act_low[j] = float(self.action_space.low[j])
+            cfg.act_high[j] = float(self.action_space.high[j])
+            cfg.u_goal[j] = float(self.U_GOAL[j])
+        if self.TASK == Task.STABILIZATION:
+            for j in range(nx):
+                cfg.x_goal[j] = float(self.X_GOAL[j])
+        sw = np.broadcast_to(np.asarray(self.rew_state_weight, dtype=np.float64), (nx,))
+        aw = np.broadcast_to(np.asarray(self.rew_act_weight, dtype=np.float64), (nu,))
+        for j in range(nx):
+            cfg.rew_state_weight[j] = float(sw[j])
+            cfg.mse_weight[j] = float(self.info_mse_metric_state_weight[j])
+        for j in range(nu):
+            cfg.rew_act_weight[j] = float(aw[j])
+        cfg.rew_exponential = int(bool(self.rew_exponential))
+        if self.COST == Cost.QUADRATIC:
+            Q = np.asarray(self.Q, dtype=np.float64).reshape(nx, nx)
+            R = np.asarray(self.R, dtype=np.float64).reshape(nu, nu)
+            for a in range(nx):
+                for b in range(nx):
+                    cfg.Q[a * _capi.SCG_MAX_NX + b] = float(Q[a, b])
+            for a in range(nu):
+                for b in range(nu):
+                    cfg.R[a * _capi.SCG_MAX_NU + b] = float(R[a, b])
+        cfg.done_on_out_of_bound = int(bool(self.done_on_out_of_bound))
+        cfg.done_on_violation = int(bool(self.DONE_ON_VIOLATION))
+        cfg.goal_tolerance = float(self.TASK_INFO['stabilization_goal_tolerance'])
+        cfg.use_constraint_penalty = int(bool(self.use_constraint_penalty))
+        cfg.constraint_penalty = float(self.constraint_penalty)
+        cfg.obs_goal_horizon = int(self.obs_goal_horizon)
+        cfg.randomized_init = int(bool(self.RANDOMIZED_INIT))
+        cfg.auto_reset = int(self.AUTO_RESET)
+        cfg.seed = self._seed & 0xFFFFFFFFFFFFFFFF
+        cfg.env_index_base = self.ENV_INDEX_BASE
+        self._fill_system_config(cfg)
+        return Engine(cfg, x_goal_table=self._x_goal_table(), constraint_list=constraint_list, device=self.device)
+
+    def _ensure_engine(self):
+        if self._engine is None or self._engine_dirty:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = self._make_engine(constraint_list=self.constraints)
+            self._engine_dirty = False
+        if self._bufs is None:
+            self._alloc_buffers()
+
+    def _alloc_buffers(self):
+        """SoA planes, padded to a multiple of 64 lanes so every plane starts 256-B aligned."""
+        n = self.num_envs
+        ld = self._ld = (n + 63) // 64 * 64
+        dev, f32 = self.device, torch.float32
+        nx, nu = self.state_dim, self.action_dim
+        b = {}
+        b['state'] = torch.zeros((nx, ld), dtype=f32, device=dev)
+        b['action'] = torch.zeros((nu, ld), dtype=f32, device=dev)
+        b['step_count'] = torch.zeros(ld, dtype=torch.int32, device=dev)
+        b['reward'] = torch.zeros(ld, dtype=f32, device=dev)
+        b['done'] = torch.zeros(ld, dtype=torch.uint8, device=dev)
+        if self.COMPENSATED_STATE:
+            b['state_lo'] = torch.zeros((nx, ld), dtype=f32, device=dev)
+        if self.TRACK_EPISODE_STATS:
+            b['ep_return'] = torch.zeros(ld, dtype=f32, device=dev)
+            b['ep_length'] = torch.zeros(ld, dtype=torch.int32, device=dev)
+        if self.constraints is not None:
+            b['constraint_values'] = torch.zeros((self.constraints.num_device_rows, ld), dtype=f32, device=dev)
+            b['constraint_violation'] = torch.zeros(ld, dtype=torch.uint8, device=dev)
+        if self.obs_dim != nx or 'observation' in self.disturbances:
+            b['obs'] = torch.zeros((self.obs_dim, ld), dtype=f32, device=dev)
+        if self.INFO_LEVEL == 'full':
+            b['mse'] = torch.zeros(ld, dtype=f32, device=dev)
+            b['truncated'] = torch.zeros(ld, dtype=torch.uint8, device=dev)
+            b['terminal_obs'] = torch.zeros((nx, ld), dtype=f32, device=dev)
+            if self.TASK == Task.STABILIZATION and self.COST == Cost.QUADRATIC:
+                b['goal_reached'] = torch.zeros(ld, dtype=torch.uint8, device=dev)
+            if self.TRACK_EPISODE_STATS:
+                b['last_ep_return'] = torch.zeros(ld, dtype=f32, device=dev)
+                b['last_ep_length'] = torch.zeros(ld, dtype=torch.int32, device=dev)
+        self._bufs = b
+        self._reset_state_buf = None
+
+    # ------------------------------------------------------------------ views
+    @property
+    def state(self):
+        """[N, nx] view of the SoA state planes (zero copy)."""
+        return self._bufs['state'][:, :self.num_envs].T
+
+    @property
+    def state_soa(self):
+        return self._bufs['state'][:, :self.num_envs]
+
+    @property
+    def action_buffer(self):
+        """[N, nu] view of the SoA action planes: write actions here to skip the transpose copy."""
+        return self._bufs['action'][:, :self.num_envs].T
+
+    @property
+    def ctrl_step_counter(self):
+        return self._bufs['step_count'][:self.num_envs]
+
+    @property
+    def pyb_step_counter(self):
+        return self.ctrl_step_counter * self.PYB_STEPS_PER_CTRL
+
+    @property
+    def episode_return(self):
+        return self._bufs['ep_return'][:self.num_envs]
+
+    @property
+    def episode_length(self):
+        return self._bufs['ep_length'][:self.num_envs]
+
+    def _raw_action_soa(self):
+        return self._bufs['action']
+
+    def set_init_states(self, init_states):
+        """Per-env nominal reset states [N, nx] (replaces the single ``init_state`` for every later reset)."""
+        t = torch.as_tensor(init_states, dtype=torch.float32, device=self.device)
+        if t.shape != (self.num_envs, self.state_dim):
+            raise ValueError('[ERROR] init_states must have shape (num_envs, state_dim).')
+        self._ensure_engine()
+        buf = torch.zeros((self.state_dim, self._ld), dtype=torch.float32, device=self.device)
+        buf[:, :self.num_envs] = t.T
+        self._reset_state_buf = buf
+
+    # ------------------------------------------------------------------ reset / step
+    def _obs_view(self):
+        src = self._bufs['obs'] if 'obs' in self._bufs else self._bufs['state']
+        return src[:, :self.num_envs].T
+
+    def reset(self, mask=None):
+        """(Re-)initialise all envs (or those where ``mask`` is set).  Returns obs or (obs, info)."""
+        if self.RESEED_ON_RESET:
+            self.seed(self.RND_SEED)
+        self._ensure_engine()
+        self.initial_reset = True
+        self.current_raw_input_action = None
+        for mode in self.disturbances:
+            self.disturbances[mode].reset(self)
+        if self.adversary_disturbance is not None:
+            self.adv_action = None
+        m = None
+        if mask is not None:
+            m = torch.zeros(self._ld, dtype=torch.uint8, device=self.device)
+            m[:self.num_envs] = torch.as_tensor(mask, device=self.device).to(torch.uint8)
+        self._engine.reset(self._bufs, m, self._reset_state_buf, self._serial, self.num_envs, self._ld)
+        self._serial += 1
+        obs = self._obs_view()
+        if self.INFO_IN_RESET:
+            return obs, self._get_reset_info()
+        return obs
+
+    def _get_reset_info(self):
+        info = {'x_reference': self.X_GOAL, 'u_reference': self.U_GOAL, 'symbolic_model': self.symbolic,
+                'ctrl_timestep': self.CTRL_TIMESTEP, 'ctrl_freq': self.CTRL_FREQ,
+                'episode_len_sec': self.EPISODE_LEN_SEC}
+        if self.constraints is not None:
+            info['symbolic_constraints'] = self.constraints.get_all_symbolic_models()
+            info['constraint_values'] = self.constraints.get_values(self, only_state=True)   # benchmark_env.py:381-382
+        else:
+            info['symbolic_constraints'] = {}
+        info['initial_state_randomization'] = self.INIT_STATE_RAND_INFO if self.RANDOMIZED_INIT else {}
+        info['inertial_prop_randomization'] = {}
+        info['disturbances'] = self.DISTURBANCES
+        return info
+
+    def _load_action(self, action):
+        """Raw action into the SoA planes.  [N, nu] row-major costs one transpose copy; a tensor that
+        already IS the SoA buffer (``env.action_buffer`` or its transpose) costs nothing."""
+        buf = self._bufs['action']
+        n, nu = self.num_envs, self.action_dim
+        if isinstance(action, torch.Tensor):
+            if action.data_ptr() == buf.data_ptr():
+                return
+            a = action.to(device=self.device, dtype=torch.float32)
+        else:
+            a = torch.as_tensor(np.asarray(action, dtype=np.float32), device=self.device)
+        if a.ndim == 1:
+            a = a.reshape(1, -1) if n == 1 else a.reshape(n, -1)
+        if a.shape == (n, nu):
+            buf[:, :n].copy_(a.T)
+        elif a.shape == (nu, n):
+            buf[:, :n].copy_(a)
+        else:
+            raise ValueError('[ERROR] action must have shape (num_envs, action_dim) = (%d, %d), got %s'
+                             % (n, nu, tuple(a.shape)))
+
+    def step(self, action):
+        """Advance every env by one control step (quadrotor.py:507-558 + benchmark_env.py:422-463)."""
+        self._check_initial_reset()
+        self._load_action(action)
+        self.current_raw_input_action = self.action_buffer
+        b = self._bufs
+        io = dict(b)
+        io['reset_state'] = self._reset_state_buf
+        # disturbances (quadrotor.py:526-548,835-838,879-880): noise planes generated on device
+        if 'action' in self.disturbances or self.adversary_disturbance == 'action':
+            io['action_disturbance'] = self._disturbance_plane('action', self.action_dim)
+        if 'dynamics' in self.disturbances or self.adversary_disturbance == 'dynamics':
+            io['dynamics_force'] = self._dynamics_force_plane()
+        if 'observation' in self.disturbances:
+            io['obs_noise'] = self._disturbance_plane('observation', self.state_dim)
+        self._engine.step(io, self.num_envs, self._ld, self._serial)
+        self._serial += 1
+        n = self.num_envs
+        obs = self._obs_view()
+        rew = b['reward'][:n]
+        done = b['done'][:n].bool()
+        info = {}
+        if 'mse' in b:
+            info['mse'] = b['mse'][:n]
+        if 'goal_reached' in b:
+            info['goal_reached'] = b['goal_reached'][:n].bool()
+        if self.constraints is not None:
+            info['constraint_values'] = self.constraints.fold(b['constraint_values'][:, :n].T)
+            info['constraint_violation'] = b['constraint_violation'][:n]
+        if 'truncated' in b:
+            info['TimeLimit.truncated'] = b['truncated'][:n].bool()
+        if 'terminal_obs' in b:
+            info['terminal_observation'] = b['terminal_obs'][:, :n].T
+        if 'last_ep_return' in b:
+            info['episode'] = {'r': b['last_ep_return'][:n], 'l': b['last_ep_length'][:n]}
+        if self.INFO_LEVEL == 'full':
+            info['n'] = LazyInfoList(info, done)
+        return obs, rew, done, info
+
+    def _disturbance_plane(self, mode, dim):
+        out = torch.zeros((dim, self._ld), dtype=torch.float32, device=self.device)
+        view = out[:, :self.num_envs].T              # [N, dim]
+        if mode in self.disturbances:
+            view.copy_(self.disturbances[mode].apply(torch.zeros_like(view), self))
+        if mode == 'action' and self.adversary_disturbance == 'action' and self.adv_action is not None:
+            view += self.adv_action
+        return out
+
+    def _dynamics_force_plane(self):
+        """World-frame force [3][ld] from the mode-dimensional disturbance (quadrotor.py:539-548)."""
+        dim = self.DISTURBANCE_MODES['dynamics']['dim']
+        f = torch.zeros((self.num_envs, dim), dtype=torch.float32, device=self.device)
+        if 'dynamics' in self.disturbances:
+            f = self.disturbances['dynamics'].apply(f, self)
+        if self.adversary_disturbance == 'dynamics' and self.adv_action is not None:
+            f = f + self.adv_action
+            self.adv_action = None
+        out = torch.zeros((3, self._ld), dtype=torch.float32, device=self.device)
+        n = self.num_envs
+        if dim == 1:
+            out[2, :n] = f[:, 0]
+        elif dim == 2:
+            out[0, :n], out[2, :n] = f[:, 0], f[:, 1]
+        else:
+            out[:, :n] = f.T
+        return out
+
+    def close(self):
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+
+    def render(self, mode='human'):
+        raise NotImplementedError('[ERROR] the batched engine does not render.')
+
+    # ------------------------------------------------------------------ reference trajectories
+    def _generate_trajectory(self, traj_type='figure8', traj_length=10.0, num_cycles=1, traj_plane='xy',
+                             position_offset=np.array([0, 0]), scaling=1.0, sample_time=0.01):
+        """Sampled planar reference (benchmark_env.py:465-519), closed forms evaluated for all samples at once.
+
+        Returns (pos (T,3), vel (T,3), speed (T,1)) sampled at ``np.arange(0, traj_length, sample_time)``.
+        """
+        if traj_type not in ('circle', 'square', 'figure8'):
+            raise ValueError('Trajectory type should be one of [circle, square, figure8].')
+        axes = ['x', 'y', 'z']
+        if traj_plane[0] in axes and traj_plane[1] in axes and traj_plane[0] != traj_plane[1]:
+            ia, ib = axes.index(traj_plane[0]), axes.index(traj_plane[1])
+        else:
+            raise ValueError('Trajectory plane should be in form of ab, where a and b can be {x, y, z}.')
+        period = traj_length / num_cycles
+        t = np.arange(0, traj_length, sample_time)
+        w = 2.0 * np.pi / period
+        if traj_type == 'circle':                    # benchmark_env.py:613-617
+            a, b = scaling * np.cos(w * t), scaling * np.sin(w * t)
+            ad, bd = -scaling * w * np.sin(w * t), scaling * w * np.cos(w * t)
+        elif traj_type == 'figure8':                 # :587-591
+            a, b = scaling * np.sin(w * t), scaling * np.sin(w * t) * np.cos(w * t)
+            ad, bd = scaling * w * np.cos(w * t), scaling * w * (np.cos(w * t) ** 2 - np.sin(w * t) ** 2)
+        else:                                        # :640-673
+            seg = period / 4.0
+            speed = scaling / seg
+            cyc = t % period
+            seg_t = cyc % seg
+            idx = np.floor(cyc / seg).astype(int)
+            s = speed * seg_t
+            zero, full = np.zeros_like(t), np.full_like(t, scaling)
+            a = np.select([idx == 0, idx == 1, idx == 2, idx == 3], [zero, -s, -full, -scaling + s])
+            b = np.select([idx == 0, idx == 1, idx == 2, idx == 3], [s, full, scaling - s, zero])
+            ad = np.select([idx == 0, idx == 1, idx == 2, idx == 3], [zero, zero - speed, zero, zero + speed])
+            bd = np.select([idx == 0, idx == 1, idx == 2, idx == 3], [zero + speed, zero, zero - speed, zero])
+        pos = np.zeros((len(t), 3))
+        vel = np.zeros((len(t), 3))
+        pos[:, ia], vel[:, ia] = a + position_offset[0], ad
+        pos[:, ib], vel[:, ib] = b + position_offset[1], bd
+        return pos, vel, np.linalg.norm(vel, axis=1, keepdims=True)

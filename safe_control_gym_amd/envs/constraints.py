@@ -1,0 +1,397 @@
+"""Constraints on batched device state -- host-side mirror of the reference's ``Constraint`` API.
+
+Same classes, constructor arguments, yaml schema and method names as the reference's
+``safe_control_gym/envs/constraints.py`` (``Constraint`` :21-176, ``QuadraticContstraint`` (sic)
+:179-223, ``LinearConstraint`` :226-270, ``BoundedConstraint`` :273-304, ``DefaultConstraint``
+:307-368, ``SymmetricStateConstraint`` :371-415, ``ConstraintList`` :426-583, factory :594-612),
+but every value is batched: ``get_value(env)`` returns a ``[N, num_constraints]`` tensor,
+``is_violated`` / ``is_almost_active`` return ``[N]`` bool tensors.
+
+On the hot path none of this Python runs per step: ``ConstraintList.compile_rows()`` lowers the
+list once to the ``scg_constraint_row`` table of the C ABI and the fused HIP step kernel evaluates
+it.  The methods here evaluate the same rows through ``scg_eval_constraints`` (a stand-alone launch
+of the same device code) so that controllers calling ``constraint.get_value(env)`` get identical
+numbers.
+
+Differences from the reference, all documented in DESIGN.md:
+  * values are float32 and are not rounded to 8 decimals (constraints.py:119 rounds float64 values;
+    a float32 ulp at |c| ~ 0.1 is already 7e-9);
+  * ``input_and_state`` constrains v = concat(state, raw action) -- the reference passes the tuple
+    ``(state, action)`` into ``np.array`` (:119,:170), which is not a numeric vector.
+"""
+from enum import Enum
+
+import numpy as np
+
+from safe_control_gym_amd import _capi
+
+
+class ConstrainedVariableType(str, Enum):
+    """constraints.py:11-18."""
+    STATE = 'state'
+    INPUT = 'input'
+    INPUT_AND_STATE = 'input_and_state'
+
+
+class Constraint:
+    """One constraint = ``num_constraints`` scalar rows g(v) <= 0."""
+
+    def __init__(self, env, constrained_variable, strict=False, active_dims=None, tolerance=None,
+                 rounding=8, **kwargs):
+        self.rounding = rounding
+        self.constrained_variable = ConstrainedVariableType(constrained_variable)
+        nx, nu = env.state_dim, env.action_dim
+        self._nx, self._nu = nx, nu
+        if self.constrained_variable == ConstrainedVariableType.STATE:
+            self.dim, self._v_offset = nx, 0
+        elif self.constrained_variable == ConstrainedVariableType.INPUT:
+            self.dim, self._v_offset = nu, nx
+        elif self.constrained_variable == ConstrainedVariableType.INPUT_AND_STATE:
+            self.dim, self._v_offset = nx + nu, 0
+        else:
+            raise NotImplementedError('[ERROR] invalid constrained_variable (use STATE, INPUT or INPUT_AND_STATE).')
+        self.strict = strict
+        if active_dims is not None:
+            if isinstance(active_dims, int):
+                active_dims = [active_dims]
+            assert isinstance(active_dims, (list, np.ndarray)), '[ERROR] active_dims is not a list/array.'
+            assert len(active_dims) <= self.dim, '[ERROR] more active_dim than constrainable self.dim'
+            assert all(isinstance(n, (int, np.integer)) for n in active_dims), '[ERROR] non-integer active_dim.'
+            assert all(n < self.dim for n in active_dims), '[ERROR] active_dim not stricly smaller than self.dim.'
+            assert len(active_dims) == len(set(active_dims)), '[ERROR] duplicates in active_dim'
+            self.constraint_filter = np.eye(self.dim)[list(active_dims)]
+            self.dim = len(active_dims)
+        else:
+            self.constraint_filter = np.eye(self.dim)
+        self.tolerance = None if tolerance is None else np.array(tolerance, ndmin=1)
+        self._env = env
+        self._own_list = None
+
+    def reset(self):
+        pass
+
+    # ---- lowering to C-ABI rows -------------------------------------------------------------
+    def _scatter(self, row_over_var):
+        """Coefficients over the constrained variable -> coefficients over v = [state; action]."""
+        out = np.zeros(_capi.SCG_MAX_NV)
+        out[self._v_offset:self._v_offset + len(row_over_var)] = row_over_var
+        return out
+
+    def rows(self):
+        """List of dicts (kind, coef | P, b) in output order."""
+        raise NotImplementedError
+
+    def _row_meta(self, k):
+        tol = None if self.tolerance is None else float(self.tolerance[k])
+        return dict(strict=bool(self.strict), tolerance=tol)
+
+    # ---- evaluation (same device code as the fused kernel) ---------------------------------
+    def _as_list(self):
+        if self._own_list is None:
+            self._own_list = ConstraintList([self], env=self._env, _standalone=True)
+        return self._own_list
+
+    def get_symbolic_model(self, env=None):
+        """A NumPy callable g(v) in float64 (the reference returns its lambda, :216-223,:263-270)."""
+        return self.sym_func
+
+    def get_value(self, env):
+        """[N, num_constraints] float32 tensor.  Input rows need ``env.current_raw_input_action``."""
+        return self._as_list().get_values(env)
+
+    def is_violated(self, env, c_value=None):
+        if c_value is None:
+            c_value = self.get_value(env)
+        return (c_value >= 0.).any(dim=-1) if self.strict else (c_value > 0.).any(dim=-1)
+
+    def is_almost_active(self, env, c_value=None):
+        import torch
+        if self.tolerance is None:
+            n = c_value.shape[0] if c_value is not None else env.num_envs
+            return torch.zeros(n, dtype=torch.bool, device=env.device)
+        if c_value is None:
+            c_value = self.get_value(env)
+        tol = torch.as_tensor(self.tolerance, dtype=c_value.dtype, device=c_value.device)
+        return (c_value + tol > 0.).any(dim=-1)
+
+    def check_tolerance_shape(self):
+        if self.tolerance is not None and len(self.tolerance) != self.num_constraints:
+            raise ValueError('[ERROR] the tolerance dimension does not match the number of constraints.')
+
+
+class QuadraticContstraint(Constraint):
+    """x' P x <= b (constraints.py:179-223; the class name keeps the reference's spelling)."""
+
+    def __init__(self, env, P, b, constrained_variable, strict=False, active_dims=None, tolerance=None):
+        super().__init__(env, constrained_variable, strict=strict, active_dims=active_dims, tolerance=tolerance)
+        P = np.array(P, ndmin=1)
+        assert P.shape == (self.dim, self.dim), '[ERROR] P has the wrong dimension!'
+        self.P = P
+        assert isinstance(b, float), '[ERROR] b is not a scalar!'
+        self.b = b
+        self.num_constraints = 1
+        F = self.constraint_filter
+        self.sym_func = lambda x: x.T @ F.T @ self.P @ F @ x - self.b
+        self.check_tolerance_shape()
+
+    def rows(self):
+        F = self.constraint_filter
+        Pv = F.T @ self.P @ F                      # over the constrained variable
+        full = np.zeros((_capi.SCG_MAX_NV, _capi.SCG_MAX_NV))
+        o, d = self._v_offset, Pv.shape[0]
+        full[o:o + d, o:o + d] = Pv
+        return [dict(kind=1, P=full, b=float(self.b), **self._row_meta(0))]
+
+
+class LinearConstraint(Constraint):
+    """A x <= b (constraints.py:226-270)."""
+
+    def __init__(self, env, A, b, constrained_variable, strict=False, active_dims=None, tolerance=None):
+        super().__init__(env, constrained_variable, strict=strict, active_dims=active_dims, tolerance=tolerance)
+        A = np.array(A, ndmin=1)
+        b = np.array(b, ndmin=1)
+        assert A.shape[1] == self.dim, '[ERROR] A has the wrong dimension!'
+        self.A = A
+        assert b.shape[0] == A.shape[0], '[ERROR] Dimension 0 of b does not match A!'
+        self.b = b
+        self.num_constraints = A.shape[0]
+        self.sym_func = lambda x: self.A @ self.constraint_filter @ x - self.b
+        self.check_tolerance_shape()
+
+    def rows(self):
+        AF = self.A @ self.constraint_filter
+        return [dict(kind=0, coef=self._scatter(AF[k]), b=float(self.b[k]), **self._row_meta(k))
+                for k in range(self.num_constraints)]
+
+
+class BoundedConstraint(LinearConstraint):
+    """lb <= x <= ub as [-I; I] x <= [-lb; ub] (constraints.py:273-304): lower rows first."""
+
+    def __init__(self, env, lower_bounds, upper_bounds, constrained_variable, strict=False, active_dims=None,
+                 tolerance=None):
+        self.lower_bounds = np.array(lower_bounds, ndmin=1)
+        self.upper_bounds = np.array(upper_bounds, ndmin=1)
+        dim = self.lower_bounds.shape[0]
+        A = np.vstack((-np.eye(dim), np.eye(dim)))
+        b = np.hstack((-self.lower_bounds, self.upper_bounds))
+        super().__init__(env, A, b, constrained_variable, strict=strict, active_dims=active_dims,
+                         tolerance=tolerance)
+        self.check_tolerance_shape()
+
+
+class DefaultConstraint(BoundedConstraint):
+    """Bounds of ``env.state_space`` / ``env.action_space`` (constraints.py:307-368)."""
+
+    def __init__(self, env, constrained_variable, lower_bounds=None, upper_bounds=None, strict=False,
+                 tolerance=None):
+        if constrained_variable == ConstrainedVariableType.STATE:
+            space = env.state_space if hasattr(env, 'state_space') else env.observation_space
+        elif constrained_variable == ConstrainedVariableType.INPUT:
+            space = env.action_space
+        else:
+            raise NotImplementedError('[ERROR] DefaultConstraint can only be of type STATE or INPUT')
+        if upper_bounds is None:
+            upper_bounds = space.high
+        else:
+            upper_bounds = np.array(upper_bounds, ndmin=1)
+            assert len(upper_bounds) == space.shape[0], '[ERROR]: Upper bound must have length equal to space dimension.'
+        if lower_bounds is None:
+            lower_bounds = space.low
+        else:
+            lower_bounds = np.array(lower_bounds, ndmin=1)
+            assert len(lower_bounds) == space.shape[0], '[ERROR]: Lower bound must have length equal to space dimension.'
+        super().__init__(env, lower_bounds=np.asarray(lower_bounds).astype(np.float64),
+                         upper_bounds=np.asarray(upper_bounds).astype(np.float64),
+                         constrained_variable=constrained_variable, strict=strict, active_dims=None,
+                         tolerance=tolerance)
+
+
+class SymmetricStateConstraint(BoundedConstraint):
+    """|F x| <= bound (constraints.py:371-415); cartpole + rl_reward only, like the reference.
+
+    |y| - bound <= 0 is the pair (y - bound <= 0, -y - bound <= 0); the device table holds both
+    rows and ``get_value`` folds them back to the reference's ``num_constraints = len(bound)`` values.
+    """
+
+    def __init__(self, env, constrained_variable, bound, strict=False, active_dims=None, tolerance=None, **kw):
+        assert bound is not None
+        self.bound = np.array(bound, ndmin=1)
+        super().__init__(env, lower_bounds=-self.bound, upper_bounds=self.bound,
+                         constrained_variable=constrained_variable, strict=strict, active_dims=active_dims,
+                         tolerance=None)
+        assert env.NAME == 'cartpole', '[ERROR] SymmetricStateConstraint is meant for CartPole environments'
+        assert env.COST == 'rl_reward', '[ERROR] SymmetricStateConstraint is meant for RL environments'
+        self.tolerance = None if tolerance is None else np.array(tolerance, ndmin=1)
+        if self.tolerance is not None and len(self.tolerance) != len(self.bound):
+            raise ValueError('[ERROR] the tolerance dimension does not match the number of constraints.')
+        self.folded = True
+        self.num_constraints = self.bound.shape[0]
+        self.sym_func = lambda x: np.abs(self.constraint_filter @ x) - self.bound
+
+    def rows(self):
+        d = len(self.bound)
+        AF = self.A @ self.constraint_filter
+        out = []
+        for k in range(2 * d):
+            tol = None if self.tolerance is None else float(self.tolerance[k % d])
+            out.append(dict(kind=0, coef=self._scatter(AF[k]), b=float(self.b[k]), strict=bool(self.strict),
+                            tolerance=tol))
+        return out
+
+    def fold(self, c_rows):
+        """[N, 2d] device rows (lower | upper) -> [N, d] values |y| - bound = max of the pair."""
+        import torch
+        d = len(self.bound)
+        return torch.maximum(c_rows[:, :d], c_rows[:, d:])
+
+
+GENERAL_CONSTRAINTS = {
+    'linear_constraint': LinearConstraint,
+    'quadratic_constraint': QuadraticContstraint,
+    'bounded_constraint': BoundedConstraint,
+    'default_constraint': DefaultConstraint,
+}
+
+
+class ConstraintList:
+    """Ordered collection (constraints.py:426-583) plus its lowering to the device table."""
+
+    def __init__(self, constraints, env=None, _standalone=False):
+        self.constraints = constraints
+        self.constraint_lengths = [con.num_constraints for con in constraints]
+        self.constraint_indices = np.cumsum(self.constraint_lengths[:-1])
+        self.num_constraints = sum(self.constraint_lengths)
+        T = ConstrainedVariableType
+        self.state_constraints = [c for c in constraints if c.constrained_variable == T.STATE]
+        self.num_state_constraints = sum(c.num_constraints for c in self.state_constraints)
+        self.input_constraints = [c for c in constraints if c.constrained_variable == T.INPUT]
+        self.num_input_constraints = sum(c.num_constraints for c in self.input_constraints)
+        self.input_state_constraints = [c for c in constraints if c.constrained_variable == T.INPUT_AND_STATE]
+        self.num_input_state_constraints = sum(c.num_constraints for c in self.input_state_constraints)
+        self._env = env
+        self._standalone = _standalone
+        self._handle = None
+        # device rows: folded constraints occupy 2 rows per value
+        self.device_row_counts = [len(c.rows()) for c in constraints]
+        self.num_device_rows = sum(self.device_row_counts)
+
+    def __len__(self):
+        return len(self.constraints)
+
+    def get_all_symbolic_models(self):
+        return [c.get_symbolic_model() for c in self.constraints]
+
+    def get_state_constraint_symbolic_models(self):
+        return [c.get_symbolic_model() for c in self.state_constraints]
+
+    def get_input_constraint_symbolic_models(self):
+        return [c.get_symbolic_model() for c in self.input_constraints]
+
+    def get_input_and_state_constraint_symbolic_models(self):
+        return [c.get_symbolic_model() for c in self.input_state_constraints]
+
+    # ---- lowering ---------------------------------------------------------------------------
+    def compile_rows(self):
+        """-> (ctypes array of scg_constraint_row, n_rows, ctypes array of P matrices, n_p)."""
+        import ctypes as C
+        rows = [r for c in self.constraints for r in c.rows()]
+        if len(rows) > _capi.SCG_MAX_CONSTRAINT_ROWS:
+            raise ValueError('too many constraint rows: %d (max %d)' % (len(rows), _capi.SCG_MAX_CONSTRAINT_ROWS))
+        arr = (_capi.ScgConstraintRow * max(len(rows), 1))()
+        pmats = []
+        for k, r in enumerate(rows):
+            arr[k].kind = r['kind']
+            arr[k].strict = int(r['strict'])
+            arr[k].has_tolerance = int(r['tolerance'] is not None)
+            arr[k].tolerance = 0.0 if r['tolerance'] is None else r['tolerance']
+            arr[k].b = r['b']
+            if r['kind'] == 1:
+                arr[k].p_index = len(pmats)
+                pmats.append(np.asarray(r['P'], dtype=np.float64))
+            else:
+                for j in range(_capi.SCG_MAX_NV):
+                    arr[k].coef[j] = float(r['coef'][j])
+        if len(pmats) > _capi.SCG_MAX_QUADRATIC:
+            raise ValueError('too many quadratic constraints: %d (max %d)' % (len(pmats), _capi.SCG_MAX_QUADRATIC))
+        flat = np.concatenate([p.ravel() for p in pmats]) if pmats else np.zeros(1)
+        parr = (C.c_double * len(flat))(*flat.tolist())
+        return arr, len(rows), parr, len(pmats)
+
+    def fold(self, c_rows):
+        """Device rows [N, num_device_rows] -> reference layout [N, num_constraints]."""
+        import torch
+        if self.num_device_rows == self.num_constraints:
+            return c_rows
+        out, o = [], 0
+        for c, nrow in zip(self.constraints, self.device_row_counts):
+            blk = c_rows[:, o:o + nrow]
+            out.append(c.fold(blk) if getattr(c, 'folded', False) else blk)
+            o += nrow
+        return torch.cat(out, dim=1)
+
+    # ---- evaluation -------------------------------------------------------------------------
+    def _eval(self, env, only_state):
+        """Stand-alone launch of the constraint device code on env.state / env.current_raw_input_action."""
+        import torch
+        if self._standalone or env._engine is None or env.constraints is not self:
+            if self._handle is None:
+                self._handle = env._make_engine(constraint_list=self)
+            eng = self._handle
+        else:
+            eng = env._engine
+        return eng.eval_constraints(env, None if only_state else env._raw_action_soa())
+
+    def get_values(self, env, only_state=False):
+        """[N, num_constraints] (only_state: the state constraints only, as at reset, :516-517)."""
+        c_rows = self._eval(env, only_state)
+        vals = self.fold(c_rows)
+        if not only_state:
+            return vals
+        keep, o = [], 0
+        for c in self.constraints:
+            if c.constrained_variable == ConstrainedVariableType.STATE:
+                keep.extend(range(o, o + c.num_constraints))
+            o += c.num_constraints
+        return vals[:, keep]
+
+    def get_violations(self, env, only_state=False):
+        cons = self.state_constraints if only_state else self.constraints
+        return [c.is_violated(env) for c in cons]
+
+    def _splits(self, c_value):
+        o = 0
+        for c in self.constraints:
+            yield c, c_value[:, o:o + c.num_constraints]
+            o += c.num_constraints
+
+    def is_violated(self, env, c_value=None):
+        import torch
+        if c_value is None:
+            c_value = self.get_values(env)
+        flag = torch.zeros(c_value.shape[0], dtype=torch.bool, device=c_value.device)
+        for c, part in self._splits(c_value):
+            flag |= c.is_violated(env, c_value=part)
+        return flag
+
+    def is_almost_active(self, env, c_value=None):
+        import torch
+        if c_value is None:
+            c_value = self.get_values(env)
+        flag = torch.zeros(c_value.shape[0], dtype=torch.bool, device=c_value.device)
+        for c, part in self._splits(c_value):
+            flag |= c.is_almost_active(env, c_value=part)
+        return flag
+
+
+def create_constraint_list(constraint_specs, available_constraints, env):
+    """yaml factory (constraints.py:594-612)."""
+    constraint_list = []
+    for constraint in constraint_specs:
+        assert isinstance(constraint, dict), '[ERROR]: Each constraint must be specified as a dict.'
+        assert 'constraint_form' in constraint.keys(), "[ERROR]: Each constraint must have a key 'constraint_form'"
+        con_form = constraint['constraint_form']
+        assert con_form in available_constraints, '[ERROR]. constraint not in list of available constraints'
+        con_class = available_constraints[con_form]
+        cfg = {key: constraint[key] for key in constraint if key != 'constraint_form'}
+        constraint_list.append(con_class(env, **cfg))
+    return ConstraintList(constraint_list, env=env)

@@ -1,0 +1,97 @@
+"""Thin Python owner of one ``scg_handle`` (C ABI, ``include/scg_rollout.h``).
+
+PyTorch-ROCm tensors are only the device buffers here: their ``data_ptr()`` and the current HIP
+stream cross the ABI; all arithmetic happens in the HIP kernels.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from safe_control_gym_amd import _capi
+
+
+def _fill(dst, values):
+    values = np.asarray(values, dtype=np.float64).ravel()
+    for j, v in enumerate(values):
+        dst[j] = float(v)
+
+
+class Engine:
+    def __init__(self, cfg, x_goal_table=None, constraint_list=None, device=None):
+        """cfg: a filled ``_capi.ScgConfig``; x_goal_table: (T, nx) float64 or None."""
+        self.lib = _capi.load()
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise _capi.ScgError('the rollout engine runs on a ROCm device only (got %r); there is no CPU path'
+                                 % (device,))
+        if not torch.cuda.is_available():
+            raise _capi.ScgError('no ROCm device is visible to this process: the rollout engine cannot run '
+                                 '(there is no CPU path)')
+        self.cfg = cfg
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _capi.check(self.lib.scg_create(C.byref(cfg), C.byref(handle)), 'scg_create')
+            self.handle = handle
+            if x_goal_table is not None:
+                tab = np.ascontiguousarray(x_goal_table, dtype=np.float64)
+                _capi.check(self.lib.scg_set_reference(handle, tab.ctypes.data_as(C.POINTER(C.c_double)),
+                                                       tab.shape[0]), 'scg_set_reference')
+            self.num_device_rows = 0
+            if constraint_list is not None and constraint_list.num_device_rows > 0:
+                rows, n_rows, pmats, n_p = constraint_list.compile_rows()
+                _capi.check(self.lib.scg_set_constraints(handle, rows, n_rows, pmats, n_p), 'scg_set_constraints')
+                self.num_device_rows = n_rows
+        self.obs_dim = self.lib.scg_obs_dim(handle)
+        self._io = _capi.ScgStepIO()
+        self._io.struct_size = C.sizeof(_capi.ScgStepIO)
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.scg_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self, bufs, mask, reset_state, serial, n, ld):
+        p = _capi.ptr
+        with torch.cuda.device(self.device):
+            _capi.check(self.lib.scg_reset(self.handle, p(bufs['state']), p(bufs.get('state_lo')),
+                                           p(bufs['step_count']), p(bufs.get('ep_return')),
+                                           p(bufs.get('ep_length')), p(bufs.get('obs')), p(mask),
+                                           p(reset_state), serial & 0xffffffff, ld, n, self._stream()), 'scg_reset')
+
+    def step(self, bufs, n, ld, serial):
+        io, p = self._io, _capi.ptr
+        io.ld = ld
+        for name in ('action', 'action_disturbance', 'dynamics_force', 'obs_noise', 'reset_state', 'state',
+                     'state_lo', 'step_count', 'ep_return', 'ep_length', 'obs', 'reward', 'done',
+                     'constraint_values', 'constraint_violation', 'truncated', 'goal_reached', 'mse',
+                     'terminal_obs', 'last_ep_return', 'last_ep_length', 'stats'):
+            t = bufs.get(name)
+            setattr(io, name, None if t is None else t.data_ptr())
+        io.reset_serial = serial & 0xffffffff
+        with torch.cuda.device(self.device):
+            _capi.check(self.lib.scg_step(self.handle, C.byref(io), n, self._stream()), 'scg_step')
+
+    def eval_constraints(self, env, action_soa):
+        """[N, num_device_rows] values of this engine's constraint table on env's state."""
+        n, ld = env.num_envs, env._ld
+        out = torch.empty((max(self.num_device_rows, 1), ld), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _capi.check(self.lib.scg_eval_constraints(self.handle, _capi.ptr(env._bufs['state']),
+                                                      _capi.ptr(action_soa), _capi.ptr(out), None, ld, n,
+                                                      self._stream()), 'scg_eval_constraints')
+        return out[:self.num_device_rows, :n].T
+
+    def kernel_info(self, n):
+        b, g, l = C.c_int32(), C.c_int32(), C.c_int32()
+        _capi.check(self.lib.scg_kernel_info(self.handle, C.byref(b), C.byref(g), C.byref(l), n), 'scg_kernel_info')
+        return dict(block=b.value, grid=g.value, lds_bytes=l.value)

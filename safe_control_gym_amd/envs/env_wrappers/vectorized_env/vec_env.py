@@ -1,0 +1,148 @@
+"""The ``VecEnv`` protocol (reference: env_wrappers/vectorized_env/vec_env.py:16-227) over a batched env."""
+from abc import ABC, abstractmethod
+
+
+class VecEnv(ABC):
+    closed = False
+    viewer = None
+    metadata = {'render.modes': []}
+
+    def __init__(self, num_envs, observation_space, action_space):
+        self.num_envs = num_envs
+        self.observation_space = observation_space
+        self.action_space = action_space
+
+    @abstractmethod
+    def reset(self):
+        pass
+
+    @abstractmethod
+    def step_async(self, actions):
+        pass
+
+    @abstractmethod
+    def step_wait(self):
+        pass
+
+    def close_extras(self):
+        pass
+
+    def close(self):
+        if self.closed:
+            return
+        self.close_extras()
+        self.closed = True
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    @property
+    def unwrapped(self):
+        return self.venv.unwrapped if isinstance(self, VecEnvWrapper) else self
+
+    @abstractmethod
+    def get_attr(self, attr_name, indices=None):
+        pass
+
+    @abstractmethod
+    def set_attr(self, attr_name, values, indices=None):
+        pass
+
+    @abstractmethod
+    def env_method(self, method_name, method_args=None, method_kwargs=None, indices=None):
+        pass
+
+    def _get_indices(self, indices):
+        if indices is None:
+            indices = range(self.num_envs)
+        elif isinstance(indices, int):
+            indices = [indices]
+        return indices
+
+
+class DeviceVecEnv(VecEnv):
+    """All ``num_envs`` environments are one batched env; ``step_async`` enqueues the kernel on the
+    current HIP stream and ``step_wait`` hands back device tensors without synchronising."""
+
+    def __init__(self, env):
+        self.env = env
+        super().__init__(env.num_envs, env.observation_space, env.action_space)
+        self._pending = None
+
+    def reset(self):
+        out = self.env.reset()
+        if isinstance(out, tuple):
+            return out
+        return out, {'n': None}
+
+    def step_async(self, actions):
+        self._pending = self.env.step(actions)
+
+    def step_wait(self):
+        out, self._pending = self._pending, None
+        return out
+
+    def close_extras(self):
+        self.env.close()
+
+    def get_attr(self, attr_name, indices=None):
+        """Attributes are shared by the whole batch: one value per requested index."""
+        return [getattr(self.env, attr_name) for _ in self._get_indices(indices)]
+
+    def set_attr(self, attr_name, values, indices=None):
+        idx = list(self._get_indices(indices))
+        assert len(idx) == len(values)
+        if any(v is not values[0] and v != values[0] for v in values):
+            raise ValueError('[ERROR] the batched engine shares attributes across the batch; values differ.')
+        setattr(self.env, attr_name, values[0])
+
+    def env_method(self, method_name, method_args=None, method_kwargs=None, indices=None):
+        idx = list(self._get_indices(indices))
+        args = method_args[0] if method_args else []
+        kwargs = method_kwargs[0] if method_kwargs else {}
+        res = getattr(self.env, method_name)(*args, **kwargs)
+        return [res for _ in idx]
+
+    def get_env_random_state(self):
+        return [{'seed': self.env._seed, 'serial': self.env._serial}]
+
+    def set_env_random_state(self, worker_random_states):
+        st = worker_random_states[0]
+        self.env.seed(st['seed'])
+        self.env._serial = st['serial']
+
+
+class VecEnvWrapper(VecEnv):
+    """vec_env.py:165-227."""
+
+    def __init__(self, venv, observation_space=None, action_space=None):
+        self.venv = venv
+        super().__init__(num_envs=venv.num_envs, observation_space=observation_space or venv.observation_space,
+                         action_space=action_space or venv.action_space)
+
+    def step_async(self, actions):
+        self.venv.step_async(actions)
+
+    def reset(self):
+        return self.venv.reset()
+
+    def step_wait(self):
+        return self.venv.step_wait()
+
+    def close(self):
+        return self.venv.close()
+
+    def get_attr(self, attr_name, indices=None):
+        return self.venv.get_attr(attr_name, indices)
+
+    def set_attr(self, attr_name, values, indices=None):
+        return self.venv.set_attr(attr_name, values, indices)
+
+    def env_method(self, method_name, method_args=None, method_kwargs=None, indices=None):
+        return self.venv.env_method(method_name, method_args, method_kwargs, indices)
+
+    def __getattr__(self, name):
+        if name.startswith('_'):
+            raise AttributeError("attempted to get missing private attribute '{}'".format(name))
+        return getattr(self.venv, name)

@@ -1,0 +1,144 @@
+"""Prior ("symbolic") model handed to controllers through ``env.symbolic`` -- host side, batched NumPy.
+
+Mirrors the public surface of the reference's CasADi ``SymbolicModel``
+(math_and_models/symbolic_systems.py:8-123) without CasADi: ``nx, nu, ny, dt``,
+``fc_func`` (:68), ``fd_func`` (:70-73), ``g_func`` (:75), ``df_func`` (:84-86), ``dg_func``
+(:89-91), ``loss`` (:119-123).  Every function takes keyword arrays like the CasADi ``Function``
+objects do and returns a dict with the same output names; inputs may carry leading batch
+dimensions (``x`` of shape (..., nx)).
+
+Differences, all deliberate:
+  * ``fd_func`` integrates with the reference's own RK4 (controllers/mpc/mpc_utils.py:79-101),
+    not CVODES (SUNDIALS is not available) -- the same discretisation the device
+    engine steps with.
+  * Jacobians come from a sympy derivation of the same equations, lambdified on first use.
+
+The equations are those of quadrotor.py:594-676 (1-D / 2-D / 3-D) and the textbook cart-pole
+(DESIGN.md, row A16).
+"""
+import numpy as np
+
+
+# Component-wise closed forms, generic over the math namespace ``m`` (numpy for evaluation, sympy
+# for deriving Jacobians): x, u are sequences of components, the result a list of components.
+def _quad1d(x, u, c, m):
+    return [x[1], u[0] / c['m'] - c['g']]
+
+
+def _quad2d(x, u, c, m):
+    th = x[4]
+    T = u[0] + u[1]
+    return [x[1], m.sin(th) * T / c['m'], x[3], m.cos(th) * T / c['m'] - c['g'],
+            x[5], c['l'] * (u[1] - u[0]) / c['Iyy'] / m.sqrt(2.0)]
+
+
+def _quad3d(x, u, c, m):
+    phi, th, psi, p, q, r = x[6], x[7], x[8], x[9], x[10], x[11]
+    f1, f2, f3, f4 = u
+    sph, cph, sth, cth, sps, cps = m.sin(phi), m.cos(phi), m.sin(th), m.cos(th), m.sin(psi), m.cos(psi)
+    Tm = (f1 + f2 + f3 + f4) / c['m']
+    ax = (cps * sth * cph + sps * sph) * Tm
+    ay = (sps * sth * cph - cps * sph) * Tm
+    az = cth * cph * Tm - c['g']
+    k = c['l'] / m.sqrt(2.0)
+    Mx, My, Mz = k * (f1 + f2 - f3 - f4), k * (-f1 + f2 + f3 - f4), c['gamma'] * (f1 - f2 + f3 - f4)
+    Ixx, Iyy, Izz = c['Ixx'], c['Iyy'], c['Izz']
+    pd = (Mx - (q * Izz * r - r * Iyy * q)) / Ixx
+    qd = (My - (r * Ixx * p - p * Izz * r)) / Iyy
+    rd = (Mz - (p * Iyy * q - q * Ixx * p)) / Izz
+    tth = sth / cth
+    return [x[1], ax, x[3], ay, x[5], az,
+            p + sph * tth * q + cph * tth * r, cph * q - sph * r, (sph * q + cph * r) / cth,
+            pd, qd, rd]
+
+
+def _cartpole(x, u, c, m):
+    th, thd = x[2], x[3]
+    Mm, ml = c['m'] + c['M'], c['m'] * c['l']
+    s, co = m.sin(th), m.cos(th)
+    tmp = (u[0] + ml * thd * thd * s) / Mm
+    thdd = (c['g'] * s - co * tmp) / (c['l'] * (4.0 / 3.0 - c['m'] * co * co / Mm))
+    return [x[1], tmp - ml * thdd * co / Mm, thd, thdd]
+
+
+_F = {'quad1d': _quad1d, 'quad2d': _quad2d, 'quad3d': _quad3d, 'cartpole': _cartpole}
+_DIMS = {'quad1d': (2, 1), 'quad2d': (6, 2), 'quad3d': (12, 4), 'cartpole': (4, 1)}
+
+
+class AnalyticModel:
+    """Closed-form stand-in for ``SymbolicModel``."""
+
+    def __init__(self, system, consts, dt):
+        self.system = system
+        self.consts = dict(consts)
+        self.dt = dt
+        self.nx, self.nu = _DIMS[system]
+        self.ny = self.nx
+        self.integration_algo = 'rk4'
+        self._jac = None
+
+    # -- dynamics ---------------------------------------------------------------------------
+    def _f(self, x, u):
+        x = np.asarray(x, dtype=np.float64)
+        u = np.asarray(u, dtype=np.float64)
+        xs = [x[..., j] for j in range(self.nx)]
+        us = [u[..., j] for j in range(self.nu)]
+        comps = _F[self.system](xs, us, self.consts, np)
+        shape = np.broadcast(*[np.asarray(v) for v in comps]).shape
+        return np.stack([np.broadcast_to(np.asarray(v, dtype=np.float64), shape) for v in comps], -1)
+
+    def fc_func(self, x, u):
+        return {'f': self._f(x, u)}
+
+    def fd_func(self, x0, p):
+        """One RK4 step of length dt with zero-order-hold input p."""
+        x0 = np.asarray(x0, dtype=np.float64)
+        dt = self.dt
+        k1 = self._f(x0, p)
+        k2 = self._f(x0 + dt / 2 * k1, p)
+        k3 = self._f(x0 + dt / 2 * k2, p)
+        k4 = self._f(x0 + dt * k3, p)
+        return {'xf': x0 + dt / 6 * (k1 + 2 * k2 + 2 * k3 + k4)}
+
+    def g_func(self, x, u):
+        return {'g': np.asarray(x, dtype=np.float64)}
+
+    def dg_func(self, x, u):
+        x = np.asarray(x)
+        lead = x.shape[:-1]
+        return {'dgdx': np.broadcast_to(np.eye(self.nx), lead + (self.nx, self.nx)).copy(),
+                'dgdu': np.zeros(lead + (self.nx, self.nu))}
+
+    def _build_jacobians(self):
+        import sympy as sp
+        X = sp.symbols('x0:%d' % self.nx)
+        U = sp.symbols('u0:%d' % self.nu)
+        F = sp.Matrix(_F[self.system](X, U, self.consts, sp))
+        self._jac = (sp.lambdify([X, U], F.jacobian(X), 'numpy'), sp.lambdify([X, U], F.jacobian(U), 'numpy'))
+
+    def df_func(self, x, u):
+        """Jacobians of f: dfdx (..., nx, nx), dfdu (..., nx, nu)."""
+        if self._jac is None:
+            self._build_jacobians()
+        x = np.asarray(x, dtype=np.float64)
+        u = np.asarray(u, dtype=np.float64)
+        lead = x.shape[:-1]
+        xf, uf = x.reshape(-1, self.nx), u.reshape(-1, self.nu)
+        A = np.stack([np.asarray(self._jac[0](xi, ui), dtype=np.float64) for xi, ui in zip(xf, uf)])
+        B = np.stack([np.asarray(self._jac[1](xi, ui), dtype=np.float64) for xi, ui in zip(xf, uf)])
+        return {'dfdx': A.reshape(lead + (self.nx, self.nx)), 'dfdu': B.reshape(lead + (self.nx, self.nu))}
+
+    # -- cost: quadrotor.py:682, symbolic_systems.py:114-123 ------------------------------------
+    def loss(self, x, u, Xr, Ur, Q, R):
+        x, u = np.asarray(x, dtype=np.float64), np.asarray(u, dtype=np.float64)
+        ex = x - np.asarray(Xr, dtype=np.float64)
+        eu = u - np.asarray(Ur, dtype=np.float64)
+        Q, R = np.asarray(Q, dtype=np.float64), np.asarray(R, dtype=np.float64)
+        Qs, Rs = 0.5 * (Q + Q.T), 0.5 * (R + R.T)
+        l = 0.5 * np.einsum('...i,ij,...j->...', ex, Q, ex) + 0.5 * np.einsum('...i,ij,...j->...', eu, R, eu)
+        lead = ex.shape[:-1]
+        return {'l': l,
+                'l_x': ex @ Qs.T, 'l_u': eu @ Rs.T,
+                'l_xx': np.broadcast_to(Qs, lead + Qs.shape).copy(),
+                'l_uu': np.broadcast_to(Rs, lead + Rs.shape).copy(),
+                'l_xu': np.zeros(lead + (self.nx, self.nu))}

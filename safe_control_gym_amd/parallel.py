@@ -1,0 +1,76 @@
+"""Sharding the env batch across GPUs (one process per GPU) and gathering episode returns.
+
+Environments never interact, so rank r simply owns the contiguous block
+``[r * N/W, (r+1) * N/W)`` of global env indices -- the block split ``SubprocVecEnv`` makes with
+``np.array_split`` (env_wrappers/vectorized_env/subproc_vec_env.py:28,52).  The step path has no
+collective.  The one exchange is the analogue of gathering ``info['episode']['r']`` into the
+return queue (record_episode_statistics.py:155-158): an all-gather of the per-env episode returns
+(``torch.distributed``; backend ``nccl`` is RCCL over xGMI on ROCm, ``gloo`` on CPU for tests).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total_envs, world_size, rank):
+    """[lo, hi) of the global env indices owned by ``rank`` (np.array_split semantics: the first
+    ``total % world`` ranks get one extra env)."""
+    base, extra = divmod(int(total_envs), int(world_size))
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    return lo, hi
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); returns (rank, world, local_rank)."""
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend)
+    return rank, world, local_rank
+
+
+def make_sharded(make_fn, total_envs, rank=0, world_size=1, **kwargs):
+    """Build this rank's shard: ``make_fn(num_envs=hi-lo, env_index_base=lo, **kwargs)``."""
+    lo, hi = shard_bounds(total_envs, world_size, rank)
+    return make_fn(num_envs=hi - lo, env_index_base=lo, **kwargs)
+
+
+def all_gather_episode_returns(local_returns, total_envs=None):
+    """[n_local] -> [total] on every rank (rank order = global env order).
+
+    Uneven shards are padded to the largest one so that a single all_gather_into_tensor suffices."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local_returns.clone()
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n_local = local_returns.shape[0]
+    if total_envs is None:
+        sizes = torch.tensor([n_local], device=local_returns.device, dtype=torch.int64)
+        all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+        dist.all_gather(all_sizes, sizes)
+        counts = [int(s.item()) for s in all_sizes]
+    else:
+        counts = [shard_bounds(total_envs, world, r)[1] - shard_bounds(total_envs, world, r)[0] for r in range(world)]
+    width = max(counts)
+    send = local_returns
+    if n_local != width:
+        send = torch.zeros(width, dtype=local_returns.dtype, device=local_returns.device)
+        send[:n_local] = local_returns
+    out = torch.empty(world * width, dtype=local_returns.dtype, device=local_returns.device)
+    dist.all_gather_into_tensor(out, send.contiguous())
+    if all(c == width for c in counts):
+        return out
+    return torch.cat([out[r * width:r * width + counts[r]] for r in range(world)])
+
+
+def all_reduce_stats(stats):
+    """Sum a small stats tensor (e.g. the kernel's [8] batch sums) over ranks."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    return stats
