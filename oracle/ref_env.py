@@ -95,7 +95,9 @@ class RefEnv:
         self.TASK, self.COST = str(task), str(cost)
         self.TASK_INFO = deepcopy(DEFAULT_TASK_INFO) if task_info is None else task_info
         if system == 'cartpole' and task_info is None:
-            self.TASK_INFO['stabilization_goal'] = [0]
+            self.TASK_INFO = {'stabilization_goal': [0], 'stabilization_goal_tolerance': 0.05,
+                              'trajectory_type': 'circle', 'num_cycles': 1, 'trajectory_plane': 'zx',
+                              'trajectory_position_offset': [0, 0], 'trajectory_scale': 0.2}
         # benchmark_env.py:151-161
         self.CTRL_FREQ, self.PYB_FREQ = ctrl_freq, pyb_freq
         if pyb_freq % ctrl_freq != 0:

@@ -107,6 +107,13 @@ def load():
     if not os.path.exists(path):
         raise ScgError('HIP extension %s is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
                        '(or safe_control_gym_amd/csrc/build.sh).  The engine has no CPU fallback.' % path)
+    # The library must share ONE HIP runtime with PyTorch (streams and device pointers cross the ABI).
+    # torch ships its own libamdhip64.so with the same soname as /opt/rocm's: whichever is loaded first
+    # serves both, so make sure it is torch's.
+    import torch
+    torch_hip = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
+    if os.path.exists(torch_hip):
+        C.CDLL(torch_hip, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(path)
     lib.scg_last_error.restype = C.c_char_p
     lib.scg_create.argtypes = [C.POINTER(ScgConfig), C.POINTER(C.c_void_p)]
