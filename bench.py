@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""Headline benchmark: env-steps/sec of the fused HIP ``env.step()`` at N parallel envs.
+
+Contract (see the build prompt): ``python bench.py --gpus N --steps K --warmup W`` -> rank 0 prints
+ONE JSON line.  A "step" is one pass of the hot path (one ``scg_step`` kernel launch) over one batch
+of synthetic input: every env of the batch advances by one control step.
+
+Workloads (BASELINE.json ``configs``):
+  * N = 1  -> C4: Quadrotor-3D trajectory tracking, 2^20 envs, quadratic cost, RK4, auto-reset;
+              algorithmic bytes B = 8 nx + 4 nu + 13 = 125 per env-step.
+  * N > 1  -> C5: the same per GPU (weak scaling, envs sharded by contiguous global index) with
+              per-env episode-return tracking (B = 141) and one RCCL all-gather of the episode
+              returns every 300 steps (= one episode) inside the timed region.
+Actions are i.i.d. U(a_low, a_high) float32, pre-generated on the device ([300, nu, N]) and reused
+cyclically; initial / reset states are nominal + the reference's uniform offsets (Philox on device).
+Inputs are resident in HBM when the timed region starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.3 TB/s achievable)
+
+
+def build_env(args, rank, world):
+    import safe_control_gym_amd as scg
+    n = args.envs_per_gpu
+    track = world > 1 or args.episode_stats
+    common = dict(num_envs=n, device='cuda', seed=1337, env_index_base=rank * n, randomized_init=True,
+                  info_level='minimal', track_episode_stats=track, ctrl_freq=60, pyb_freq=240, episode_len_sec=5)
+    w = args.workload
+    if w in ('c4', 'c5'):
+        env = scg.make('quadrotor', quad_type=3, task='traj_tracking', cost='quadratic', **common)
+        name = 'Quadrotor-3D traj_tracking (circle), quadratic cost Q=R=I, RK4 dt=1/60, auto-reset'
+    elif w == 'c3':
+        cons = [{'constraint_form': 'bounded_constraint', 'constrained_variable': 'state', 'active_dims': [0, 2, 4],
+                 'lower_bounds': [-2, 0, -0.5], 'upper_bounds': [2, 2, 0.5]}]
+        env = scg.make('quadrotor', quad_type=2, task='stabilization', cost='rl_reward', constraints=cons, **common)
+        name = 'Quadrotor-2D stabilization, rl_reward, BoundedConstraint(active_dims [0,2,4])'
+    elif w == 'c2':
+        common.update(ctrl_freq=50, pyb_freq=50)
+        env = scg.make('cartpole', task='stabilization', cost='quadratic', **common)
+        name = 'CartPole stabilization, quadratic cost, RK4 dt=1/50 (no reference env: parity unpinned)'
+    else:
+        raise SystemExit('unknown workload %r' % w)
+    nx, nu = env.state_dim, env.action_dim
+    bytes_per = 8 * nx + 4 * nu + 13
+    if track:
+        bytes_per += 16                                  # ep_return + ep_length read-modify-write
+    if env.constraints is not None:
+        bytes_per += 4 * env.constraints.num_device_rows + 1
+    return env, name, bytes_per
+
+
+def cpu_baseline(args, env_kwargs_name):
+    """The C float64 port of the same step (oracle/c), timed on this box's host cores (bounded sample)."""
+    import numpy as np
+    from oracle.ref_env import RefEnv
+    from oracle.c_port import CPort
+    w = args.workload
+    if w in ('c4', 'c5'):
+        ref = RefEnv(system=3, task='traj_tracking', cost='quadratic', ctrl_freq=60, pyb_freq=240)
+    elif w == 'c3':
+        cons = [{'constraint_form': 'bounded_constraint', 'constrained_variable': 'state', 'active_dims': [0, 2, 4],
+                 'lower_bounds': [-2, 0, -0.5], 'upper_bounds': [2, 2, 0.5]}]
+        ref = RefEnv(system=2, task='stabilization', cost='rl_reward', ctrl_freq=60, pyb_freq=240, constraints=cons)
+    else:
+        ref = RefEnv(system='cartpole', task='stabilization', cost='quadratic', ctrl_freq=50, pyb_freq=50)
+    port = CPort.from_ref_env(ref)
+    n = 1 << 18
+    rng = np.random.default_rng(1337)
+    from oracle.ref_env import INIT_STATE_LABELS
+    lo = np.array([ref.INIT_STATE_RAND_INFO[k]['low'] for k in INIT_STATE_LABELS[ref.system]])
+    hi = np.array([ref.INIT_STATE_RAND_INFO[k]['high'] for k in INIT_STATE_LABELS[ref.system]])
+    x0 = rng.uniform(lo, hi, size=(n, ref.nx))
+    state, t = x0.copy(), np.zeros(n, dtype=np.int32)
+    acts = rng.uniform(ref.action_space_low, ref.action_space_high, size=(8, n, ref.nu))
+    threads = port.max_threads()
+    port.step(acts[0], state, t, x0, num_threads=threads)                   # warm-up (page faults, thread pool)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        port.step(acts[steps % 8], state, t, x0, num_threads=threads)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > args.cpu_seconds or steps >= 400:
+            break
+    # one-core Python oracle (the structure-equivalent stand-in for the reference's own step()): tiny sample
+    from oracle.ref_env import RefEnv as _R
+    ref.reset_sampler = lambda i, e: np.zeros(ref.nx)
+    ref.RANDOMIZED_INIT = False
+    ref.reset()
+    k, t1 = 0, time.perf_counter()
+    while time.perf_counter() - t1 < 2.0:
+        o, r, d, _ = ref.step(acts[0][k % n])
+        if d:
+            ref.reset()
+        k += 1
+    py_rate = k / (time.perf_counter() - t1)
+    return {'value': steps * n / el, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
+            'sample': 'oracle/c float64 OpenMP port, %d envs x %d steps (%.1f s) of the same workload; '
+                      'python oracle 1 core: %.0f env-steps/s' % (n, steps, el, py_rate)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3000)
+    ap.add_argument('--warmup', type=int, default=100)
+    ap.add_argument('--envs-per-gpu', type=int, default=1 << 20)
+    ap.add_argument('--workload', default=None, help='c4 (default at 1 GPU), c5 (default at >1), c3, c2')
+    ap.add_argument('--episode-stats', action='store_true', help='track episode returns at 1 GPU too (B += 16)')
+    ap.add_argument('--action-period', type=int, default=300)
+    ap.add_argument('--python-loop', action='store_true', help='also time env.step() called from Python per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from safe_control_gym_amd import parallel
+
+    rank, world, local_rank = parallel.init_from_env()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`'
+                             % (args.gpus, args.gpus))
+    if args.workload is None:
+        args.workload = 'c4' if world == 1 else 'c5'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    env, wname, bytes_per = build_env(args, rank, world)
+    n, nu = env.num_envs, env.action_dim
+    ld = env.plane_stride
+    g = torch.Generator(device=dev)
+    g.manual_seed(1337 + rank)
+    lo = torch.as_tensor(env.action_space.low, device=dev)[None, :, None]
+    hi = torch.as_tensor(env.action_space.high, device=dev)[None, :, None]
+    actions = torch.rand((args.action_period, nu, ld), generator=g, device=dev, dtype=torch.float32) * (hi - lo) + lo
+    env.reset()
+    gather_every = 300
+
+    def run(steps):
+        done_steps = 0
+        while done_steps < steps:
+            chunk = min(gather_every, steps - done_steps) if world > 1 else steps - done_steps
+            env.rollout(actions, steps=chunk)
+            done_steps += chunk
+            if world > 1:
+                parallel.all_gather_episode_returns(env.episode_return, total_envs=n * world)
+
+    run(args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run(args.steps)
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    dev_ms = ev0.elapsed_time(ev1)
+    t = torch.tensor([wall_ms, dev_ms], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall_ms, dev_ms = float(t[0]), float(t[1])
+    ms_per_step = wall_ms / args.steps
+    value = n * world * args.steps / (wall_ms * 1e-3)
+
+    py_value = None
+    if args.python_loop and world == 1:
+        for k in range(20):
+            env.step(actions[k % args.action_period])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            env.step(actions[k % args.action_period])
+        torch.cuda.synchronize()
+        py_value = n * args.steps / (time.perf_counter() - t1)
+
+    if rank == 0:
+        kernel_us = dev_ms * 1e3 / args.steps            # HIP-event time over the timed region / launches
+        achieved = bytes_per * n / (kernel_us * 1e-6) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(args.workload if world == 1 else 'c5', {}).get('bytes_per_launch')
+        out = {
+            'metric': 'env-steps/sec at N parallel envs, 1/2/4/8 GPUs; % HBM-BW roofline',
+            'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s: %s' % (args.workload.upper(), wname), 'envs_per_gpu': n,
+                       'total_envs': n * world, 'bytes_per_env_step': bytes_per,
+                       'launch': 'one fused scg_step kernel per step (scg_rollout issues the launches)',
+                       'sharding': 'envs block-sharded by global index; all-gather of episode returns every '
+                                   '%d steps' % gather_every if world > 1 else 'single GPU'},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'kernel_us_per_launch': kernel_us, 'algorithmic_bytes_per_launch': bytes_per * n},
+        }
+        if py_value is not None:
+            out['python_step_api_value'] = py_value
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args, wname)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -180,6 +180,15 @@ int scg_reset(scg_handle* h, float* state, float* state_lo, int32_t* step_count,
  * VecRecordEpisodeStatistics.step_wait (record_episode_statistics.py:142-169) for n envs. */
 int scg_step(scg_handle* h, const scg_step_io* io, int64_t n, void* stream);
 
+/* `steps` consecutive scg_step() launches from one call: step k reads its raw actions at
+ * io->action + (k % action_period) * action_stride elements and uses reset_serial + k.  This is the
+ * open-loop rollout loop of the reference's harnesses (tests/scripts/verbose_api.py:71-77: sample an
+ * action, step, repeat) with the action sequence pre-generated on the device; every other buffer of
+ * `io` is reused by all steps, so the outputs hold the LAST step's values and ep_return / ep_length /
+ * stats accumulate.  Same kernel, one launch per step: per-step HBM traffic is that of scg_step(). */
+int scg_rollout(scg_handle* h, const scg_step_io* io, int64_t n, int32_t steps, int64_t action_stride,
+                int32_t action_period, void* stream);
+
 /* ConstraintList.get_values (constraints.py:503-520) on explicit buffers: state [nx][ld],
  * action [nu][ld] (nullable -> only_state semantics: input rows are written as NaN), out [nc][ld]. */
 int scg_eval_constraints(scg_handle* h, const float* state, const float* action, float* c_val,

@@ -380,6 +380,21 @@ int scg_step(scg_handle* h, const scg_step_io* io, int64_t n, void* stream) {
     return SCG_OK;
 }
 
+int scg_rollout(scg_handle* h, const scg_step_io* io, int64_t n, int32_t steps, int64_t action_stride,
+                int32_t action_period, void* stream) {
+    if (!io) return fail(SCG_ERR_INVALID, "scg_rollout: null argument");
+    if (steps < 0 || action_period < 1 || action_stride < 0)
+        return fail(SCG_ERR_INVALID, "scg_rollout: need steps >= 0, action_period >= 1, action_stride >= 0");
+    scg_step_io local = *io;
+    for (int32_t k = 0; k < steps; ++k) {
+        local.action = io->action + (int64_t)(k % action_period) * action_stride;
+        local.reset_serial = io->reset_serial + (uint32_t)k;
+        const int rc = scg_step(h, &local, n, stream);
+        if (rc != SCG_OK) return rc;
+    }
+    return SCG_OK;
+}
+
 int scg_eval_constraints(scg_handle* h, const float* state, const float* action, float* c_val,
                          uint8_t* violation, int64_t ld, int64_t n, void* stream) {
     if (!h || !state) return fail(SCG_ERR_INVALID, "scg_eval_constraints: null argument");

@@ -395,7 +395,34 @@ class BenchmarkEnv:
         return self._bufs['ep_length'][:self.num_envs]
 
     def _raw_action_soa(self):
-        return self._bufs['action']
+        return getattr(self, '_raw_action', None) if getattr(self, '_raw_action', None) is not None else self._bufs['action']
+
+    def rollout(self, actions, steps=None):
+        """Open-loop rollout: ``steps`` fused step launches issued from one C-ABI call (``scg_rollout``).
+
+        ``actions``: contiguous float32 device tensor [T, nu, ld] (``ld = env.plane_stride``), used
+        cyclically.  Outputs (``env.state``, reward, done, ... buffers) hold the last step's values;
+        episode statistics accumulate.  Disturbance planes are not refreshed between the steps."""
+        self._check_initial_reset()
+        if self.disturbances or self.adversary_disturbance is not None:
+            raise RuntimeError('[ERROR] rollout() does not regenerate disturbance planes per step; use step().')
+        if not (isinstance(actions, torch.Tensor) and actions.dtype == torch.float32 and actions.is_contiguous()
+                and actions.ndim == 3 and actions.shape[1:] == (self.action_dim, self._ld)):
+            raise ValueError('[ERROR] rollout() needs a contiguous float32 [T, %d, %d] device tensor.'
+                             % (self.action_dim, self._ld))
+        steps = actions.shape[0] if steps is None else int(steps)
+        io = dict(self._bufs)
+        io['reset_state'] = self._reset_state_buf
+        self._engine.rollout(io, self.num_envs, self._ld, self._serial, steps, actions)
+        self._serial += steps
+        k = (steps - 1) % actions.shape[0]
+        self._raw_action = actions[k]
+        self.current_raw_input_action = actions[k][:, :self.num_envs].T
+
+    @property
+    def plane_stride(self):
+        self._ensure_engine()
+        return self._ld
 
     def set_init_states(self, init_states):
         """Per-env nominal reset states [N, nx] (replaces the single ``init_state`` for every later reset)."""
@@ -455,7 +482,10 @@ class BenchmarkEnv:
         n, nu = self.num_envs, self.action_dim
         if isinstance(action, torch.Tensor):
             if action.data_ptr() == buf.data_ptr():
-                return
+                return buf
+            if (action.shape == (nu, self._ld) and action.dtype == torch.float32 and action.is_contiguous()
+                    and action.device == buf.device):
+                return action                      # already SoA with the engine's plane stride: zero copy
             a = action.to(device=self.device, dtype=torch.float32)
         else:
             a = torch.as_tensor(np.asarray(action, dtype=np.float32), device=self.device)
@@ -468,14 +498,17 @@ class BenchmarkEnv:
         else:
             raise ValueError('[ERROR] action must have shape (num_envs, action_dim) = (%d, %d), got %s'
                              % (n, nu, tuple(a.shape)))
+        return buf
 
     def step(self, action):
         """Advance every env by one control step (quadrotor.py:507-558 + benchmark_env.py:422-463)."""
         self._check_initial_reset()
-        self._load_action(action)
-        self.current_raw_input_action = self.action_buffer
+        act = self._load_action(action)
+        self._raw_action = act
+        self.current_raw_input_action = act[:, :self.num_envs].T
         b = self._bufs
         io = dict(b)
+        io['action'] = act
         io['reset_state'] = self._reset_state_buf
         # disturbances (quadrotor.py:526-548,835-838,879-880): noise planes generated on device
         if 'action' in self.disturbances or self.adversary_disturbance == 'action':

@@ -68,18 +68,34 @@ class Engine:
                                            p(bufs.get('ep_length')), p(bufs.get('obs')), p(mask),
                                            p(reset_state), serial & 0xffffffff, ld, n, self._stream()), 'scg_reset')
 
-    def step(self, bufs, n, ld, serial):
-        io, p = self._io, _capi.ptr
+    _IO_FIELDS = ('action', 'action_disturbance', 'dynamics_force', 'obs_noise', 'reset_state', 'state',
+                  'state_lo', 'step_count', 'ep_return', 'ep_length', 'obs', 'reward', 'done',
+                  'constraint_values', 'constraint_violation', 'truncated', 'goal_reached', 'mse',
+                  'terminal_obs', 'last_ep_return', 'last_ep_length', 'stats')
+
+    def _bind(self, bufs, ld):
+        io = self._io
         io.ld = ld
-        for name in ('action', 'action_disturbance', 'dynamics_force', 'obs_noise', 'reset_state', 'state',
-                     'state_lo', 'step_count', 'ep_return', 'ep_length', 'obs', 'reward', 'done',
-                     'constraint_values', 'constraint_violation', 'truncated', 'goal_reached', 'mse',
-                     'terminal_obs', 'last_ep_return', 'last_ep_length', 'stats'):
+        for name in self._IO_FIELDS:
             t = bufs.get(name)
             setattr(io, name, None if t is None else t.data_ptr())
+        return io
+
+    def step(self, bufs, n, ld, serial):
+        io = self._bind(bufs, ld)
         io.reset_serial = serial & 0xffffffff
         with torch.cuda.device(self.device):
             _capi.check(self.lib.scg_step(self.handle, C.byref(io), n, self._stream()), 'scg_step')
+
+    def rollout(self, bufs, n, ld, serial, steps, actions):
+        """``steps`` launches; ``actions`` is a contiguous [period, nu, ld] float32 tensor used cyclically."""
+        io = self._bind(bufs, ld)
+        io.action = actions.data_ptr()
+        io.reset_serial = serial & 0xffffffff
+        period, stride = actions.shape[0], actions.shape[1] * actions.shape[2]
+        with torch.cuda.device(self.device):
+            _capi.check(self.lib.scg_rollout(self.handle, C.byref(io), n, steps, stride, period, self._stream()),
+                        'scg_rollout')
 
     def eval_constraints(self, env, action_soa):
         """[N, num_device_rows] values of this engine's constraint table on env's state."""
