@@ -95,6 +95,10 @@ _LIB = None
 
 
 def library_path():
+    """In-tree library; SCG_ROLLOUT_LIB overrides it (used by tools/tune.py to A/B kernel builds)."""
+    override = os.environ.get('SCG_ROLLOUT_LIB')
+    if override:
+        return override
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libscg_rollout.so')
 
 

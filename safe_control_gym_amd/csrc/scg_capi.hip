@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -264,9 +265,13 @@ int scg_set_reference(scg_handle* h, const double* x_goal, int32_t rows) {
     HIP_TRY(hipMemcpy(h->d_ref, tmp.data(), count * sizeof(float), hipMemcpyHostToDevice));
     h->ref_rows = rows;
     h->kp.ref_rows = rows;
-    // stage in LDS when it leaves room for >= 2 workgroups per CU; otherwise read through L1/L2
+    // Reference-table placement.  Default: gathered from global memory through L1/L2 (measured faster
+    // at the default table size).  SCG_REF_IN_LDS=1 stages it in LDS instead
+    // (when it leaves room for >= 2 workgroups per CU).
+    const char* lds_env = getenv("SCG_REF_IN_LDS");
+    const bool want_lds = lds_env && lds_env[0] == '1';
     const int lds_budget = h->max_lds_bytes > 0 ? h->max_lds_bytes / 2 : 32768;
-    if ((int64_t)bytes <= lds_budget) h->kp.flags |= F_REF_IN_LDS; else h->kp.flags &= ~F_REF_IN_LDS;
+    if (want_lds && (int64_t)bytes <= lds_budget) h->kp.flags |= F_REF_IN_LDS; else h->kp.flags &= ~F_REF_IN_LDS;
     return SCG_OK;
 }
 

@@ -15,11 +15,30 @@
 // contraction worth a matrix core; the kernel is HBM-bandwidth bound.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "scg_device.h"
 
 namespace scg {
 
-constexpr int kBlock = 256;
+// Build-time tunables (defaults are the measured best: DESIGN.md section 6).
+#ifndef SCG_BLOCK
+#define SCG_BLOCK 256          // threads per workgroup
+#endif
+#ifndef SCG_MIN_WAVES
+#define SCG_MIN_WAVES 0        // 2nd __launch_bounds__ argument (waves per SIMD the allocator must allow); 0 = unset
+#endif
+#ifndef SCG_PREFETCH
+#define SCG_PREFETCH 0         // load the next grid-stride iteration's lane inputs before computing this one
+#endif
+#ifndef SCG_NT
+#define SCG_NT 1               // nontemporal hint on the streamed planes (measured -5% kernel time)
+#endif
+constexpr int kBlock = SCG_BLOCK;
+#if SCG_MIN_WAVES > 0
+#define SCG_BOUNDS __launch_bounds__(kBlock, SCG_MIN_WAVES)
+#else
+#define SCG_BOUNDS __launch_bounds__(kBlock)
+#endif
 
 template <int SYS> struct Dim;
 template <> struct Dim<SCG_QUAD_1D> { static constexpr int NX = 2, NU = 1; };
@@ -32,7 +51,11 @@ template <> struct Dim<SCG_CARTPOLE> { static constexpr int NX = 4, NU = 1; };
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float rcp_f(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32, 1 ulp
 __device__ __forceinline__ float sqrt_f(float x) { return __builtin_amdgcn_sqrtf(x); }    // v_sqrt_f32, 1 ulp
-__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+// clamp as ONE v_med3_f32 (fminf(fmaxf()) costs two extra canonicalising v_max_f32 per call)
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+// make a wave-uniform 64-bit value opaque to CSE: the expression that uses it is re-evaluated on the
+// scalar unit at each use instead of being kept alive (and spilled) across the ~1200-instruction body
+__device__ __forceinline__ int64_t opaque_s(int64_t v) { asm volatile("" : "+s"(v)); return v; }
 
 // Plane access with a wave-uniform base and a 32-bit per-lane BYTE offset: lowers to the
 // `global_load_dword v, v_off, s[base:base+1]` (saddr) form -- one VGPR of address for every plane
@@ -47,11 +70,19 @@ __device__ __forceinline__ T* uptr(T* p) {       // pin a wave-uniform pointer i
 }
 template <class T>
 __device__ __forceinline__ T ldp(const T* base, uint32_t boff) {
+#if SCG_NT
+    return __builtin_nontemporal_load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + boff));
+#else
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + boff);
+#endif
 }
 template <class T>
 __device__ __forceinline__ void stp(T* base, uint32_t boff, T v) {
+#if SCG_NT
+    __builtin_nontemporal_store(v, reinterpret_cast<T*>(reinterpret_cast<char*>(base) + boff));
+#else
     *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + boff) = v;
+#endif
 }
 
 // sin and cos together.  Cody-Waite reduction by pi/2 (two fp32 pieces, each applied with one
@@ -59,7 +90,15 @@ __device__ __forceinline__ void stp(T* base, uint32_t boff, T v) {
 // polynomials on [-pi/4, pi/4] fitted for this kernel (max abs error 9.3e-8 = 0.8 ulp(1) for
 // |x| <= 1000, measured against float64 sin/cos over 2e6 points: DESIGN.md section 5).
 // ~20 VALU ops for the pair instead of two libm calls with their slow-path range reduction.
+#ifndef SCG_FAST_TRIG
+#define SCG_FAST_TRIG 0        // 1: hardware v_sin_f32 / v_cos_f32 (tuning experiment; ~1e-6 abs error)
+#endif
 __device__ __forceinline__ void sincos_f(float x, float& s, float& c) {
+#if SCG_FAST_TRIG
+    const float rev = x * 0.15915494309189535f;                 // revolutions
+    s = __builtin_amdgcn_sinf(rev);
+    c = __builtin_amdgcn_cosf(rev);
+#else
     const float kf = rintf(x * 0.636619772367581343f);          // x * 2/pi
     const int k = (int)kf;
     float r = fmaf(kf, -1.5707963705062866f, x);                // fl32(pi/2)
@@ -78,6 +117,7 @@ __device__ __forceinline__ void sincos_f(float x, float& s, float& c) {
     const float cc = (k & 1) ? sr : cr;
     s = (k & 2) ? -ss : ss;
     c = ((k + 1) & 2) ? -cc : cc;
+#endif
 }
 
 // Philox4x32-10 (Salmon et al., SC'11).  Counter layout shared with oracle/philox.py.
@@ -100,8 +140,13 @@ template <int NX>
 __device__ __forceinline__ void reset_state_of(const KParams& p, const KTables* __restrict__ tb,
                                                const float* __restrict__ reset_state, int64_t ld, uint32_t i,
                                                uint32_t serial, float (&x)[NX]) {
+    if (reset_state) {
 #pragma unroll
-    for (int j = 0; j < NX; ++j) x[j] = reset_state ? ldp(uptr(reset_state + j * ld), i * 4u) : tb->init_state[j];
+        for (int j = 0; j < NX; ++j) x[j] = ldp(uptr(reset_state + j * opaque_s(ld)), i * 4u);
+    } else {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) x[j] = tb->init_state[j];
+    }
     if (p.flags & F_RAND_INIT) {
         const uint64_t g = (uint64_t)(p.env_base + (int64_t)i);
 #pragma unroll
@@ -116,6 +161,66 @@ __device__ __forceinline__ void reset_state_of(const KParams& p, const KTables* 
                     x[d] += fmaf(tb->init_span[d], u, tb->init_lo[d]);
                 }
             }
+        }
+    }
+}
+
+// Wave-cooperative version of reset_state_of for the fused auto-reset.  A lane that needs a reset needs
+// ceil(NX/4) Philox blocks; with one lane per env those evaluations would run with most of the wave idle
+// (typically a few lanes of 64 are done), yet the whole wave pays for them.  Instead the wave's lanes
+// share the work: the resetting lanes publish their env index in LDS, EVERY lane evaluates ONE Philox
+// block for one (env, block) job, and the uniforms travel back through LDS.  Same counters, same draws,
+// bit for bit, as the per-lane form; 1 Philox evaluation per wave instead of 3 (3-D) per pass of
+// 64/ceil(NX/4) resetting lanes.  `scratch` is kCoopFloats floats of LDS private to this wave.
+constexpr int kCoopFloats = 64 + 64 * 4;
+
+template <int NX>
+__device__ __forceinline__ void reset_state_coop(const KParams& p, const KTables* __restrict__ tb,
+                                                 const float* __restrict__ reset_state, int64_t ld, uint32_t i,
+                                                 uint32_t serial, bool need, float* scratch, float (&x)[NX]) {
+    constexpr int NB = (NX + 3) / 4;          // Philox blocks per env
+    constexpr int W = 4 * NB;                 // uniforms per env (>= NX)
+    constexpr int JOBS = 64 / NB;             // envs served per pass
+    const unsigned long long exec = __ballot(1);
+    if (!(p.flags & F_RAND_INIT) || exec != ~0ull) {
+        // no randomisation, or a ragged last wave: plain per-lane path
+        if (need) reset_state_of<NX>(p, tb, reset_state, ld, i, serial, x);
+        return;
+    }
+    if (need) {
+        if (reset_state) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) x[j] = ldp(uptr(reset_state + j * opaque_s(ld)), i * 4u);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) x[j] = tb->init_state[j];
+        }
+    }
+    const unsigned long long m = __ballot(need);
+    const int lane = (int)__lane_id();
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    const int total = __popcll(m);
+    uint32_t* s_idx = reinterpret_cast<uint32_t*>(scratch);
+    float* s_u = scratch + 64;
+    if (need) s_idx[rank] = i;
+    const int k = lane / NB, blk = lane - k * NB;
+    for (int base = 0; base < total; base += JOBS) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");     // LDS writes above visible to the wave's reads
+        __builtin_amdgcn_wave_barrier();
+        const int slot = base + k;
+        if (lane < JOBS * NB && slot < total) {
+            const uint64_t g = (uint64_t)(p.env_base + (int64_t)s_idx[slot]);
+            uint32_t w[4];
+            philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), serial, (uint32_t)blk, p.seed_lo, p.seed_hi, w);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s_u[k * W + 4 * blk + q] = (float)(w[q] >> 8) * 5.9604644775390625e-8f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (need && rank >= base && rank < base + JOBS) {
+            const float* mine = s_u + (rank - base) * W;
+#pragma unroll
+            for (int d = 0; d < NX; ++d) x[d] += fmaf(tb->init_span[d], mine[d], tb->init_lo[d]);
         }
     }
 }
@@ -327,7 +432,12 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// goal row for a lane-local step index; read from the LDS-staged table when it is staged.
+// goal row for a lane-local step index: X_GOAL[row] (NX floats, rows are 8- or 16-byte aligned).
+// Default path: vector gathers straight from the table in global memory -- it is tiny (14.4 KB for the
+// 300-step 3-D reference), read by every wave and therefore L1/L2-resident; lanes at the same step
+// counter coalesce.  Optional path (F_REF_IN_LDS): the table staged once per workgroup into LDS.
+// Measured on MI355X at 2^20 envs: the LDS fill + barrier costs ~10% more than
+// the cached gathers it saves, so the gather is the default.
 template <int NX>
 __device__ __forceinline__ void load_goal(const KParams& p, const float* __restrict__ ref_glb, int row,
                                           float (&g)[NX]) {
@@ -336,9 +446,20 @@ __device__ __forceinline__ void load_goal(const KParams& p, const float* __restr
     if (p.flags & F_REF_IN_LDS) {
 #pragma unroll
         for (int j = 0; j < NX; ++j) g[j] = s_ref[row * NX + j];
-    } else {
+    } else if (NX % 4 == 0) {
+        const float4* src = reinterpret_cast<const float4*>(ref_glb + row * NX);
 #pragma unroll
-        for (int j = 0; j < NX; ++j) g[j] = ref_glb[row * NX + j];
+        for (int q = 0; q < NX / 4; ++q) {
+            const float4 v = src[q];
+            g[4 * q] = v.x; g[4 * q + 1] = v.y; g[4 * q + 2] = v.z; g[4 * q + 3] = v.w;
+        }
+    } else {
+        const float2* src = reinterpret_cast<const float2*>(ref_glb + row * NX);
+#pragma unroll
+        for (int q = 0; q < NX / 2; ++q) {
+            const float2 v = src[q];
+            g[2 * q] = v.x; g[2 * q + 1] = v.y;
+        }
     }
 }
 
@@ -349,6 +470,8 @@ __device__ __forceinline__ void load_goal(const KParams& p, const float* __restr
 // wave-uniform, so each access is `global_load_dword v, v_off, s[base:base+1]` -- one VGPR of
 // address for all ~30 planes instead of a 64-bit VGPR pair per plane.
 #define PL(ptr, j) uptr((ptr) + (int64_t)(j) * ld)
+// store-side twin of PL: same address, recomputed (2-4 SALU ops) rather than carried in SGPRs
+#define PLS(ptr, j) uptr((ptr) + (int64_t)(j) * opaque_s(ld))
 
 // Compile-time feature tiers.  Every optional part of step() is wave-uniform, but leaving all
 // of them as run-time branches costs ~200 scalar branches, 300+ spilled SGPRs and 160 VGPRs
@@ -363,7 +486,7 @@ enum Feat : uint32_t {
 };
 
 template <int SYS, bool COMP, uint32_t FT>
-__global__ __launch_bounds__(kBlock) void scg_step_kernel(const KParams p, const scg_step_io io,
+__global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io,
                                                           const KTables* __restrict__ tb,
                                                           const ConTable* __restrict__ ct,
                                                           const float* __restrict__ ref, const uint32_t n) {
@@ -374,6 +497,46 @@ __global__ __launch_bounds__(kBlock) void scg_step_kernel(const KParams p, const
     const bool tracking = EXTRA ? ((p.flags & F_TRACKING) != 0) : ((FT & FT_TRACK) != 0);
     const bool has_con = EXTRA ? (p.n_con_rows > 0) : ((FT & FT_CON) != 0);
 
+    // per-wave LDS scratch of the cooperative reset, placed after the (16-B padded) reference table
+    float* coop_scratch = s_ref + ((tracking && (p.flags & F_REF_IN_LDS)) ? (((p.ref_rows * NX + 3) >> 2) << 2) : 0) +
+                          (threadIdx.x >> 6) * kCoopFloats;
+
+    const int64_t ld = io.ld;
+    float st_rew = 0.f, st_done = 0.f, st_viol = 0.f, st_fret = 0.f, st_flen = 0.f, st_trunc = 0.f;
+
+    // Per-lane inputs of one env.  With SCG_PREFETCH the next grid-stride iteration's inputs are
+    // requested before this iteration's arithmetic, so their HBM latency hides under ~1200 VALU ops.
+    struct LaneIn {
+        float x[NX], a_raw[NU], xlo[COMP ? NX : 1];
+        int t, epl;
+        float epr, fx, fy, fz;
+    };
+    auto load_lane = [&](LaneIn& L, uint32_t idx) {
+        const uint32_t b4 = idx * 4u;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) L.x[j] = ldp(PL(io.state, j), b4);
+#pragma unroll
+        for (int j = 0; j < NU; ++j) L.a_raw[j] = ldp(PL(io.action, j), b4);
+        L.t = ldp(io.step_count, b4);                                       // ctrl_step_counter (pre-increment)
+        if (COMP) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) L.xlo[j] = ldp(PL(io.state_lo, j), b4);
+        }
+        L.epr = 0.f; L.epl = 0;
+        if (io.ep_return) L.epr = ldp(io.ep_return, b4);
+        if (io.ep_length) L.epl = ldp(io.ep_length, b4);
+        L.fx = L.fy = L.fz = 0.f;
+        if (EXTRA && io.dynamics_force) {
+            L.fx = ldp(PL(io.dynamics_force, 0), b4); L.fy = ldp(PL(io.dynamics_force, 1), b4);
+            L.fz = ldp(PL(io.dynamics_force, 2), b4);
+        }
+    };
+
+    const uint32_t stride = gridDim.x * kBlock;
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    LaneIn cur;
+    if (i < n) load_lane(cur, i);                 // first lane inputs are in flight while the table is staged
+
     if (tracking && (p.flags & F_REF_IN_LDS)) {
         // stage X_GOAL (quadrotor.py:280-325) once per workgroup; rows*NX floats, 16-B vector copies
         const int total4 = (p.ref_rows * NX + 3) >> 2;                      // buffer is padded to 16 B
@@ -383,31 +546,24 @@ __global__ __launch_bounds__(kBlock) void scg_step_kernel(const KParams p, const
         __syncthreads();
     }
 
-    const int64_t ld = io.ld;
-    float st_rew = 0.f, st_done = 0.f, st_viol = 0.f, st_fret = 0.f, st_flen = 0.f, st_trunc = 0.f;
-
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    for (; i < n; i += stride) {
         const uint32_t i4 = i * 4u;
-        // ---- loads (issued together: NX+NU+1 independent 256-B wave transactions in flight)
-        float x[NX], a_raw[NU];
+        const uint32_t inext = i + stride;
+        LaneIn nxt;
+        if (SCG_PREFETCH && inext < n) load_lane(nxt, inext);
+        // ---- this lane's inputs (NX+NU+1 independent 256-B wave transactions were issued together)
+        float x[NX], a_raw[NU], xlo[COMP ? NX : 1];
 #pragma unroll
-        for (int j = 0; j < NX; ++j) x[j] = ldp(PL(io.state, j), i4);
+        for (int j = 0; j < NX; ++j) x[j] = cur.x[j];
 #pragma unroll
-        for (int j = 0; j < NU; ++j) a_raw[j] = ldp(PL(io.action, j), i4);
-        const int t = ldp(io.step_count, i4);                               // ctrl_step_counter (pre-increment)
-        float xlo[NX];
+        for (int j = 0; j < NU; ++j) a_raw[j] = cur.a_raw[j];
         if (COMP) {
 #pragma unroll
-            for (int j = 0; j < NX; ++j) xlo[j] = ldp(PL(io.state_lo, j), i4);
+            for (int j = 0; j < NX; ++j) xlo[j] = cur.xlo[j];
         }
-        float epr = 0.f; int epl = 0;
-        if (io.ep_return) epr = ldp(io.ep_return, i4);
-        if (io.ep_length) epl = ldp(io.ep_length, i4);
-        float fx = 0.f, fy = 0.f, fz = 0.f;
-        if (EXTRA && io.dynamics_force) {
-            fx = ldp(PL(io.dynamics_force, 0), i4); fy = ldp(PL(io.dynamics_force, 1), i4);
-            fz = ldp(PL(io.dynamics_force, 2), i4);
-        }
+        const int t = cur.t;
+        float epr = cur.epr; int epl = cur.epl;
+        const float fx = cur.fx, fy = cur.fy, fz = cur.fz;
 
         // ---- before_step / _preprocess_control (benchmark_env.py:394-404, quadrotor.py:815-842)
         float a_clip[NU], u[NU];
@@ -564,14 +720,39 @@ __global__ __launch_bounds__(kBlock) void scg_step_kernel(const KParams p, const
         if (done) {
             if (EXTRA) {
                 if (io.terminal_obs) {
+                    // the observation step() would have returned without the auto-reset (dummy_vec_env.py:43):
+                    // state (+ observation noise) + the goal extension of extend_obs(obs, t + 1)
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) stp(PL(io.terminal_obs, j), i4, x[j]);
+                    for (int j = 0; j < NX; ++j) {
+                        float o = x[j];
+                        if (io.obs_noise) o += ldp(PL(io.obs_noise, j), i4);
+                        stp(PLS(io.terminal_obs, j), i4, o);
+                    }
+                    if (p.obs_goal_horizon > 0) {
+                        if (tracking) {
+                            for (int k = 0; k < p.obs_goal_horizon; ++k) {
+                                float g[NX];
+                                load_goal<NX>(p, ref, t + 1 + k, g);
+#pragma unroll
+                                for (int j = 0; j < NX; ++j) stp(PLS(io.terminal_obs, NX * (1 + k) + j), i4, g[j]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < NX; ++j) stp(PLS(io.terminal_obs, NX + j), i4, tb->x_goal[j]);
+                        }
+                    }
                 }
                 if (io.last_ep_return) stp(io.last_ep_return, i4, epr);
                 if (io.last_ep_length) stp(io.last_ep_length, i4, epl);
             }
-            if (p.flags & F_AUTO_RESET) {
-                reset_state_of<NX>(p, tb, io.reset_state, ld, i, io.reset_serial, x);
+        }
+        const bool need_reset = done && (p.flags & F_AUTO_RESET);
+        if (__ballot(need_reset)) {                                         // wave-uniform
+            float xr[NX];
+            reset_state_coop<NX>(p, tb, io.reset_state, ld, i, io.reset_serial, need_reset, coop_scratch, xr);
+            if (need_reset) {
+#pragma unroll
+                for (int j = 0; j < NX; ++j) x[j] = xr[j];
                 if (COMP) {
 #pragma unroll
                     for (int j = 0; j < NX; ++j) xlo[j] = 0.f;
@@ -583,10 +764,10 @@ __global__ __launch_bounds__(kBlock) void scg_step_kernel(const KParams p, const
 
         // ---- stores
 #pragma unroll
-        for (int j = 0; j < NX; ++j) stp(PL(io.state, j), i4, x[j]);
+        for (int j = 0; j < NX; ++j) stp(PLS(io.state, j), i4, x[j]);
         if (COMP) {
 #pragma unroll
-            for (int j = 0; j < NX; ++j) stp(PL(io.state_lo, j), i4, xlo[j]);
+            for (int j = 0; j < NX; ++j) stp(PLS(io.state_lo, j), i4, xlo[j]);
         }
         stp(io.step_count, i4, t_out);
         if (io.ep_return) stp(io.ep_return, i4, epr);
@@ -618,6 +799,10 @@ __global__ __launch_bounds__(kBlock) void scg_step_kernel(const KParams p, const
                 }
             }
         }
+
+        // ---- next grid-stride iteration's inputs
+        if (SCG_PREFETCH) cur = nxt;
+        else if (inext < n) load_lane(cur, inext);
     }
 
     if (EXTRA && io.stats) {
@@ -723,11 +908,18 @@ LaunchGeom step_geometry(const KParams& p, int system, int64_t n, int num_cus) {
     g.block = kBlock;
     int64_t blocks = (n + kBlock - 1) / kBlock;
     g.lds_bytes = 0;
+    if ((p.flags & F_AUTO_RESET) && (p.flags & F_RAND_INIT))
+        g.lds_bytes += (kBlock / 64) * kCoopFloats * (int)sizeof(float);     // cooperative-reset scratch
     if ((p.flags & F_TRACKING) && (p.flags & F_REF_IN_LDS)) {
-        g.lds_bytes = p.ref_rows * nx_of(system) * (int)sizeof(float);
-        g.lds_bytes = (g.lds_bytes + 15) & ~15;
+        int table = p.ref_rows * nx_of(system) * (int)sizeof(float);
+        g.lds_bytes += (table + 15) & ~15;
         // amortise the LDS fill: a few resident workgroups per CU, grid-stride over the envs
-        const int64_t cap = (int64_t)num_cus * 8;
+        static const int cap_per_cu = [] {
+            const char* e = getenv("SCG_GRID_CAP_PER_CU");   // tuning knob; default measured best
+            const int v = e ? atoi(e) : 0;
+            return v > 0 ? v : 8;
+        }();
+        const int64_t cap = (int64_t)num_cus * cap_per_cu;
         if (blocks > cap) blocks = cap;
     }
     if (blocks < 1) blocks = 1;

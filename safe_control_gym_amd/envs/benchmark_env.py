@@ -354,7 +354,7 @@ class BenchmarkEnv:
         if self.INFO_LEVEL == 'full':
             b['mse'] = torch.zeros(ld, dtype=f32, device=dev)
             b['truncated'] = torch.zeros(ld, dtype=torch.uint8, device=dev)
-            b['terminal_obs'] = torch.zeros((nx, ld), dtype=f32, device=dev)
+            b['terminal_obs'] = torch.zeros((self.obs_dim, ld), dtype=f32, device=dev)
             if self.TASK == Task.STABILIZATION and self.COST == Cost.QUADRATIC:
                 b['goal_reached'] = torch.zeros(ld, dtype=torch.uint8, device=dev)
             if self.TRACK_EPISODE_STATS:

@@ -149,6 +149,9 @@ class Quadrotor(BenchmarkEnv):
             elif self.QUAD_TYPE == QuadType.TWO_D:
                 self.X_GOAL = np.hstack([g[0], 0.0, g[1], 0.0, 0.0, 0.0])
             else:
+                if len(g) < 3:      # the reference indexes goal[2] (quadrotor.py:277) -> the same IndexError, explained
+                    raise IndexError("[ERROR] 3-D stabilization needs task_info['stabilization_goal'] = [x, y, z] "
+                                     '(the default TASK_INFO holds the 2-D goal [0, 1]).')
                 self.X_GOAL = np.hstack([g[0], 0.0, g[1], 0.0, g[2], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0])
         else:
             pos, vel, _ = self._generate_trajectory(traj_type=ti['trajectory_type'],

@@ -1,0 +1,247 @@
+"""CPU-only tests of the host-side mirror of the reference interface (no GPU compute calls)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import safe_control_gym_amd as scg
+from safe_control_gym_amd import _capi
+from safe_control_gym_amd.envs.benchmark_env import Cost, Task, Environment
+from safe_control_gym_amd.envs.constraints import (BoundedConstraint, DefaultConstraint, LinearConstraint,
+                                                   QuadraticContstraint, ConstraintList, GENERAL_CONSTRAINTS)
+from safe_control_gym_amd.envs.spaces import Box
+from oracle.ref_env import RefEnv
+from oracle.ref_constraints import create_ref_constraint_list
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_registry_surface():
+    """register / make / spec / get_config as in utils/registration.py:138-161."""
+    cfg = scg.get_config('quadrotor')
+    assert cfg['ctrl_freq'] == 60 and cfg['pyb_freq'] == 240 and cfg['quad_type'] == 2
+    assert scg.spec('quadrotor').id == 'quadrotor'
+    with pytest.raises(Exception, match='Cannot re-register'):
+        scg.register(id='quadrotor', entry_point='x:y')
+    with pytest.raises(Exception, match='Key not found'):
+        scg.spec('nope')
+    env = scg.make('quadrotor', num_envs=3)
+    assert env.spec.id == 'quadrotor' and env.NAME == 'quadrotor' and env.num_envs == 3
+    assert scg.make('cartpole', num_envs=2).NAME == 'cartpole'
+
+
+def test_enums_match_reference_values():
+    assert Cost('rl_reward') == Cost.RL_REWARD and Cost('quadratic') == Cost.QUADRATIC
+    assert Task('stabilization') == Task.STABILIZATION and Task('traj_tracking') == Task.TRAJ_TRACKING
+    assert Environment.CARTPOLE == 'cartpole' and Environment.QUADROTOR == 'quadrotor'
+
+
+@pytest.mark.parametrize('quad_type,nx,nu', [(1, 2, 1), (2, 6, 2), (3, 12, 4)])
+def test_quadrotor_spaces_and_goals_match_oracle(quad_type, nx, nu):
+    ti = {'stabilization_goal': [0.3, 1.1, 0.7], 'stabilization_goal_tolerance': 0.05}
+    for task in ('stabilization', 'traj_tracking'):
+        kw = dict(task=task, ctrl_freq=60, pyb_freq=240, cost='quadratic')
+        if task == 'stabilization':
+            kw['task_info'] = ti
+        env = scg.make('quadrotor', quad_type=quad_type, num_envs=2, **kw)
+        ref = RefEnv(system=quad_type, **kw)
+        assert env.state_dim == nx and env.action_dim == nu and env.obs_dim == nx
+        assert np.array_equal(env.action_space.low.astype(np.float64), ref.action_space_low)
+        assert np.array_equal(env.action_space.high.astype(np.float64), ref.action_space_high)
+        assert np.array_equal(env.state_space.low.astype(np.float64), ref.state_space_low)
+        assert np.array_equal(env.state_space.high.astype(np.float64), ref.state_space_high)
+        assert env.action_space.low.dtype == np.float32
+        assert np.max(np.abs(env.X_GOAL - ref.X_GOAL)) < 1e-15
+        assert np.array_equal(env.U_GOAL, ref.U_GOAL) and np.array_equal(env.U_EQ, env.U_GOAL)
+        assert env.CTRL_STEPS == 300 and env.PYB_STEPS_PER_CTRL == 4 and env.CTRL_TIMESTEP == 1 / 60
+
+
+@pytest.mark.parametrize('traj', ['circle', 'figure8', 'square'])
+@pytest.mark.parametrize('plane', ['zx', 'xy', 'xz'])
+def test_reference_tables_match_oracle(traj, plane):
+    ti = dict(scg.make('quadrotor', num_envs=1).TASK_INFO)
+    ti.update(trajectory_type=traj, trajectory_plane=plane, num_cycles=2, trajectory_position_offset=[0.2, -0.1],
+              trajectory_scale=0.7)
+    for qt in (1, 2, 3):
+        kw = dict(task='traj_tracking', task_info=ti, ctrl_freq=50, pyb_freq=50, episode_len_sec=7)
+        env = scg.make('quadrotor', quad_type=qt, num_envs=1, **kw)
+        ref = RefEnv(system=qt, **kw)
+        assert env.X_GOAL.shape == ref.X_GOAL.shape == (350, env.state_dim)
+        assert np.max(np.abs(env.X_GOAL - ref.X_GOAL)) < 1e-14
+
+
+def test_obs_goal_horizon_widens_observation_space():
+    env = scg.make('quadrotor', quad_type=2, num_envs=1, task='traj_tracking', cost='rl_reward', obs_goal_horizon=3)
+    assert env.obs_dim == 6 * 4 and env.state_dim == 6
+    env = scg.make('quadrotor', quad_type=2, num_envs=1, task='stabilization', cost='rl_reward', obs_goal_horizon=3)
+    assert env.obs_dim == 12
+    env = scg.make('quadrotor', quad_type=2, num_envs=1, task='traj_tracking', cost='quadratic', obs_goal_horizon=3)
+    assert env.obs_dim == 6                         # quadrotor.py:794: only for rl_reward
+
+
+def test_error_conventions():
+    """Exception types of the reference ('Error conventions')."""
+    with pytest.raises(ValueError, match='not divisible'):
+        scg.make('quadrotor', num_envs=1, pyb_freq=100, ctrl_freq=60)
+    with pytest.raises(ValueError, match='init_state incorrect format'):
+        scg.make('quadrotor', num_envs=1, init_state=[0, 0])
+    with pytest.raises(ValueError, match='inertial_prop incorrect format'):
+        scg.make('quadrotor', num_envs=1, inertial_prop=[1, 2, 3])
+    with pytest.raises(ValueError, match='info_mse_metric_state_weight'):
+        scg.make('quadrotor', num_envs=1, info_mse_metric_state_weight=[1, 0])
+    env = scg.make('quadrotor', num_envs=4)
+    with pytest.raises(RuntimeError, match='reset'):                    # benchmark_env.py:268-275
+        env.step(np.zeros((4, 2), dtype=np.float32))
+    with pytest.raises(RuntimeError, match='adversary_disturbance does not exist'):
+        env.set_adversary_control(np.zeros((4, 2)))
+    with pytest.raises(AssertionError):
+        scg.make('quadrotor', num_envs=1, constraints=[{'constrained_variable': 'state'}])
+    with pytest.raises(AssertionError):
+        scg.make('quadrotor', num_envs=1, constraints=[{'constraint_form': 'nope', 'constrained_variable': 'state'}])
+    with pytest.raises(AssertionError):
+        scg.make('quadrotor', num_envs=1, disturbances={'action': [{'disturbance_func': 'nope'}]})
+    with pytest.raises(NotImplementedError):
+        scg.make('quadrotor', num_envs=1, cost='competition')
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
+def test_engine_fails_loudly_without_gpu():
+    env = scg.make('quadrotor', num_envs=4)
+    with pytest.raises(_capi.ScgError, match='no ROCm device|ROCm device only'):
+        env.reset()
+
+
+def test_box_space():
+    b = Box(low=np.array([-1.0, 0.0]), high=np.array([1.0, 2.0]))
+    b.seed(3)
+    s = b.sample()
+    assert s.dtype == np.float32 and b.contains(s) and b.sample(5).shape == (5, 2)
+    assert not b.contains(np.array([2.0, 0.0], dtype=np.float32))
+
+
+CONSTRAINT_SPECS = [
+    [{'constraint_form': 'default_constraint', 'constrained_variable': 'input'},
+     {'constraint_form': 'default_constraint', 'constrained_variable': 'state'}],
+    [{'constraint_form': 'default_constraint', 'constrained_variable': 'input', 'strict': True},
+     {'constraint_form': 'bounded_constraint', 'constrained_variable': 'state', 'active_dims': [0, 2, 4],
+      'upper_bounds': [3, 3, 2], 'lower_bounds': [-3, -3, -0.1], 'tolerance': [0.1] * 6}],
+    [{'constraint_form': 'linear_constraint', 'constrained_variable': 'state', 'A': [[1.0, 0.5, 0, 0, 0, 0], [0, 0, 1.0, -1.0, 0.2, 0]],
+      'b': [1.0, 2.0]},
+     {'constraint_form': 'quadratic_constraint', 'constrained_variable': 'input', 'P': [[2.0, 0.1], [0.1, 1.0]], 'b': 0.5},
+     {'constraint_form': 'linear_constraint', 'constrained_variable': 'input_and_state',
+      'A': [[1, 0, 0, 0, 0, 0, 1.0, -1.0]], 'b': [0.3]}],
+]
+
+
+@pytest.mark.parametrize('specs', CONSTRAINT_SPECS)
+def test_constraint_rows_reproduce_oracle_values(specs):
+    """The rows handed to scg_set_constraints, evaluated in float64 on the host, equal the oracle's values."""
+    env = scg.make('quadrotor', quad_type=2, num_envs=1, constraints=specs)
+    ref = RefEnv(system=2, constraints=specs)
+    cl = env.constraints
+    assert cl.num_constraints == ref.constraints.num_constraints
+    rows, n_rows, pmats, n_p = cl.compile_rows()
+    rng = np.random.default_rng(0)
+    P = np.array(list(pmats)).reshape(-1, 16, 16) if n_p else None
+    for _ in range(20):
+        x, a = rng.normal(size=6), rng.uniform(0.0, 0.35, size=2)
+        ref.state, ref.current_raw_input_action = x, a
+        expect = ref.constraints.get_values(ref)
+        v = np.zeros(16)
+        v[:6], v[6:8] = x, a
+        got = []
+        for r in range(n_rows):
+            row = rows[r]
+            if row.kind == 0:
+                got.append(np.dot(np.array(list(row.coef)), v) - row.b)
+            else:
+                got.append(v @ P[row.p_index] @ v - row.b)
+        assert np.max(np.abs(np.array(got) - expect)) < 1e-7       # oracle rounds to 8 decimals
+    for k, con in enumerate(cl.constraints):
+        assert con.strict == ref.constraints.constraints[k].strict
+
+
+GOAL3 = {'stabilization_goal': [0, 0, 1], 'stabilization_goal_tolerance': 0.05}
+
+
+def test_constraint_classes_keep_reference_attributes():
+    with pytest.raises(IndexError):
+        scg.make('quadrotor', quad_type=3, num_envs=1)         # quadrotor.py:277 indexes goal[2] of the 2-D default
+    env = scg.make('quadrotor', quad_type=3, num_envs=1, task_info=GOAL3)
+    c = BoundedConstraint(env, lower_bounds=[-3, -3, -0.1], upper_bounds=[3, 3, 2], constrained_variable='state',
+                          active_dims=[0, 2, 4])
+    assert c.num_constraints == 6 and c.dim == 3 and c.constraint_filter.shape == (3, 12)
+    assert np.array_equal(c.A, np.vstack([-np.eye(3), np.eye(3)])) and np.array_equal(c.b, [3, 3, 0.1, 3, 3, 2])
+    d = DefaultConstraint(env, constrained_variable='input')
+    assert d.num_constraints == 8 and np.allclose(d.lower_bounds, env.action_space.low)
+    assert d.sym_func(env.U_GOAL).shape == (8,)
+    q = QuadraticContstraint(env, P=np.eye(4), b=1.0, constrained_variable='input')
+    assert q.num_constraints == 1
+    cl = ConstraintList([c, d, q])
+    assert cl.num_constraints == 15 and list(cl.constraint_indices) == [6, 14] and len(cl) == 3
+    assert cl.num_state_constraints == 6 and cl.num_input_constraints == 9
+    assert set(GENERAL_CONSTRAINTS) == {'linear_constraint', 'quadratic_constraint', 'bounded_constraint', 'default_constraint'}
+    with pytest.raises(ValueError, match='tolerance dimension'):
+        BoundedConstraint(env, lower_bounds=[0], upper_bounds=[1], constrained_variable='state', active_dims=[4],
+                          tolerance=[0.1])
+
+
+def test_symbolic_model_surface():
+    env = scg.make('quadrotor', quad_type=3, num_envs=1, task_info=GOAL3)
+    m = env.symbolic
+    assert (m.nx, m.nu, m.ny) == (12, 4, 12) and m.dt == env.CTRL_TIMESTEP
+    x = np.zeros(12); x[4] = 1.0
+    assert np.allclose(m.fc_func(x=x, u=env.U_GOAL)['f'], 0.0, atol=1e-14)
+    assert np.allclose(m.fd_func(x0=x, p=env.U_GOAL)['xf'], x, atol=1e-14)
+    J = m.df_func(x=x, u=env.U_GOAL)
+    assert J['dfdx'].shape == (12, 12) and J['dfdu'].shape == (12, 4)
+    assert J['dfdx'][1, 7] == pytest.approx(9.8)                    # x_ddot = g * theta near hover
+    out = m.loss(x=x, u=env.U_GOAL, Xr=np.zeros(12), Ur=env.U_GOAL, Q=np.eye(12), R=np.eye(4))
+    assert out['l'] == pytest.approx(0.5) and out['l_x'][4] == pytest.approx(1.0)
+
+
+def test_c_abi_header_matches_library_and_binding():
+    """Every function declared in include/scg_rollout.h is exported by the .so and bound by _capi."""
+    header = open(os.path.join(ROOT, 'include', 'scg_rollout.h')).read()
+    declared = set(re.findall(r'^(?:int|const char\*)\s+(scg_\w+)\s*\(', header, flags=re.M))
+    assert {'scg_create', 'scg_destroy', 'scg_set_reference', 'scg_set_constraints', 'scg_reset', 'scg_step',
+            'scg_rollout', 'scg_eval_constraints', 'scg_last_error', 'scg_version'} <= declared
+    lib = _capi.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == set(_capi.EXPORTS)
+    nm = subprocess.run(['nm', '-D', '--defined-only', _capi.library_path()], capture_output=True, text=True).stdout
+    exported = set(re.findall(r' T (scg_\w+)', nm))
+    assert declared <= exported
+    assert lib.scg_version() == _capi.SCG_ABI_VERSION
+    assert lib.scg_sizeof_config() == ctypes.sizeof(_capi.ScgConfig)
+    assert lib.scg_sizeof_step_io() == ctypes.sizeof(_capi.ScgStepIO)
+    assert lib.scg_sizeof_constraint_row() == ctypes.sizeof(_capi.ScgConstraintRow)
+    for macro, val in (('SCG_MAX_NX', _capi.SCG_MAX_NX), ('SCG_MAX_NU', _capi.SCG_MAX_NU), ('SCG_MAX_NV', _capi.SCG_MAX_NV),
+                       ('SCG_MAX_CONSTRAINT_ROWS', _capi.SCG_MAX_CONSTRAINT_ROWS), ('SCG_ABI_VERSION', _capi.SCG_ABI_VERSION)):
+        assert int(re.search(r'#define %s (\d+)' % macro, header).group(1)) == val
+
+
+def test_c_abi_rejects_bad_arguments_without_gpu_work():
+    lib = _capi.load()
+    h = ctypes.c_void_p()
+    cfg = _capi.ScgConfig()
+    assert lib.scg_create(None, ctypes.byref(h)) == -1
+    cfg.struct_size = 7
+    assert lib.scg_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    assert b'struct_size' in lib.scg_last_error()
+    assert lib.scg_step(None, None, 0, None) == -1
+    assert lib.scg_destroy(None) == 0
+
+
+def test_shard_bounds_partition():
+    from safe_control_gym_amd.parallel import shard_bounds
+    for total, world in ((8388608, 8), (10, 4), (7, 8), (1, 1)):
+        spans = [shard_bounds(total, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(spans[r][1] == spans[r + 1][0] for r in range(world - 1))
+        assert [hi - lo for lo, hi in spans] == [len(c) for c in np.array_split(np.arange(total), world)]

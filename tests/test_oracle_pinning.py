@@ -1,0 +1,281 @@
+"""Pins the CPU oracle (CPU-only tests).
+
+The reference's own tests hold no golden vectors or known-answer tests for this path (SURVEY.md
+section 4) and the reference cannot be imported here (casadi / pybullet / gym missing), so the oracle is
+pinned by (a) the analytic known-answer tests of SURVEY.md section 8(c), (b) an independent sympy /
+DOP853 derivation, (c) published Philox vectors, and (d) frozen golden fixtures of its own output.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ref_model as rm
+from oracle import independent as ind
+from oracle import philox
+from oracle.ref_env import RefEnv
+from oracle.ref_vec import RefVecEnv
+from oracle.ref_trajectory import generate_trajectory, transform_trajectory, projection_matrix
+from helpers import PhiloxSampler
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+P = rm.QuadParams()
+DT = 1 / 60
+
+
+def zeros_sampler(i, e):
+    return np.zeros(12)
+
+
+# ---- (1) hover fixed point: level attitude, u = m g / nu each -> x_dot = 0 (quadrotor.py:262,328-329)
+@pytest.mark.parametrize('system', [1, 2, 3])
+def test_kat_hover_fixed_point(system):
+    nx, nu = rm.NX[system], rm.NU[system]
+    x = [0.0] * nx
+    x[{1: 0, 2: 2, 3: 4}[system]] = 1.0
+    u = [P.m * P.g / nu] * nu
+    f = rm.F_BY_SYSTEM[system](x, u, P)
+    assert np.allclose(f, 0.0, atol=1e-15)
+    assert np.allclose(rm.rk4_step(rm.F_BY_SYSTEM[system], x, u, P, DT), x, atol=1e-15)
+
+
+# ---- (2) free fall / constant thrust in 1-D: z(t) quadratic, which RK4 reproduces to rounding
+def test_kat_1d_constant_acceleration():
+    T = rm.action_bounds(1)[0]
+    a = T / P.m - P.g
+    x = [1.0, 0.3]
+    for _ in range(10):
+        x = rm.rk4_step(rm.f_quad1d, x, [T], P, DT)
+    t = 10 * DT
+    assert abs(x[0] - (1.0 + 0.3 * t + 0.5 * a * t * t)) < 1e-14
+    assert abs(x[1] - (0.3 + a * t)) < 1e-14
+
+
+# ---- (3) 3-D pure yaw couple at level attitude: r_dot = 4 gamma delta / Izz, psi quadratic, rest unchanged
+def test_kat_3d_yaw_couple():
+    h, d = P.m * P.g / 4, 0.003
+    u = [h + d, h - d, h + d, h - d]
+    x = [0.0] * 12
+    x[4] = 1.0
+    for _ in range(6):
+        x = rm.rk4_step(rm.f_quad3d, x, u, P, DT)
+    t = 6 * DT
+    rdot = 4 * (P.km / P.kf) * d / P.izz
+    assert abs(x[11] - rdot * t) < 1e-12
+    assert abs(x[8] - 0.5 * rdot * t * t) < 1e-12
+    assert np.allclose([x[0], x[1], x[2], x[3], x[4] - 1.0, x[5], x[6], x[7], x[9], x[10]], 0.0, atol=1e-13)
+
+
+# ---- (4) 2-D pure pitch couple: theta_ddot = l (T2 - T1) / (Iyy sqrt 2)
+def test_kat_2d_pitch_couple():
+    u = [0.10, 0.11]
+    d = rm.f_quad2d([0, 0, 1, 0, 0, 0], u, P)
+    assert abs(d[5] - P.l * (u[1] - u[0]) / P.iyy / math.sqrt(2)) < 1e-12
+    assert d[1] == 0.0 and abs(d[3] - ((u[0] + u[1]) / P.m - P.g)) < 1e-15
+
+
+# ---- (5) action-bound constants of SURVEY.md row A2
+def test_kat_action_bounds():
+    assert rm.action_bounds(4) == pytest.approx((0.02816168745, 0.14834144334), rel=3e-8)
+    assert rm.action_bounds(2) == pytest.approx((0.0563234, 0.2966829), rel=1e-6)
+    assert rm.action_bounds(1) == pytest.approx((0.1126467, 0.5933658), rel=1e-6)
+    # stored float32-rounded, as gym.spaces.Box(dtype=float32) does
+    lo, hi = rm.action_bounds(4)
+    assert lo == float(np.float32(lo)) and hi == float(np.float32(hi))
+    assert P.m * P.g / 4 == pytest.approx(0.084623, rel=1e-6)
+
+
+# ---- (6) the competition BoundedConstraint (getting_started.yaml:128-156) at x=(0,.,0,.,1,...)
+COMPETITION = [{'constraint_form': 'default_constraint', 'constrained_variable': 'input'},
+               {'constraint_form': 'bounded_constraint', 'constrained_variable': 'state', 'active_dims': [0, 2, 4],
+                'upper_bounds': [3, 3, 2], 'lower_bounds': [-3, -3, -0.1]}]
+
+
+def _env3(**kw):
+    kw.setdefault('task_info', {'stabilization_goal': [0, 0, 1], 'stabilization_goal_tolerance': 0.05})
+    return RefEnv(system=3, ctrl_freq=60, pyb_freq=240, randomized_init=False, reset_sampler=zeros_sampler, **kw)
+
+
+def test_kat_bounded_and_default_constraints():
+    env = _env3(constraints=COMPETITION, init_state=np.array([0, 0, 0, 0, 1.0, 0, 0, 0, 0, 0, 0, 0]))
+    env.reset()
+    _, _, _, info = env.step(env.U_GOAL)
+    c = info['constraint_values']
+    assert c.shape == (14,)
+    a_low, a_high = rm.action_bounds(4)
+    # (7) DefaultConstraint(input) at u = U_GOAL: (a_low - u) x4, (u - a_high) x4 -- lower rows first
+    assert np.allclose(c[:4], a_low - 0.084623, atol=1e-6) and np.allclose(c[4:8], 0.084623 - a_high, atol=1e-6)
+    assert np.allclose(c[8:], [-3, -3, -1.1, -3, -3, -1], atol=1e-7)
+    assert info['constraint_violation'] == 0
+
+
+# ---- (8) RL reward at the goal with a = U_GOAL is exp(0) = 1; quadratic cost there is 0
+def test_kat_rewards_at_goal():
+    x0 = np.array([0, 0, 0, 0, 1.0, 0, 0, 0, 0, 0, 0, 0])
+    env = _env3(cost='rl_reward', init_state=x0)
+    env.reset()
+    _, rew, _, _ = env.step(env.U_GOAL)
+    assert abs(rew - 1.0) < 1e-12
+    env = _env3(cost='quadratic', init_state=x0)
+    env.reset()
+    _, rew, done, info = env.step(env.U_GOAL)
+    assert abs(rew) < 1e-20 and done and info['goal_reached']       # within 0.05 of the goal -> done (:964-967)
+
+
+# ---- (9) time limit: step 300 of a 5 s / 60 Hz episode
+def test_kat_time_limit():
+    env = _env3(cost='rl_reward', init_state=np.array([0, 0, 0, 0, 1.0, 0, 0, 0, 0, 0, 0, 0]))
+    env.reset()
+    for k in range(300):
+        _, _, done, info = env.step(env.U_GOAL)
+        if k < 299:
+            assert not done and 'TimeLimit.truncated' not in info
+    assert done and info['TimeLimit.truncated'] is True
+
+
+# ---- (10) out-of-bound termination at z < 0 and |theta| > 85 deg (quadrotor.py:742-747,979-993)
+def test_kat_out_of_bound_done():
+    env = _env3(cost='rl_reward', init_state=np.array([0, 0, 0, 0, 0.001, -1.0, 0, 0, 0, 0, 0, 0]))
+    env.reset()
+    assert env.step(env.U_GOAL)[2]
+    env = _env3(cost='rl_reward', init_state=np.array([0, 0, 0, 0, 1.0, 0, 0, 1.4836, 0, 0, 0, 0]))
+    env.reset()
+    assert env.step(env.U_GOAL)[2]
+    env = _env3(cost='rl_reward', init_state=np.array([0, 0, 0, 0, 1.0, 0, 0, 1.40, 0, 0, 0, 0]))
+    env.reset()
+    assert not env.step(env.U_GOAL)[2]
+    env = _env3(cost='rl_reward', done_on_out_of_bound=False,
+                init_state=np.array([0, 0, 0, 0, 0.001, -1.0, 0, 0, 0, 0, 0, 0]))
+    env.reset()
+    assert not env.step(env.U_GOAL)[2]
+
+
+# ---- independent derivation (sympy matrix form) vs the hand-expanded oracle
+@pytest.mark.parametrize('system', [2, 3, 'cartpole'])
+def test_independent_derivation_agrees(system):
+    rng = np.random.default_rng(3)
+    p = rm.CartPoleParams() if system == 'cartpole' else P
+    f_ind = ind.f_independent(system)
+    pv = ind.params_vector(system, p)
+    for _ in range(50):
+        x = rng.normal(size=rm.NX[system]) * 0.4
+        u = rng.uniform(-3, 3, size=1) if system == 'cartpole' else rng.uniform(0.03, 0.14, size=rm.NU[system])
+        a = np.array(rm.F_BY_SYSTEM[system](list(x), list(u), p))
+        b = np.asarray(f_ind(x, u, pv), dtype=float).ravel()
+        assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0)) < 1e-13
+
+
+def test_rk4_close_to_exact_flow():
+    """RK4 at dt = 1/60 vs DOP853 (rtol 1e-13), the CVODES stand-in: ~1e-9 at mild states."""
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for _ in range(10):
+        x = np.concatenate([rng.normal(size=6) * 0.3, rng.normal(size=3) * 0.1, rng.normal(size=3) * 0.2])
+        u = P.m * P.g / 4 * (1 + 0.02 * rng.normal(size=4))
+        a = np.array(rm.rk4_step(rm.f_quad3d, list(x), list(u), P, DT))
+        b = ind.exact_step(3, x, u, P, DT)
+        worst = max(worst, np.max(np.abs(a - b)))
+    assert worst < 5e-8
+
+
+def test_motor_map_is_identity_inside_pwm_range_and_clips_outside():
+    lo, hi = rm.action_bounds(4)
+    for T in np.linspace(lo, hi, 7)[1:-1]:
+        assert rm.motor_map([T] * 4, P)[0] == pytest.approx(T, rel=1e-12)
+    # the float32-rounded a_high sits 2.5e-8 above the true PWM_max thrust: the motor map clips it there
+    assert rm.motor_map([hi] * 4, P)[0] == pytest.approx(P.kf * (P.pwm2rpm_scale * P.max_pwm + P.pwm2rpm_const) ** 2, rel=1e-12)
+    assert rm.motor_map([0.0] * 4, P)[0] == pytest.approx(P.kf * (P.pwm2rpm_scale * P.min_pwm + P.pwm2rpm_const) ** 2, rel=1e-12)
+    assert rm.motor_map([1.0] * 4, P)[0] == pytest.approx(P.kf * (P.pwm2rpm_scale * P.max_pwm + P.pwm2rpm_const) ** 2, rel=1e-12)
+    # 2-D: each input drives two motors
+    assert rm.motor_map([0.1, 0.2], P) == pytest.approx([0.1, 0.2], rel=1e-12)
+
+
+def test_philox_known_answers():
+    """Random123 kat_vectors, philox4x32-10."""
+    f = lambda c, k: [int(v) for v in philox.philox4x32_10(np.array(c, np.uint32), np.array(k, np.uint32))]
+    assert f([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert f([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert f([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_reset_offsets_are_uniform_in_range():
+    lo, hi = np.full(12, -0.5), np.full(12, 0.5)
+    draws = np.stack([philox.reset_offsets(1337, i, 7, lo, hi) for i in range(2000)])
+    assert draws.min() >= -0.5 and draws.max() < 0.5
+    assert abs(draws.mean()) < 0.01 and abs(draws.std() - 1 / math.sqrt(12)) < 0.01
+    assert np.abs(np.corrcoef(draws.T) - np.eye(12)).max() < 0.08
+
+
+def test_reference_trajectory_quirks():
+    """3-D tracking reference: circle in 'zx' projected on the plane (point [0,0,.5], normal [0,1,1]);
+    the velocity rows get the plane offset added too (transformations.py:119-122)."""
+    pos, vel, speed = generate_trajectory('circle', 5, 1, 'zx', [0.5, 0], -0.5, DT)
+    assert pos.shape == (300, 3) and speed.shape == (300, 1)
+    assert pos[0] == pytest.approx([0, 0, 0]) and vel[0] == pytest.approx([-0.5 * 2 * math.pi / 5, 0, 0])
+    M = projection_matrix([0, 0, 0.5], [0, 1, 1])
+    n = np.array([0, 1, 1]) / math.sqrt(2)
+    assert np.allclose(M[:3, :3], np.eye(3) - np.outer(n, n)) and np.allclose(M[:3, 3], (0.5 / math.sqrt(2)) * n)
+    p2, v2 = transform_trajectory(pos, vel, [0, 0, 0.5], [0, 1, 1])
+    assert np.allclose(v2[0], vel[0] @ (np.eye(3) - np.outer(n, n)) + M[:3, 3])
+    env = RefEnv(system=3, task='traj_tracking', cost='quadratic', ctrl_freq=60, pyb_freq=240)
+    assert env.X_GOAL.shape == (300, 12)
+    assert np.allclose(env.X_GOAL[0, :6], [0, -0.62831853, 0.25, 0.25, 0.25, 0.25])
+
+
+def test_c_port_matches_python_oracle():
+    from oracle.c_port import CPort
+    rng = np.random.default_rng(11)
+    cases = [
+        (3, dict(task='traj_tracking', cost='quadratic', ctrl_freq=60, pyb_freq=240)),
+        (2, dict(task='stabilization', cost='rl_reward', ctrl_freq=60, pyb_freq=240,
+                 constraints=[{'constraint_form': 'bounded_constraint', 'constrained_variable': 'state',
+                               'active_dims': [0, 2, 4], 'lower_bounds': [-2, 0, -0.5], 'upper_bounds': [2, 2, 0.5]}])),
+        (1, dict(task='stabilization', cost='quadratic', ctrl_freq=50, pyb_freq=50)),
+        ('cartpole', dict(task='traj_tracking', cost='rl_reward', ctrl_freq=50, pyb_freq=50)),
+    ]
+    for system, kw in cases:
+        ref = RefEnv(system=system, randomized_init=False, reset_sampler=zeros_sampler, **kw)
+        port = CPort.from_ref_env(ref)
+        n, nx, nu = 64, ref.nx, ref.nu
+        x0 = rng.normal(size=(n, nx)) * 0.15
+        if system != 'cartpole':
+            x0[:, {1: 0, 2: 2, 3: 4}[system]] += 1.0
+        state, t = x0.copy(), rng.integers(0, 5, size=n).astype(np.int32)
+        t0 = t.copy()
+        lo, hi = ref.action_space_low, ref.action_space_high
+        a = rng.uniform(lo - 0.1 * (hi - lo), hi + 0.1 * (hi - lo), size=(n, nu))
+        rew, done, cv, viol = port.step(a, state, t, x0, want_constraints=ref.constraints is not None)
+        for i in range(n):
+            ref.reset()
+            ref.state, ref.ctrl_step_counter = x0[i].copy(), int(t0[i])
+            o, r, d, info = ref.step(a[i])
+            assert bool(done[i]) == bool(d)
+            assert abs(r - rew[i]) <= 1e-12 * max(1, abs(r))
+            expect = x0[i] if d else ref.state
+            assert np.max(np.abs(state[i] - expect)) < 1e-12
+            if ref.constraints is not None:
+                assert np.max(np.abs(cv[i] - info['constraint_values'])) < 1e-7      # oracle rounds to 8 decimals
+                assert viol[i] == info['constraint_violation']
+
+
+def test_golden_matches_oracle():
+    """The committed fixtures are exactly what the oracle produces today (freezes the oracle)."""
+    meta = json.load(open(os.path.join(HERE, 'golden', 'cases.json')))
+    for name, case in meta['cases'].items():
+        g = np.load(os.path.join(HERE, 'golden', name + '.npz'))
+        system = case['system']
+        sampler = PhiloxSampler(meta['seed'], system)
+        refs = [RefEnv(system=system, env_index=i, reset_sampler=sampler, randomized_init=True, **case['kw'])
+                for i in range(meta['n'])]
+        vec = RefVecEnv(refs)
+        sampler.serial = 0
+        obs0, _ = vec.reset()
+        assert np.array_equal(obs0, g['obs0'])
+        for k in range(meta['t']):
+            sampler.serial = k + 1
+            o, r, d, info = vec.step(g['actions'][k].astype(np.float64))
+            assert np.array_equal(o, g['obs'][k]) and np.array_equal(r, g['reward'][k])
+            assert np.array_equal(d.astype(np.uint8), g['done'][k])

@@ -1,0 +1,141 @@
+"""Size-independent properties checked at BASELINE.json's full sizes (2^20 envs) on the GPU, where the
+float64 oracle is too slow to follow: fixed points, time limits, determinism, shard invariance, batch sums."""
+import numpy as np
+import pytest
+import torch
+
+import safe_control_gym_amd as scg
+
+pytestmark = pytest.mark.gpu
+N = 1 << 20
+
+
+def _hover_env(**kw):
+    x0 = np.zeros(12)
+    x0[4] = 1.0
+    return scg.make('quadrotor', quad_type=3, num_envs=N, device='cuda', seed=1337, ctrl_freq=60, pyb_freq=240,
+                    randomized_init=False, init_state=x0, **kw)
+
+
+def test_hover_is_a_fixed_point_and_time_limit_truncates_at_300(gpu):
+    """Level attitude + u = m g / 4 is an equilibrium (quadrotor.py:262,328-329): 1M envs stay put for a whole
+    episode, every one is truncated at step 300 exactly (benchmark_env.py:460-462) with episode length 300."""
+    env = _hover_env(task='stabilization', cost='rl_reward',
+                     task_info={'stabilization_goal': [0, 0, 1], 'stabilization_goal_tolerance': 0.05})
+    env.reset()
+    a = torch.tensor(env.U_GOAL, dtype=torch.float32, device='cuda').repeat(N, 1)
+    for k in range(300):
+        obs, rew, done, info = env.step(a)
+        if k in (0, 150, 298):
+            assert not bool(done.any())
+            assert float((obs[:, 4] - 1.0).abs().max()) < 2e-5 and float(obs[:, [0, 2, 6, 7, 8]].abs().max()) < 1e-6
+            assert float((rew - 1.0).abs().max()) < 1e-4            # exp(-dist) with dist ~ 0
+    assert bool(done.all()) and bool(info['TimeLimit.truncated'].all())
+    assert bool((info['episode']['l'] == 300).all())
+    assert float((info['episode']['r'] - 300.0).abs().max()) < 0.05
+    assert int(env.ctrl_step_counter.max()) == 0                   # auto-reset
+
+
+def test_determinism_and_shard_invariance(gpu):
+    """Same seed -> bit-identical rollouts; a shard built with env_index_base reproduces the matching slice of
+    the big batch bit for bit (per-env Philox streams are keyed by the GLOBAL env index)."""
+    kw = dict(quad_type=3, device='cuda', seed=7, ctrl_freq=60, pyb_freq=240, randomized_init=True,
+              task='traj_tracking', cost='quadratic')
+    g = torch.Generator(device='cuda')
+    g.manual_seed(3)
+    full = scg.make('quadrotor', num_envs=N, **kw)
+    lo = torch.as_tensor(full.action_space.low, device='cuda')
+    hi = torch.as_tensor(full.action_space.high, device='cuda')
+    acts = [torch.rand((N, 4), generator=g, device='cuda') * (hi - lo) + lo for _ in range(12)]
+
+    def roll(env, sl):
+        env.reset()
+        outs = []
+        for a in acts:
+            obs, rew, done, _ = env.step(a[sl])
+            outs.append((obs.clone(), rew.clone(), done.clone()))
+        return outs
+    ref = roll(full, slice(0, N))
+    again = roll(scg.make('quadrotor', num_envs=N, **kw), slice(0, N))
+    for (o1, r1, d1), (o2, r2, d2) in zip(ref, again):
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+    assert sum(int(d.sum()) for _, _, d in ref) > N // 4            # resets (Philox path) were exercised
+    lo_i, hi_i = 3 * (N // 8), 4 * (N // 8)                         # rank 3 of 8
+    shard = roll(scg.make('quadrotor', num_envs=hi_i - lo_i, env_index_base=lo_i, **kw), slice(lo_i, hi_i))
+    for (o1, r1, d1), (o2, r2, d2) in zip(ref, shard):
+        assert torch.equal(o1[lo_i:hi_i], o2) and torch.equal(r1[lo_i:hi_i], r2) and torch.equal(d1[lo_i:hi_i], d2)
+
+
+def test_reset_randomisation_statistics(gpu):
+    """Reset states = nominal + U(low, high) per component (quadrotor.py:68-134 ranges), independent streams."""
+    env = scg.make('quadrotor', quad_type=3, num_envs=N, device='cuda', seed=11, randomized_init=True,
+                   task='traj_tracking', cost='quadratic', ctrl_freq=60, pyb_freq=240)
+    x = env.reset().double()
+    lo = torch.tensor([-0.5, -0.01, -0.5, -0.01, 0.1, -0.01, -0.3, -0.3, -0.3, -0.01, -0.01, -0.01], device='cuda')
+    hi = torch.tensor([0.5, 0.01, 0.5, 0.01, 1.5, 0.01, 0.3, 0.3, 0.3, 0.01, 0.01, 0.01], device='cuda')
+    assert bool((x >= lo).all()) and bool((x <= hi).all())
+    u = (x - lo) / (hi - lo)
+    assert float((u.mean(0) - 0.5).abs().max()) < 2e-3 and float((u.std(0) - 12 ** -0.5).abs().max()) < 2e-3
+    c = torch.corrcoef(u.T) - torch.eye(12, device='cuda', dtype=torch.float64)
+    assert float(c.abs().max()) < 5e-3
+    x2 = env.reset().double()
+    assert float(((x2 - x).abs() > 0).double().mean()) > 0.99       # a new serial draws new offsets
+
+
+def test_rollout_equals_step_loop_and_stats(gpu):
+    """scg_rollout (K launches from one C call) == K step() calls; the kernel's wave-reduced batch sums
+    agree with torch reductions."""
+    kw = dict(quad_type=3, device='cuda', seed=5, ctrl_freq=60, pyb_freq=240, randomized_init=True,
+              task='traj_tracking', cost='quadratic')
+    n = 1 << 16
+    a_env = scg.make('quadrotor', num_envs=n, **kw)
+    b_env = scg.make('quadrotor', num_envs=n, **kw)
+    a_env.reset(); b_env.reset()
+    ld = a_env.plane_stride
+    g = torch.Generator(device='cuda'); g.manual_seed(1)
+    lo = torch.as_tensor(a_env.action_space.low, device='cuda')[None, :, None]
+    hi = torch.as_tensor(a_env.action_space.high, device='cuda')[None, :, None]
+    acts = torch.rand((7, 4, ld), generator=g, device='cuda') * (hi - lo) + lo
+    K = 20
+    stats = torch.zeros(8, dtype=torch.float64, device='cuda')
+    b_env._bufs['stats'] = stats
+    rew_sum, done_sum, ret_sum, len_sum = 0.0, 0, 0.0, 0
+    for k in range(K):
+        obs, rew, done, info = a_env.step(acts[k % 7])
+        b_env.step(acts[k % 7])
+        rew_sum += float(rew.double().sum()); done_sum += int(done.sum())
+        ret_sum += float(info['episode']['r'][done].double().sum()); len_sum += int(info['episode']['l'][done].sum())
+    assert torch.equal(a_env.state, b_env.state)
+    assert abs(float(stats[0]) - rew_sum) <= 1e-5 * abs(rew_sum) and int(stats[1]) == done_sum
+    assert abs(float(stats[3]) - ret_sum) <= 1e-5 * abs(ret_sum) and int(stats[4]) == len_sum
+    c_env = scg.make('quadrotor', num_envs=n, **kw)
+    c_env.reset()
+    c_env.rollout(acts, steps=K)
+    assert torch.equal(a_env.state, c_env.state) and torch.equal(a_env.episode_return, c_env.episode_return)
+    assert torch.equal(a_env.ctrl_step_counter, c_env.ctrl_step_counter)
+
+
+def test_vec_env_protocol_and_episode_statistics(gpu):
+    """make_vec_envs + VecRecordEpisodeStatistics keep the reference's call surface
+    (env_wrappers/vectorized_env/__init__.py:40-65, record_episode_statistics.py:92-169)."""
+    from functools import partial
+    from safe_control_gym_amd.envs.env_wrappers.vectorized_env import make_vec_envs
+    from safe_control_gym_amd.envs.env_wrappers.record_episode_statistics import VecRecordEpisodeStatistics
+    env_func = partial(scg.make, 'quadrotor', quad_type=2, device='cuda', ctrl_freq=60, pyb_freq=240,
+                       episode_len_sec=1, randomized_init=True,
+                       constraints=[{'constraint_form': 'default_constraint', 'constrained_variable': 'state'}])
+    venv = VecRecordEpisodeStatistics(make_vec_envs(env_func, batch_size=512, n_processes=4, seed=3), deque_size=10000)
+    venv.add_tracker('constraint_violation', 0, mode='queue')
+    obs, _ = venv.reset()
+    assert obs.shape == (512, 6) and venv.num_envs == 512
+    a = torch.as_tensor(venv.action_space.sample(512), device='cuda')
+    total_done = 0
+    for k in range(70):
+        obs, rew, done, info = venv.step(a)
+        total_done += int(done.sum())
+    assert len(venv.return_queue) == total_done == len(venv.length_queue) and total_done >= 512
+    assert max(venv.length_queue) <= 60 and len(venv.queued_stats['constraint_violation']) == total_done
+    assert venv.get_attr('CTRL_FREQ')[0] == 60 and len(venv.get_attr('CTRL_FREQ')) == 512
+    per_env = info['n'][0]
+    assert 'constraint_values' in per_env and 'mse' in per_env
+    venv.close()

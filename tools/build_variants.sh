@@ -1,0 +1,20 @@
+#!/bin/bash
+# Build A/B variants of the HIP library into safe_control_gym_amd/lib/variants/ (tuning only).
+set -euo pipefail
+root="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
+src="$root/safe_control_gym_amd/csrc"
+out="$root/safe_control_gym_amd/lib/variants"
+mkdir -p "$out"
+build() { # name, extra flags...
+  local name="$1"; shift
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared "$@" -o "$out/$name.so" "$src/scg_kernels.hip" "$src/scg_capi.hip" &
+}
+build base -fno-slp-vectorize
+build nont -fno-slp-vectorize -DSCG_NT=0
+build w5 -fno-slp-vectorize -DSCG_MIN_WAVES=5
+build w6 -fno-slp-vectorize -DSCG_MIN_WAVES=6
+build b512 -fno-slp-vectorize -DSCG_BLOCK=512
+build b128 -fno-slp-vectorize -DSCG_BLOCK=128
+build fasttrig -fno-slp-vectorize -DSCG_FAST_TRIG=1
+wait
+ls -la "$out"

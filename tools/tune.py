@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""A/B the kernel build variants and launch-geometry knobs on the GPU box (tuning only).
+
+Each arm runs bench.py in a child process (fresh library load) and reports kernel us/launch; arms are
+interleaved over `--rounds` rounds so that clock / thermal drift hits all arms alike.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(lib, env_extra, steps, extra_args):
+    env = dict(os.environ)
+    if lib:
+        env['SCG_ROLLOUT_LIB'] = lib
+    env.update(env_extra)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', str(steps), '--warmup', '100',
+                          '--no-cpu-baseline'] + extra_args, env=env, capture_output=True, text=True)
+    for line in out.stdout.splitlines():
+        if line.startswith('{'):
+            return json.loads(line)
+    return {'error': out.stderr[-400:]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--rounds', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=1500)
+    ap.add_argument('--arms', default='')
+    ap.add_argument('bench_args', nargs='*')
+    a = ap.parse_args()
+    vdir = os.path.join(ROOT, 'safe_control_gym_amd', 'lib', 'variants')
+    arms = []
+    for f in sorted(os.listdir(vdir)):
+        if f.endswith('.so'):
+            arms.append((f[:-3], os.path.join(vdir, f), {}))
+    base = os.path.join(vdir, 'base.so')
+    for cap in (4, 16, 32, 100000):
+        arms.append(('base_cap%d' % cap, base, {'SCG_GRID_CAP_PER_CU': str(cap)}))
+    arms.append(('base_nolds', base, {'SCG_REF_IN_LDS': '0'}))
+    for v in ('w5', 'b512', 'b128'):
+        arms.append((v + '_nocap', os.path.join(vdir, v + '.so'), {'SCG_GRID_CAP_PER_CU': '100000'}))
+        arms.append((v + '_nolds', os.path.join(vdir, v + '.so'), {'SCG_REF_IN_LDS': '0'}))
+    if a.arms:
+        keep = set(a.arms.split(','))
+        arms = [x for x in arms if x[0] in keep]
+    res = {name: [] for name, _, _ in arms}
+    for r in range(a.rounds):
+        for name, lib, envx in arms:
+            j = run(lib, envx, a.steps, a.bench_args)
+            us = j.get('roofline', {}).get('kernel_us_per_launch')
+            res[name].append(us)
+            print('round %d %-20s %s' % (r, name, us if us else j), flush=True)
+    print('---- summary (kernel us per launch; lower is better)')
+    for name, v in sorted(res.items(), key=lambda kv: min([x for x in kv[1] if x] or [9e9])):
+        vv = [x for x in v if x]
+        print('%-20s min %.2f  all %s' % (name, min(vv) if vv else float('nan'), ['%.2f' % x for x in vv]))
+
+
+if __name__ == '__main__':
+    main()
