@@ -59,7 +59,7 @@ def test_determinism_and_shard_invariance(gpu):
     again = roll(scg.make('quadrotor', num_envs=N, **kw), slice(0, N))
     for (o1, r1, d1), (o2, r2, d2) in zip(ref, again):
         assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
-    assert sum(int(d.sum()) for _, _, d in ref) > N // 4            # resets (Philox path) were exercised
+    assert sum(int(d.sum()) for _, _, d in ref) > N // 8            # resets (Philox path) were exercised
     lo_i, hi_i = 3 * (N // 8), 4 * (N // 8)                         # rank 3 of 8
     shard = roll(scg.make('quadrotor', num_envs=hi_i - lo_i, env_index_base=lo_i, **kw), slice(lo_i, hi_i))
     for (o1, r1, d1), (o2, r2, d2) in zip(ref, shard):
