@@ -34,6 +34,10 @@ def build_env(args, rank, world):
     track = world > 1 or args.episode_stats
     common = dict(num_envs=n, device='cuda', seed=1337, env_index_base=rank * n, randomized_init=True,
                   info_level='minimal', track_episode_stats=track, ctrl_freq=60, pyb_freq=240, episode_len_sec=5)
+    import yaml
+    for kv in args.env_kw:
+        k, v = kv.split('=', 1)
+        common[k] = yaml.safe_load(v)
     w = args.workload
     if w in ('c4', 'c5'):
         env = scg.make('quadrotor', quad_type=3, task='traj_tracking', cost='quadratic', **common)
@@ -119,6 +123,7 @@ def main():
     ap.add_argument('--python-loop', action='store_true', help='also time env.step() called from Python per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--env-kw', action='append', default=[], help='extra make() kwargs key=value (yaml), for experiments')
     args = ap.parse_args()
 
     import torch
@@ -171,7 +176,7 @@ def main():
     torch.cuda.synchronize()
     wall_ms = (time.perf_counter() - t0) * 1e3
     dev_ms = ev0.elapsed_time(ev1)
-    t = torch.tensor([wall_ms, dev_ms], device=dev, dtype=torch.float64)
+    t = torch.tensor([wall_ms, dev_ms], dtype=torch.float64, device=dev if (world == 1 or dist.get_backend() == 'nccl') else 'cpu')
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_ms, dev_ms = float(t[0]), float(t[1])

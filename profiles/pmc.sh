@@ -21,7 +21,7 @@ out = sys.argv[1]
 acc = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(out + '/pass*/**/*counter_collection.csv', recursive=True):
     for row in csv.DictReader(open(f)):
-        if 'scg_step_kernel' not in row.get('Kernel_Name', ''):
+        if 'scg_step' not in row.get('Kernel_Name', ''):
             continue
         k = row['Counter_Name']
         acc[k][0] += float(row['Counter_Value']); acc[k][1] += 1

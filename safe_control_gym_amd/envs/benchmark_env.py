@@ -332,7 +332,14 @@ class BenchmarkEnv:
     def _alloc_buffers(self):
         """SoA planes, padded to a multiple of 64 lanes so every plane starts 256-B aligned."""
         n = self.num_envs
-        ld = self._ld = (n + 63) // 64 * 64
+        ld = (n + 63) // 64 * 64
+        # Plane-stride skew: with a power-of-two stride the j-th plane of every array maps to the same HBM
+        # channel for a given env index and the 12 + 4 + ... streams of a wave collide there.  17 x 256 B of
+        # padding per plane measured best (-10 % kernel time at 2^20 envs; 64 x 256 B is as bad as none) --
+        # DESIGN.md section 6.  SCG_LD_PAD (units of 64 lanes) overrides it for tuning.
+        if n >= 4096:
+            ld += 64 * int(os.environ.get('SCG_LD_PAD', '17'))
+        self._ld = ld
         dev, f32 = self.device, torch.float32
         nx, nu = self.state_dim, self.action_dim
         b = {}

@@ -27,6 +27,9 @@ def init_from_env(backend=None):
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('SCG_SINGLE_DEVICE') == '1':
+        # rehearsal on a one-GPU box: every rank drives device 0 and the collectives run over gloo
+        local_rank, backend = 0, (backend or 'gloo')
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
@@ -58,12 +61,18 @@ def all_gather_episode_returns(local_returns, total_envs=None):
     else:
         counts = [shard_bounds(total_envs, world, r)[1] - shard_bounds(total_envs, world, r)[0] for r in range(world)]
     width = max(counts)
-    send = local_returns
+    dev = local_returns.device
+    # gloo (CPU tests, or several ranks sharing one GPU) gathers host tensors; nccl = RCCL gathers in place on device
+    via_host = dist.get_backend() == 'gloo' and dev.type == 'cuda'
+    send = local_returns.cpu() if via_host else local_returns
     if n_local != width:
-        send = torch.zeros(width, dtype=local_returns.dtype, device=local_returns.device)
-        send[:n_local] = local_returns
-    out = torch.empty(world * width, dtype=local_returns.dtype, device=local_returns.device)
+        padded = torch.zeros(width, dtype=send.dtype, device=send.device)
+        padded[:n_local] = send
+        send = padded
+    out = torch.empty(world * width, dtype=send.dtype, device=send.device)
     dist.all_gather_into_tensor(out, send.contiguous())
+    if via_host:
+        out = out.to(dev)
     if all(c == width for c in counts):
         return out
     return torch.cat([out[r * width:r * width + counts[r]] for r in range(world)])

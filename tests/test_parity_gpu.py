@@ -30,6 +30,48 @@ CONFIGS = [
 ]
 
 
+LEAN = CONFIGS + [
+    ('q3_competition_constraints', 3, dict(task='stabilization', cost='rl_reward', ctrl_freq=60, pyb_freq=240,
+                                           task_info={'stabilization_goal': [0.2, -0.1, 1.0], 'stabilization_goal_tolerance': 0.05},
+                                           constraints=[{'constraint_form': 'default_constraint', 'constrained_variable': 'input'},
+                                                        {'constraint_form': 'bounded_constraint', 'constrained_variable': 'state',
+                                                         'active_dims': [0, 2, 4], 'upper_bounds': [3, 3, 2],
+                                                         'lower_bounds': [-3, -3, -0.1]}], done_on_violation=True)),
+    ('q2_track_quadratic_default_constraints', 2, dict(task='traj_tracking', cost='quadratic', ctrl_freq=60, pyb_freq=240,
+                                                       constraints=[{'constraint_form': 'default_constraint', 'constrained_variable': 'state'}])),
+]
+
+
+@pytest.mark.parametrize('n', [96, 1, 2, 127, 130])
+@pytest.mark.parametrize('name,system,kw', LEAN, ids=[c[0] for c in LEAN])
+@pytest.mark.parametrize('packed', ['0', '1'])
+def test_lean_tier_parity_teacher_forced(gpu, monkeypatch, name, system, kw, n, packed):
+    """info_level='minimal' selects the lean feature tiers (no FT_EXTRA).  packed=1 runs them on the opt-in
+    two-envs-per-lane kernel (scg_step2_kernel; SCG_PACKED is read once per process, so the packed arm only
+    takes effect when the whole session runs with SCG_PACKED=1 -- tools/run_gpu_tests.sh does both).
+    Odd n exercises the one-env tail lane."""
+    import os
+    if packed == '1' and os.environ.get('SCG_PACKED') != '1':
+        pytest.skip('packed arm runs in a session started with SCG_PACKED=1')
+    if packed == '0' and os.environ.get('SCG_PACKED') == '1':
+        pytest.skip('unpacked arm runs in a session without SCG_PACKED=1')
+    if n != 96 and name not in ('q3_track_quadratic', 'q2_stab_rl', 'q3_competition_constraints'):
+        pytest.skip('batch-size sweep on three representative configs only')
+    env, ref, sampler = make_pair(system, n, randomized_init=True, engine_kwargs=dict(info_level='minimal'), **kw)
+    obs_e, obs_r = sync_reset(env, ref, sampler)
+    assert rel_err(obs_e.cpu().numpy(), obs_r) <= RTOL
+    rng = np.random.default_rng(17)
+    worst = 0.0
+    for k in range(30):
+        force_state(env, ref)
+        out = sync_step(env, ref, sampler, _actions(env, rng, n))
+        worst = max(worst, compare_step(*out, ref))
+        ep_r = env.episode_return.cpu().numpy()
+        assert rel_err(ep_r, ref.episode_return) <= 10 * RTOL
+        assert np.array_equal(env.episode_length.cpu().numpy(), ref.episode_length.astype(np.int32))
+    print('packed %s n=%d worst rel err %.3e' % (name, n, worst))
+
+
 @pytest.mark.parametrize('name,system,kw', CONFIGS, ids=[c[0] for c in CONFIGS])
 def test_single_step_parity_teacher_forced(gpu, name, system, kw):
     """Identical state and action every step (the oracle's state is forced into the engine):

@@ -10,11 +10,9 @@ build() { # name, extra flags...
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared "$@" -o "$out/$name.so" "$src/scg_kernels.hip" "$src/scg_capi.hip" &
 }
 build base -fno-slp-vectorize
-build nont -fno-slp-vectorize -DSCG_NT=0
-build w5 -fno-slp-vectorize -DSCG_MIN_WAVES=5
+build slp
+build pf -fno-slp-vectorize -DSCG_PREFETCH=1
 build w6 -fno-slp-vectorize -DSCG_MIN_WAVES=6
-build b512 -fno-slp-vectorize -DSCG_BLOCK=512
-build b128 -fno-slp-vectorize -DSCG_BLOCK=128
 build fasttrig -fno-slp-vectorize -DSCG_FAST_TRIG=1
 wait
 ls -la "$out"

@@ -39,12 +39,16 @@ def main():
         if f.endswith('.so'):
             arms.append((f[:-3], os.path.join(vdir, f), {}))
     base = os.path.join(vdir, 'base.so')
-    for cap in (4, 16, 32, 100000):
-        arms.append(('base_cap%d' % cap, base, {'SCG_GRID_CAP_PER_CU': str(cap)}))
-    arms.append(('base_nolds', base, {'SCG_REF_IN_LDS': '0'}))
-    for v in ('w5', 'b512', 'b128'):
-        arms.append((v + '_nocap', os.path.join(vdir, v + '.so'), {'SCG_GRID_CAP_PER_CU': '100000'}))
-        arms.append((v + '_nolds', os.path.join(vdir, v + '.so'), {'SCG_REF_IN_LDS': '0'}))
+    for e in ({'SCG_PACKED': '0'}, {'SCG_PACKED': '1', 'SCG_PACKED_BLOCKS_PER_CU': '100000'}):
+        arms.append(('base_' + '_'.join('%s%s' % (k[4:].lower(), v) for k, v in e.items()), base, e))
+    for pad in (0, 8, 16, 24):
+        arms.append(('base_pad%d' % pad, base, {'SCG_PACKED': '0', 'SCG_LD_PAD': str(pad)}))
+    pf = os.path.join(vdir, 'pf.so')
+    for cap in (4, 5, 8, 100000):
+        arms.append(('pf_cap%d' % cap, pf, {'SCG_PACKED': '0', 'SCG_GRID_CAP_PER_CU': str(cap)}))
+    for v in ('slp', 'w6', 'fasttrig'):
+        arms.append((v + '_unpacked', os.path.join(vdir, v + '.so'), {'SCG_PACKED': '0'}))
+    arms = [x for x in arms if not (x[2] == {} )]
     if a.arms:
         keep = set(a.arms.split(','))
         arms = [x for x in arms if x[0] in keep]
