@@ -1,0 +1,24 @@
+#!/bin/bash
+# One GPU-box session that produces everything committed under profiles/<tag>/ (run via gpurun).
+# usage: tools/round_measure.sh <tag>
+set -u
+tag="${1:-r01}"
+root="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+out="$root/gpurun_out/$tag"
+mkdir -p "$out"
+cd "$root"
+echo "== tests"; tools/run_gpu_tests.sh > "$out/gpu_tests.log" 2>&1; tail -4 "$out/gpu_tests.log"
+echo "== smoke"; python __graft_entry__.py smoke 2>&1 | tail -1
+echo "== bench c4"; python bench.py --python-loop > "$out/bench_c4.json" 2> "$out/bench_c4.err"; cat "$out/bench_c4.json"
+echo "== bench c4 + episode stats (the C5 per-GPU shard)"; python bench.py --episode-stats --no-cpu-baseline > "$out/bench_c5shard.json" 2>/dev/null; cat "$out/bench_c5shard.json"
+echo "== bench c3"; python bench.py --workload c3 --envs-per-gpu 262144 --steps 5000 > "$out/bench_c3.json" 2>/dev/null; cat "$out/bench_c3.json"
+echo "== bench c2"; python bench.py --workload c2 --envs-per-gpu 65536 --steps 10000 > "$out/bench_c2.json" 2>/dev/null; cat "$out/bench_c2.json"
+echo "== N sweep"; for e in 10 12 14 16 18 20 22; do python bench.py --envs-per-gpu $((1<<e)) --steps 2000 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read()); print('N=2^$e  %.3e env-steps/s  %.2f us/step  frac %.3f' % (j['value'], j['roofline']['kernel_us_per_launch'], j['roofline']['frac']))"; done | tee "$out/n_sweep.txt"
+echo "== 2 ranks sharing this GPU over gloo (rehearsal of the N>1 path)"
+SCG_SINGLE_DEVICE=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 600 --warmup 50 --envs-per-gpu 524288 > "$out/bench_2rank_rehearsal.json" 2> "$out/bench_2rank.err"; tail -1 "$out/bench_2rank_rehearsal.json"
+echo "== rocprof kernel trace"
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -- python3 "$root/bench.py" --steps 500 --warmup 50 --no-cpu-baseline > "$out/prof.log" 2>&1 )
+find "$out/prof" -name "*kernel_stats.csv" -exec cp {} "$out/c4_kernel_stats.csv" \;
+head -3 "$out/c4_kernel_stats.csv" | cut -c1-200
+echo "== pmc"; profiles/pmc.sh "$out/pmc" > "$out/pmc_summary.txt" 2>&1; cat "$out/pmc_summary.txt"
+rm -rf "$out/prof" "$out"/pmc/pass*
