@@ -23,6 +23,7 @@ struct scg_handle {
     int max_lds_bytes;
     ConTable* d_con;       // device
     KTables* d_tb;         // device
+    PhysT<double> phd;
     float* d_ref;          // device, [rows][nx]
     int ref_rows;
     int n_con_rows;
@@ -102,33 +103,42 @@ static void derive_params(scg_handle* h) {
     k.seed_lo = (uint32_t)(c.seed & 0xffffffffull);
     k.seed_hi = (uint32_t)(c.seed >> 32);
     k.env_base = c.env_index_base;
-    k.h = (float)(c.dt / (double)c.substeps);
+    PhysT<double> d;
+    std::memset(&d, 0, sizeof(d));
+    d.h = c.dt / (double)c.substeps;
     if (c.system != SCG_CARTPOLE) {
         const double n_motor = 4.0 / nu;
-        k.inv_m = (float)(1.0 / c.mass);
-        k.g = (float)c.gravity;
-        k.arm_s2 = (float)(c.arm / std::sqrt(2.0));
-        k.gamma = (float)(c.km / c.kf);
-        k.inv_ixx = (float)(1.0 / c.ixx);
-        k.inv_iyy = (float)(1.0 / c.iyy);
-        k.inv_izz = (float)(1.0 / c.izz);
-        k.cxx = (float)((c.izz - c.iyy) / c.ixx);
-        k.cyy = (float)((c.ixx - c.izz) / c.iyy);
-        k.czz = (float)((c.iyy - c.ixx) / c.izz);
-        k.l_s2_iyy = (float)(c.arm / c.iyy / std::sqrt(2.0));
-        k.inv_nmotor_kf = (float)(1.0 / (n_motor * c.kf));
-        k.nmotor_kf = (float)(n_motor * c.kf);
-        k.pwm_scale = (float)c.pwm2rpm_scale;
-        k.inv_pwm_scale = (float)(1.0 / c.pwm2rpm_scale);
-        k.pwm_const = (float)c.pwm2rpm_const;
-        k.pwm_min = (float)c.pwm_min;
-        k.pwm_max = (float)c.pwm_max;
+        d.inv_m = 1.0 / c.mass;
+        d.g = c.gravity;
+        d.arm_s2 = c.arm / std::sqrt(2.0);
+        d.gamma = c.km / c.kf;
+        d.inv_ixx = 1.0 / c.ixx;
+        d.inv_iyy = 1.0 / c.iyy;
+        d.inv_izz = 1.0 / c.izz;
+        d.cxx = (c.izz - c.iyy) / c.ixx;
+        d.cyy = (c.ixx - c.izz) / c.iyy;
+        d.czz = (c.iyy - c.ixx) / c.izz;
+        d.l_s2_iyy = c.arm / c.iyy / std::sqrt(2.0);
+        d.inv_nmotor_kf = 1.0 / (n_motor * c.kf);
+        d.nmotor_kf = n_motor * c.kf;
+        d.pwm_scale = c.pwm2rpm_scale;
+        d.inv_pwm_scale = 1.0 / c.pwm2rpm_scale;
+        d.pwm_const = c.pwm2rpm_const;
+        d.pwm_min = c.pwm_min;
+        d.pwm_max = c.pwm_max;
     } else {
-        k.cp_l = (float)c.pole_length;
-        k.cp_m = (float)c.pole_mass;
-        k.cp_inv_Mm = (float)(1.0 / (c.pole_mass + c.cart_mass));
-        k.cp_ml = (float)(c.pole_mass * c.pole_length);
-        k.cp_g = (float)c.gravity;
+        d.cp_l = c.pole_length;
+        d.cp_m = c.pole_mass;
+        d.cp_inv_Mm = 1.0 / (c.pole_mass + c.cart_mass);
+        d.cp_ml = c.pole_mass * c.pole_length;
+        d.cp_g = c.gravity;
+    }
+    h->phd = d;
+    {
+        // fp32 copy, member by member (PhysT<float> has the same field order)
+        const double* src = reinterpret_cast<const double*>(&d);
+        float* dst = reinterpret_cast<float*>(&k.ph);
+        for (size_t q = 0; q < sizeof(d) / sizeof(double); ++q) dst[q] = (float)src[q];
     }
     k.norm_act_scale = (float)c.norm_act_scale;
     k.hover_thrust = (float)c.hover_thrust;
@@ -159,6 +169,8 @@ static void derive_tables(const scg_handle* h, KTables& t) {
         t.init_lo[j] = (float)c.init_rand_low[j];
         t.init_span[j] = (float)(c.init_rand_high[j] - c.init_rand_low[j]);
     }
+    t.phd = h->phd;
+    for (int j = 0; j < nu; ++j) { t.act_low_d[j] = c.act_low[j]; t.act_high_d[j] = c.act_high[j]; }
     for (int a = 0; a < SCG_MAX_NX * SCG_MAX_NX; ++a) t.Q[a] = (float)c.Q[a];
     for (int a = 0; a < SCG_MAX_NU * SCG_MAX_NU; ++a) t.R[a] = (float)c.R[a];
 }

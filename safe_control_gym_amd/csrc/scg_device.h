@@ -24,6 +24,27 @@ enum Flags : uint32_t {
     F_REF_IN_LDS = 1u << 12,    // reference table staged in LDS (else read through L1/L2)
 };
 
+// Physical constants of the model, in the real type the integrator runs in: float in the kernarg block for
+// the default path, double in KTables for the precise (fp64-integration) mode -- there a 1e-8 mismatch of
+// a constant is a model bias that the open-loop plant integrates four times (torque -> position ~ t^4).
+template <class T>
+struct PhysT {
+    T h;                        // dt / substeps
+    // quadrotor
+    T inv_m, g;
+    T arm_s2;                   // l / sqrt(2)
+    T gamma;                    // KM / KF
+    T inv_ixx, inv_iyy, inv_izz;
+    T cxx, cyy, czz;            // (Izz-Iyy)/Ixx, (Ixx-Izz)/Iyy, (Iyy-Ixx)/Izz
+    T l_s2_iyy;                 // l / sqrt(2) / Iyy  (2-D)
+    // motor map
+    T inv_nmotor_kf;            // 1 / (n_motor KF)
+    T nmotor_kf;                // n_motor KF
+    T pwm_scale, inv_pwm_scale, pwm_const, pwm_min, pwm_max;
+    // cartpole
+    T cp_l, cp_m, cp_inv_Mm, cp_ml, cp_g;
+};
+
 // Scalars: travel in the kernarg block (SGPRs).
 struct KParams {
     uint32_t flags;
@@ -34,20 +55,7 @@ struct KParams {
     int32_t n_con_rows;         // total constraint rows (c_val planes)
     uint32_t seed_lo, seed_hi;
     int64_t env_base;
-    float h;                    // dt / substeps
-    // quadrotor
-    float inv_m, g;
-    float arm_s2;               // l / sqrt(2)
-    float gamma;                // KM / KF
-    float inv_ixx, inv_iyy, inv_izz;
-    float cxx, cyy, czz;        // (Izz-Iyy)/Ixx, (Ixx-Izz)/Iyy, (Iyy-Ixx)/Izz
-    float l_s2_iyy;             // l / sqrt(2) / Iyy  (2-D)
-    // motor map
-    float inv_nmotor_kf;        // 1 / (n_motor KF)
-    float nmotor_kf;            // n_motor KF
-    float pwm_scale, inv_pwm_scale, pwm_const, pwm_min, pwm_max;
-    // cartpole
-    float cp_l, cp_m, cp_inv_Mm, cp_ml, cp_g;
+    PhysT<float> ph;            // physical constants (fp32 copy, SGPRs)
     // action
     float norm_act_scale, hover_thrust, action_scale;
     float goal_tol2;
@@ -68,6 +76,8 @@ struct KTables {
     float mse_w[SCG_MAX_NX];
     float oob_low[SCG_MAX_NX], oob_high[SCG_MAX_NX];
     float init_state[SCG_MAX_NX], init_lo[SCG_MAX_NX], init_span[SCG_MAX_NX];
+    PhysT<double> phd;          // double-precision physical constants (precise mode only)
+    double act_low_d[SCG_MAX_NU], act_high_d[SCG_MAX_NU];
     // full Q / R (only read when F_Q_DIAG is clear)
     float Q[SCG_MAX_NX * SCG_MAX_NX];
     float R[SCG_MAX_NU * SCG_MAX_NU];

@@ -234,140 +234,154 @@ __device__ __forceinline__ void reset_state_coop(const KParams& p, const KTables
 // ------------------------------------------------------------------------------------------
 // continuous dynamics  x_dot = f(x, u)   (quadrotor.py:594-676; cartpole: DESIGN.md A16)
 // ------------------------------------------------------------------------------------------
-template <int SYS> struct Inputs;
+// All of it is generic over the real type T: float for the default path, double for the precise mode
+// (compensated_state), where the state travels as hi + lo float32 planes and the ODE is integrated in fp64
+// (fp64 FMA issues at the same 4-cycle rate as unpacked fp32 on this chip).
+template <class T> struct Real;
+template <> struct Real<float> {
+    static __device__ __forceinline__ float rcp(float x) { return rcp_f(x); }
+    static __device__ __forceinline__ void sincos(float x, float& s, float& c) { sincos_f(x, s, c); }
+};
+template <> struct Real<double> {
+    static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+    // fdlibm-style kernels on [-pi/4, pi/4] after a two-piece FMA Cody-Waite reduction; |err| < 4e-15 for |x| < 50
+    static __device__ __forceinline__ void sincos(double x, double& s, double& c) {
+        const double kf = rint(x * 0.63661977236758134308);
+        const int k = (int)kf;
+        double r = fma(kf, -1.5707963267948966, x);
+        r = fma(kf, -6.123233995736766e-17, r);
+        const double z = r * r;
+        double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+        ps = fma(ps, z, 2.75573137070700676789e-06);
+        ps = fma(ps, z, -1.98412698298579493134e-04);
+        ps = fma(ps, z, 8.33333333332248946124e-03);
+        ps = fma(ps, z, -1.66666666666666324348e-01);
+        const double sr = fma(r * z, ps, r);
+        double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+        pc = fma(pc, z, -2.75573143513906633035e-07);
+        pc = fma(pc, z, 2.48015872894767294178e-05);
+        pc = fma(pc, z, -1.38888888888741095749e-03);
+        pc = fma(pc, z, 4.16666666666666019037e-02);
+        const double cr = fma(z * z, pc, fma(z, -0.5, 1.0));
+        const double ss = (k & 1) ? cr : sr, cc = (k & 1) ? sr : cr;
+        s = (k & 2) ? -ss : ss;
+        c = ((k + 1) & 2) ? -cc : cc;
+    }
+};
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return fma(a, b, c); }
 
-template <> struct Inputs<SCG_QUAD_1D> { float acc; };                       // T/m - g (+ Fz/m)
-template <> struct Inputs<SCG_QUAD_2D> { float Tm, ax, az, thdd; };
-template <> struct Inputs<SCG_QUAD_3D> { float Tm, ax, ay, az, mx, my, mz; };
-template <> struct Inputs<SCG_CARTPOLE> { float F; };
+template <int SYS, class T> struct Inputs;
+template <class T> struct Inputs<SCG_QUAD_1D, T> { T acc; };                       // T/m - g (+ Fz/m)
+template <class T> struct Inputs<SCG_QUAD_2D, T> { T Tm, ax, az, thdd; };
+template <class T> struct Inputs<SCG_QUAD_3D, T> { T Tm, ax, ay, az, mx, my, mz; };
+template <class T> struct Inputs<SCG_CARTPOLE, T> { T F; };
 
-template <int SYS>
-__device__ __forceinline__ void make_inputs(const KParams& p, const float* u, float fx, float fy, float fz,
-                                            Inputs<SYS>& in);
-
-template <>
-__device__ __forceinline__ void make_inputs<SCG_QUAD_1D>(const KParams& p, const float* u, float fx, float fy,
-                                                         float fz, Inputs<SCG_QUAD_1D>& in) {
-    in.acc = fmaf(u[0] + fz, p.inv_m, -p.g);                                // quadrotor.py:602
-}
-template <>
-__device__ __forceinline__ void make_inputs<SCG_QUAD_2D>(const KParams& p, const float* u, float fx, float fy,
-                                                         float fz, Inputs<SCG_QUAD_2D>& in) {
-    in.Tm = (u[0] + u[1]) * p.inv_m;                                        // quadrotor.py:619-620
-    in.ax = fx * p.inv_m;
-    in.az = fmaf(fz, p.inv_m, -p.g);
-    in.thdd = p.l_s2_iyy * (u[1] - u[0]);                                   // quadrotor.py:621
-}
-template <>
-__device__ __forceinline__ void make_inputs<SCG_QUAD_3D>(const KParams& p, const float* u, float fx, float fy,
-                                                         float fz, Inputs<SCG_QUAD_3D>& in) {
-    in.Tm = ((u[0] + u[1]) + (u[2] + u[3])) * p.inv_m;                      // quadrotor.py:664
-    in.ax = fx * p.inv_m;
-    in.ay = fy * p.inv_m;
-    in.az = fmaf(fz, p.inv_m, -p.g);
-    in.mx = p.arm_s2 * ((u[0] + u[1]) - (u[2] + u[3])) * p.inv_ixx;         // quadrotor.py:667
-    in.my = p.arm_s2 * ((u[1] + u[2]) - (u[0] + u[3])) * p.inv_iyy;         // quadrotor.py:668
-    in.mz = p.gamma * ((u[0] + u[2]) - (u[1] + u[3])) * p.inv_izz;          // quadrotor.py:669
-}
-template <>
-__device__ __forceinline__ void make_inputs<SCG_CARTPOLE>(const KParams& p, const float* u, float fx, float fy,
-                                                          float fz, Inputs<SCG_CARTPOLE>& in) {
-    in.F = u[0] + fx;
-}
-
-template <int SYS>
-__device__ __forceinline__ void f_eval(const KParams& p, const Inputs<SYS>& in,
-                                       const float (&x)[Dim<SYS>::NX], float (&d)[Dim<SYS>::NX]);
-
-template <>
-__device__ __forceinline__ void f_eval<SCG_QUAD_1D>(const KParams& p, const Inputs<SCG_QUAD_1D>& in,
-                                                    const float (&x)[2], float (&d)[2]) {
-    d[0] = x[1];
-    d[1] = in.acc;
-}
-
-template <>
-__device__ __forceinline__ void f_eval<SCG_QUAD_2D>(const KParams& p, const Inputs<SCG_QUAD_2D>& in,
-                                                    const float (&x)[6], float (&d)[6]) {
-    float s, c;
-    sincos_f(x[4], s, c);
-    d[0] = x[1];
-    d[1] = fmaf(s, in.Tm, in.ax);
-    d[2] = x[3];
-    d[3] = fmaf(c, in.Tm, in.az);
-    d[4] = x[5];
-    d[5] = in.thdd;
-}
-
-template <>
-__device__ __forceinline__ void f_eval<SCG_QUAD_3D>(const KParams& p, const Inputs<SCG_QUAD_3D>& in,
-                                                    const float (&x)[12], float (&d)[12]) {
-    float sph, cph, sth, cth, sps, cps;
-    sincos_f(x[6], sph, cph);
-    sincos_f(x[7], sth, cth);
-    sincos_f(x[8], sps, cps);
-    const float P = x[9], Q = x[10], R = x[11];
-    // third column of R = Rz(psi) Ry(theta) Rx(phi)  (transformations.py:125-182)
-    const float sthcph = sth * cph;
-    d[0] = x[1];
-    d[1] = fmaf(fmaf(cps, sthcph, sps * sph), in.Tm, in.ax);
-    d[2] = x[3];
-    d[3] = fmaf(fmaf(sps, sthcph, -(cps * sph)), in.Tm, in.ay);
-    d[4] = x[5];
-    d[5] = fmaf(cth * cph, in.Tm, in.az);
-    // Euler-angle rates (quadrotor.py:671-673)
-    const float rcth = rcp_f(cth);
-    const float w = fmaf(sph, Q, cph * R);               // sin(phi) q + cos(phi) r
-    d[6] = fmaf(sth * rcth, w, P);
-    d[7] = fmaf(cph, Q, -(sph * R));
-    d[8] = w * rcth;
-    // body rates: Jinv (Mb - w x J w)  (quadrotor.py:670)
-    d[9] = fmaf(-p.cxx, Q * R, in.mx);
-    d[10] = fmaf(-p.cyy, R * P, in.my);
-    d[11] = fmaf(-p.czz, P * Q, in.mz);
+// ZOH inputs of one step.  In the precise mode the physical constants are the float-rounded kernarg values
+// widened to double -- the same constants the float path uses, so the two modes integrate the same model.
+template <int SYS, class T>
+__device__ __forceinline__ void make_inputs(const PhysT<T>& c, const T* u, float fx, float fy, float fz,
+                                            Inputs<SYS, T>& in) {
+    const T inv_m = c.inv_m, g = c.g;
+    if constexpr (SYS == SCG_QUAD_1D) {
+        in.acc = fma_t(u[0] + (T)fz, inv_m, -g);                                // quadrotor.py:602
+    } else if constexpr (SYS == SCG_QUAD_2D) {
+        in.Tm = (u[0] + u[1]) * inv_m;                                          // quadrotor.py:619-620
+        in.ax = (T)fx * inv_m;
+        in.az = fma_t((T)fz, inv_m, -g);
+        in.thdd = c.l_s2_iyy * (u[1] - u[0]);                                // quadrotor.py:621
+    } else if constexpr (SYS == SCG_QUAD_3D) {
+        in.Tm = ((u[0] + u[1]) + (u[2] + u[3])) * inv_m;                        // quadrotor.py:664
+        in.ax = (T)fx * inv_m;
+        in.ay = (T)fy * inv_m;
+        in.az = fma_t((T)fz, inv_m, -g);
+        in.mx = c.arm_s2 * ((u[0] + u[1]) - (u[2] + u[3])) * c.inv_ixx;   // quadrotor.py:667
+        in.my = c.arm_s2 * ((u[1] + u[2]) - (u[0] + u[3])) * c.inv_iyy;   // quadrotor.py:668
+        in.mz = c.gamma * ((u[0] + u[2]) - (u[1] + u[3])) * c.inv_izz;    // quadrotor.py:669
+    } else {
+        in.F = u[0] + (T)fx;
+    }
 }
 
-template <>
-__device__ __forceinline__ void f_eval<SCG_CARTPOLE>(const KParams& p, const Inputs<SCG_CARTPOLE>& in,
-                                                     const float (&x)[4], float (&d)[4]) {
-    float s, c;
-    sincos_f(x[2], s, c);
-    const float thd = x[3];
-    const float tmp = fmaf(p.cp_ml * thd * thd, s, in.F) * p.cp_inv_Mm;
-    const float den = p.cp_l * fmaf(-p.cp_m * p.cp_inv_Mm, c * c, 4.0f / 3.0f);
-    const float thdd = fmaf(p.cp_g, s, -(c * tmp)) * rcp_f(den);
-    d[0] = x[1];
-    d[1] = fmaf(-p.cp_ml * p.cp_inv_Mm, thdd * c, tmp);
-    d[2] = thd;
-    d[3] = thdd;
+template <int SYS, class T>
+__device__ __forceinline__ void f_eval(const PhysT<T>& c, const Inputs<SYS, T>& in, const T (&x)[Dim<SYS>::NX],
+                                       T (&d)[Dim<SYS>::NX]) {
+    if constexpr (SYS == SCG_QUAD_1D) {
+        d[0] = x[1];
+        d[1] = in.acc;
+    } else if constexpr (SYS == SCG_QUAD_2D) {
+        T s, co;
+        Real<T>::sincos(x[4], s, co);
+        d[0] = x[1];
+        d[1] = fma_t(s, in.Tm, in.ax);
+        d[2] = x[3];
+        d[3] = fma_t(co, in.Tm, in.az);
+        d[4] = x[5];
+        d[5] = in.thdd;
+    } else if constexpr (SYS == SCG_QUAD_3D) {
+        T sph, cph, sth, cth, sps, cps;
+        Real<T>::sincos(x[6], sph, cph);
+        Real<T>::sincos(x[7], sth, cth);
+        Real<T>::sincos(x[8], sps, cps);
+        const T P = x[9], Q = x[10], R = x[11];
+        // third column of R = Rz(psi) Ry(theta) Rx(phi)  (transformations.py:125-182)
+        const T sthcph = sth * cph;
+        d[0] = x[1];
+        d[1] = fma_t(fma_t(cps, sthcph, sps * sph), in.Tm, in.ax);
+        d[2] = x[3];
+        d[3] = fma_t(fma_t(sps, sthcph, -(cps * sph)), in.Tm, in.ay);
+        d[4] = x[5];
+        d[5] = fma_t(cth * cph, in.Tm, in.az);
+        // Euler-angle rates (quadrotor.py:671-673)
+        const T rcth = Real<T>::rcp(cth);
+        const T w = fma_t(sph, Q, cph * R);               // sin(phi) q + cos(phi) r
+        d[6] = fma_t(sth * rcth, w, P);
+        d[7] = fma_t(cph, Q, -(sph * R));
+        d[8] = w * rcth;
+        // body rates: Jinv (Mb - w x J w)  (quadrotor.py:670)
+        d[9] = fma_t(-c.cxx, Q * R, in.mx);
+        d[10] = fma_t(-c.cyy, R * P, in.my);
+        d[11] = fma_t(-c.czz, P * Q, in.mz);
+    } else {
+        T s, co;
+        Real<T>::sincos(x[2], s, co);
+        const T thd = x[3];
+        const T tmp = fma_t(c.cp_ml * thd * thd, s, in.F) * c.cp_inv_Mm;
+        const T den = c.cp_l * fma_t(-c.cp_m * c.cp_inv_Mm, co * co, (T)(4.0 / 3.0));
+        const T thdd = fma_t(c.cp_g, s, -(co * tmp)) * Real<T>::rcp(den);
+        d[0] = x[1];
+        d[1] = fma_t(-c.cp_ml * c.cp_inv_Mm, thdd * co, tmp);
+        d[2] = thd;
+        d[3] = thdd;
+    }
 }
 
-// One fixed step; returns the increment (so the caller can add it with compensation).
-template <int SYS>
-__device__ __forceinline__ void integrate(const KParams& p, const Inputs<SYS>& in,
-                                          const float (&x)[Dim<SYS>::NX], float (&inc)[Dim<SYS>::NX]) {
+// One fixed step; returns the increment (so the float path can add it with its own rounding).
+template <int SYS, class T>
+__device__ __forceinline__ void integrate(const PhysT<T>& c, uint32_t flags, const Inputs<SYS, T>& in,
+                                          const T (&x)[Dim<SYS>::NX], T (&inc)[Dim<SYS>::NX]) {
     constexpr int NX = Dim<SYS>::NX;
-    const float h = p.h;
-    float k[NX];
-    f_eval<SYS>(p, in, x, k);
-    if (p.flags & F_EULER) {
+    const T h = c.h;
+    T k[NX];
+    f_eval<SYS, T>(c, in, x, k);
+    if (flags & F_EULER) {
 #pragma unroll
         for (int j = 0; j < NX; ++j) inc[j] = h * k[j];
         return;
     }
     // RK4, zero-order-hold input (controllers/mpc/mpc_utils.py:93-97)
-    float xt[NX], acc[NX];
-    const float hh = 0.5f * h;
+    T xt[NX], acc[NX];
+    const T hh = (T)0.5 * h;
 #pragma unroll
-    for (int j = 0; j < NX; ++j) { acc[j] = k[j]; xt[j] = fmaf(hh, k[j], x[j]); }
-    f_eval<SYS>(p, in, xt, k);
+    for (int j = 0; j < NX; ++j) { acc[j] = k[j]; xt[j] = fma_t(hh, k[j], x[j]); }
+    f_eval<SYS, T>(c, in, xt, k);
 #pragma unroll
-    for (int j = 0; j < NX; ++j) { acc[j] = fmaf(2.0f, k[j], acc[j]); xt[j] = fmaf(hh, k[j], x[j]); }
-    f_eval<SYS>(p, in, xt, k);
+    for (int j = 0; j < NX; ++j) { acc[j] = fma_t((T)2, k[j], acc[j]); xt[j] = fma_t(hh, k[j], x[j]); }
+    f_eval<SYS, T>(c, in, xt, k);
 #pragma unroll
-    for (int j = 0; j < NX; ++j) { acc[j] = fmaf(2.0f, k[j], acc[j]); xt[j] = fmaf(h, k[j], x[j]); }
-    f_eval<SYS>(p, in, xt, k);
-    const float h6 = h * (1.0f / 6.0f);
+    for (int j = 0; j < NX; ++j) { acc[j] = fma_t((T)2, k[j], acc[j]); xt[j] = fma_t(h, k[j], x[j]); }
+    f_eval<SYS, T>(c, in, xt, k);
+    const T h6 = h * (T)(1.0 / 6.0);
 #pragma unroll
     for (int j = 0; j < NX; ++j) inc[j] = h6 * (acc[j] + k[j]);
 }
@@ -571,51 +585,72 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         float epr = cur.epr; int epl = cur.epl;
         const float fx = cur.fx, fy = cur.fy, fz = cur.fz;
 
-        // ---- before_step / _preprocess_control (benchmark_env.py:394-404, quadrotor.py:815-842)
-        float a_clip[NU], u[NU];
+        // ---- before_step / _preprocess_control (benchmark_env.py:394-404, quadrotor.py:815-842) and the state
+        //      advance: _advance_simulation replaced by fixed-step integration of the prior model.
+        //      RT = float, or double in the precise mode (state = hi + lo float32 planes, fp64 constants).
+        float a_clip[NU];
+        auto advance = [&](auto tag, const auto& ph) {
+            using RT = decltype(tag);
+            RT u[NU];
 #pragma unroll
-        for (int j = 0; j < NU; ++j) {
-            float a = clampf(a_raw[j], tb->act_low[j], tb->act_high[j]);
-            if (EXTRA && (p.flags & F_NORMALIZED)) {
-                if (SYS == SCG_CARTPOLE) a *= p.action_scale;
-                else a = fmaf(p.norm_act_scale, a, 1.0f) * p.hover_thrust;  // quadrotor.py:828
+            for (int j = 0; j < NU; ++j) {
+                float a = clampf(a_raw[j], tb->act_low[j], tb->act_high[j]);
+                if (EXTRA && (p.flags & F_NORMALIZED)) {
+                    if (SYS == SCG_CARTPOLE) a *= p.action_scale;
+                    else a = fmaf(p.norm_act_scale, a, 1.0f) * p.hover_thrust;   // quadrotor.py:828
+                }
+                a_clip[j] = a;                                                   // current_preprocessed_action (:833)
+                RT th = (RT)a;
+                if (sizeof(RT) == 8 && !(EXTRA && (p.flags & F_NORMALIZED))) {
+                    // the float32-typed bounds are exact in both precisions; clip in double all the same
+                    const double ad = (double)a_raw[j];
+                    th = (RT)fmin(fmax(ad, tb->act_low_d[j]), tb->act_high_d[j]);
+                }
+                if (EXTRA && io.action_disturbance) th += (RT)ldp(PL(io.action_disturbance, j), i4);   // :835-838
+                if (SYS != SCG_CARTPOLE && (p.flags & F_MOTOR_MAP)) {
+                    // cmd2pwm / pwm2rpm / KF rpm^2  (quadrotor_utils.py:38-50,66; base_aviary.py:420)
+                    RT pwm;
+                    if (sizeof(RT) == 8) pwm = (RT)((sqrt((double)(th > (RT)0 ? th : (RT)0) * (double)ph.inv_nmotor_kf) - (double)ph.pwm_const) * (double)ph.inv_pwm_scale);
+                    else pwm = (RT)((sqrt_f(fmaxf((float)th, 0.0f) * (float)ph.inv_nmotor_kf) - (float)ph.pwm_const) * (float)ph.inv_pwm_scale);
+                    pwm = pwm < ph.pwm_min ? ph.pwm_min : (pwm > ph.pwm_max ? ph.pwm_max : pwm);
+                    const RT rpm = fma_t(ph.pwm_scale, pwm, ph.pwm_const);
+                    th = ph.nmotor_kf * rpm * rpm;
+                }
+                u[j] = th;
             }
-            a_clip[j] = a;                                                  // current_preprocessed_action (:833)
-            float th = a;
-            if (EXTRA && io.action_disturbance) th += ldp(PL(io.action_disturbance, j), i4);   // :835-838
-            if (SYS != SCG_CARTPOLE && (p.flags & F_MOTOR_MAP)) {
-                // cmd2pwm / pwm2rpm / KF rpm^2  (quadrotor_utils.py:38-50,66; base_aviary.py:420)
-                float pwm = (sqrt_f(fmaxf(th, 0.0f) * p.inv_nmotor_kf) - p.pwm_const) * p.inv_pwm_scale;
-                pwm = clampf(pwm, p.pwm_min, p.pwm_max);
-                const float rpm = fmaf(p.pwm_scale, pwm, p.pwm_const);
-                th = p.nmotor_kf * rpm * rpm;
-            }
-            u[j] = th;
-        }
-
-        // ---- _advance_simulation replaced by fixed-step integration of the prior model
-        Inputs<SYS> in;
-        make_inputs<SYS>(p, u, fx, fy, fz, in);
-        for (int s = 0; s < p.substeps; ++s) {
-            float inc[NX];
-            integrate<SYS>(p, in, x, inc);
-            if (COMP) {
-                // compensated accumulation: (x + xlo) += inc with an error-free TwoSum
+            Inputs<SYS, RT> in;
+            make_inputs<SYS, RT>(ph, u, fx, fy, fz, in);
+            if (sizeof(RT) == 8) {
+                RT xd[NX];
+#pragma unroll
+                for (int j = 0; j < NX; ++j) xd[j] = (RT)x[j] + (RT)xlo[COMP ? j : 0];
+                for (int s = 0; s < p.substeps; ++s) {
+                    RT inc[NX];
+                    integrate<SYS, RT>(ph, p.flags, in, xd, inc);
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) xd[j] += inc[j];
+                }
 #pragma unroll
                 for (int j = 0; j < NX; ++j) {
-                    const float sum = x[j] + inc[j];
-                    const float bb = sum - x[j];
-                    const float err = (x[j] - (sum - bb)) + (inc[j] - bb);
-                    const float lo = xlo[j] + err;
-                    const float hi = sum + lo;
-                    xlo[j] = lo - (hi - sum);
-                    x[j] = hi;
+                    x[j] = (float)xd[j];
+                    xlo[COMP ? j : 0] = (float)(xd[j] - (RT)x[j]);
                 }
             } else {
+                RT xs[NX];
 #pragma unroll
-                for (int j = 0; j < NX; ++j) x[j] += inc[j];
+                for (int j = 0; j < NX; ++j) xs[j] = (RT)x[j];
+                for (int s = 0; s < p.substeps; ++s) {
+                    RT inc[NX];
+                    integrate<SYS, RT>(ph, p.flags, in, xs, inc);
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) xs[j] += inc[j];
+                }
+#pragma unroll
+                for (int j = 0; j < NX; ++j) x[j] = (float)xs[j];
             }
-        }
+        };
+        if constexpr (COMP) advance(double{}, tb->phd);
+        else advance(float{}, p.ph);
 
         // ---- error to the goal of this step: X_GOAL (stabilisation) or X_GOAL[min(t, T-1)]
         //      (quadrotor.py:905,1021; the quadratic cost's unclamped X_GOAL[t] (:926) is the same row
@@ -890,21 +925,21 @@ template <int SYS>
 __device__ __forceinline__ void make_inputs2(const KParams& p, const f2* u, Inputs2<SYS>& in);
 template <>
 __device__ __forceinline__ void make_inputs2<SCG_QUAD_1D>(const KParams& p, const f2* u, Inputs2<SCG_QUAD_1D>& in) {
-    in.acc = fma2(u[0], p.inv_m, -p.g);
+    in.acc = fma2(u[0], p.ph.inv_m, -p.ph.g);
 }
 template <>
 __device__ __forceinline__ void make_inputs2<SCG_QUAD_2D>(const KParams& p, const f2* u, Inputs2<SCG_QUAD_2D>& in) {
-    in.Tm = (u[0] + u[1]) * p.inv_m;
-    in.az = -p.g;
-    in.thdd = (u[1] - u[0]) * p.l_s2_iyy;
+    in.Tm = (u[0] + u[1]) * p.ph.inv_m;
+    in.az = -p.ph.g;
+    in.thdd = (u[1] - u[0]) * p.ph.l_s2_iyy;
 }
 template <>
 __device__ __forceinline__ void make_inputs2<SCG_QUAD_3D>(const KParams& p, const f2* u, Inputs2<SCG_QUAD_3D>& in) {
-    in.Tm = ((u[0] + u[1]) + (u[2] + u[3])) * p.inv_m;
-    in.az = -p.g;
-    in.mx = (((u[0] + u[1]) - (u[2] + u[3])) * p.arm_s2) * p.inv_ixx;
-    in.my = (((u[1] + u[2]) - (u[0] + u[3])) * p.arm_s2) * p.inv_iyy;
-    in.mz = (((u[0] + u[2]) - (u[1] + u[3])) * p.gamma) * p.inv_izz;
+    in.Tm = ((u[0] + u[1]) + (u[2] + u[3])) * p.ph.inv_m;
+    in.az = -p.ph.g;
+    in.mx = (((u[0] + u[1]) - (u[2] + u[3])) * p.ph.arm_s2) * p.ph.inv_ixx;
+    in.my = (((u[1] + u[2]) - (u[0] + u[3])) * p.ph.arm_s2) * p.ph.inv_iyy;
+    in.mz = (((u[0] + u[2]) - (u[1] + u[3])) * p.ph.gamma) * p.ph.inv_izz;
 }
 template <>
 __device__ __forceinline__ void make_inputs2<SCG_CARTPOLE>(const KParams& p, const f2* u, Inputs2<SCG_CARTPOLE>& in) {
@@ -952,9 +987,9 @@ __device__ __forceinline__ void f_eval2<SCG_QUAD_3D>(const KParams& p, const Inp
     d[6] = fma2(sth * rcth, w, P);
     d[7] = fma2(cph, Q, -(sph * R));
     d[8] = w * rcth;
-    d[9] = fma2(Q * R, -p.cxx, in.mx);
-    d[10] = fma2(R * P, -p.cyy, in.my);
-    d[11] = fma2(P * Q, -p.czz, in.mz);
+    d[9] = fma2(Q * R, -p.ph.cxx, in.mx);
+    d[10] = fma2(R * P, -p.ph.cyy, in.my);
+    d[11] = fma2(P * Q, -p.ph.czz, in.mz);
 }
 template <>
 __device__ __forceinline__ void f_eval2<SCG_CARTPOLE>(const KParams& p, const Inputs2<SCG_CARTPOLE>& in,
@@ -962,11 +997,11 @@ __device__ __forceinline__ void f_eval2<SCG_CARTPOLE>(const KParams& p, const In
     f2 s, c;
     sincos2(x[2], s, c);
     const f2 thd = x[3];
-    const f2 tmp = fma2((thd * thd) * p.cp_ml, s, in.F) * p.cp_inv_Mm;
-    const f2 den = fma2(c * c, -p.cp_m * p.cp_inv_Mm, 4.0f / 3.0f) * p.cp_l;
-    const f2 thdd = fma2(s, p.cp_g, -(c * tmp)) * rcp2(den);
+    const f2 tmp = fma2((thd * thd) * p.ph.cp_ml, s, in.F) * p.ph.cp_inv_Mm;
+    const f2 den = fma2(c * c, -p.ph.cp_m * p.ph.cp_inv_Mm, 4.0f / 3.0f) * p.ph.cp_l;
+    const f2 thdd = fma2(s, p.ph.cp_g, -(c * tmp)) * rcp2(den);
     d[0] = x[1];
-    d[1] = fma2(thdd * c, -p.cp_ml * p.cp_inv_Mm, tmp);
+    d[1] = fma2(thdd * c, -p.ph.cp_ml * p.ph.cp_inv_Mm, tmp);
     d[2] = thd;
     d[3] = thdd;
 }
@@ -974,7 +1009,7 @@ __device__ __forceinline__ void f_eval2<SCG_CARTPOLE>(const KParams& p, const In
 template <int SYS>
 __device__ __forceinline__ void integrate2(const KParams& p, const Inputs2<SYS>& in, f2 (&x)[Dim<SYS>::NX]) {
     constexpr int NX = Dim<SYS>::NX;
-    const float h = p.h;
+    const float h = p.ph.h;
     f2 k[NX];
     f_eval2<SYS>(p, in, x, k);
     if (p.flags & F_EULER) {
@@ -1145,11 +1180,11 @@ __global__ __launch_bounds__(kBlock) void scg_step2_kernel(const KParams p, cons
             l_act = fma2(ea * tb->w_act[j], ea, l_act);
             f2 th = a;
             if (SYS != SCG_CARTPOLE && (p.flags & F_MOTOR_MAP)) {
-                const f2 arg = (f2){fmaxf(th.x, 0.0f), fmaxf(th.y, 0.0f)} * p.inv_nmotor_kf;
-                f2 pwm = ((f2){sqrt_f(arg.x), sqrt_f(arg.y)} - p.pwm_const) * p.inv_pwm_scale;
-                pwm = (f2){clampf(pwm.x, p.pwm_min, p.pwm_max), clampf(pwm.y, p.pwm_min, p.pwm_max)};
-                const f2 rpm = fma2(pwm, p.pwm_scale, p.pwm_const);
-                th = (rpm * p.nmotor_kf) * rpm;
+                const f2 arg = (f2){fmaxf(th.x, 0.0f), fmaxf(th.y, 0.0f)} * p.ph.inv_nmotor_kf;
+                f2 pwm = ((f2){sqrt_f(arg.x), sqrt_f(arg.y)} - p.ph.pwm_const) * p.ph.inv_pwm_scale;
+                pwm = (f2){clampf(pwm.x, p.ph.pwm_min, p.ph.pwm_max), clampf(pwm.y, p.ph.pwm_min, p.ph.pwm_max)};
+                const f2 rpm = fma2(pwm, p.ph.pwm_scale, p.ph.pwm_const);
+                th = (rpm * p.ph.nmotor_kf) * rpm;
             }
             u[j] = th;
         }

@@ -147,6 +147,7 @@ class BenchmarkEnv:
         if info_level not in ('full', 'minimal'):
             raise ValueError("[ERROR] info_level must be 'full' or 'minimal'.")
         self.INFO_LEVEL = info_level
+        # precise mode: state kept as hi + lo float32 planes and integrated in float64
         self.COMPENSATED_STATE = bool(compensated_state)
         self.TRACK_EPISODE_STATS = bool(track_episode_stats)
         self.ENV_INDEX_BASE = int(env_index_base)

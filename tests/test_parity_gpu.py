@@ -356,49 +356,44 @@ def test_constraint_api_on_explicit_state(gpu):
             ref.envs, [r.constraints.constraints[env.constraints.constraints.index(con_e)] for r in ref.envs])]))
 
 
-def test_compensated_state_reduces_drift(gpu):
-    """compensated_state=True (hi + lo float32 planes, TwoSum accumulation) against plain float32 storage on a
-    300-step closed-loop-recorded action sequence: both within the episodic bound, compensated tighter."""
-    import torch
-    n = 32
+def test_precise_mode_open_loop_1000_step_drift(gpu):
+    """BASELINE north-star: "<= 1e-5 state drift vs CasADi over 1000 steps" on an identical action sequence.
+    Replaying a recorded sequence open loop on this marginally stable plant integrates any 1e-7 evaluation
+    error four times (torque -> rate -> attitude -> velocity -> position, ~t^4), so float32 arithmetic cannot
+    meet it (measured below); compensated_state=True integrates in float64 on hi + lo float32 state planes
+    with float64 constants and does."""
+    n = 16
     kw = dict(task='stabilization', task_info=GOAL3, cost='rl_reward', ctrl_freq=60, pyb_freq=240,
               done_on_out_of_bound=False, episode_len_sec=20)
     rng = np.random.default_rng(5)
     x0 = np.zeros((n, 12))
     x0[:, [0, 2, 4]] = [0.2, -0.1, 1.0]
-    x0 += rng.normal(size=(n, 12)) * 0.02
+    x0 = (x0 + rng.normal(size=(n, 12)) * 0.05).astype(np.float32).astype(np.float64)
     errs = {}
     for comp in (False, True):
         env, ref, sampler = make_pair(3, n, randomized_init=False, init_states=x0,
                                       engine_kwargs=dict(compensated_state=comp), **kw)
         sync_reset(env, ref, sampler)
         hover = ref.envs[0].U_GOAL
-        worst = 0.0
-        for k in range(300):
-            # PD attitude / altitude feedback evaluated on the ORACLE state, replayed open-loop on the engine
-            xs = np.stack([r.state for r in ref.envs])
-            thrust = hover[0] * 4 * (1 + 1.5 * (1.0 - xs[:, 4]) - 0.8 * xs[:, 5])
-            mx = -2e-3 * (xs[:, 6] + 0.02 * (xs[:, 2] + 0.1) * 0 ) - 4e-4 * xs[:, 9]
-            my = -2e-3 * xs[:, 7] - 4e-4 * xs[:, 10]
-            mz = -1e-3 * xs[:, 8] - 3e-4 * xs[:, 11]
-            k_arm = 0.0397 / np.sqrt(2)
-            gamma = 7.94e-12 / 3.16e-10
-            f = np.stack([thrust / 4 + mx / (4 * k_arm) - my / (4 * k_arm) + mz / (4 * gamma),
-                          thrust / 4 + mx / (4 * k_arm) + my / (4 * k_arm) - mz / (4 * gamma),
-                          thrust / 4 - mx / (4 * k_arm) + my / (4 * k_arm) + mz / (4 * gamma),
-                          thrust / 4 - mx / (4 * k_arm) - my / (4 * k_arm) - mz / (4 * gamma)], axis=1)
+        worst, at = 0.0, {}
+        for k in range(1000):
+            # feedback evaluated on the ORACLE state, then the same float32 actions replayed on the engine
+            f = _pd_controller(np.stack([r.state for r in ref.envs]), hover)
             out_e, out_r = sync_step(env, ref, sampler, f)
+            assert not bool(out_e[2].any()) and not out_r[2].any()
             xe = env.state.double()
             if comp:
                 xe = xe + env._bufs['state_lo'][:, :n].T.double()
             worst = max(worst, rel_err(xe.cpu().numpy(), np.stack([r.state for r in ref.envs])))
-        errs[comp] = worst
-        assert np.abs(np.stack([r.state for r in ref.envs])[:, 6:9]).max() < 0.5, 'controller failed to stabilise'
-    print('300-step open-loop replay drift: float32 state %.3e, compensated %.3e' % (errs[False], errs[True]))
-    # Open-loop replay on a marginally stable plant: the error is set by the fp32 evaluation of the torque ->
-    # body-rate -> attitude -> position chain (~1e-7 per stage, growing ~t^3), not by state storage, so the
-    # compensated accumulation only has to be no worse.  Measured values are recorded in DESIGN.md section 5.
-    assert errs[False] <= 1e-2 and errs[True] <= errs[False] * 1.2
+            if k + 1 in (100, 300, 1000):
+                at[k + 1] = worst
+        errs[comp] = at
+        xs = np.stack([r.state for r in ref.envs])
+        assert np.abs(xs[:, [0, 2, 4]] - [0.2, -0.1, 1.0]).max() < 0.02, 'controller did not converge'
+    print('open-loop replay drift  float32: %s   precise (fp64 integration): %s'
+          % ({k: '%.1e' % v for k, v in errs[False].items()}, {k: '%.1e' % v for k, v in errs[True].items()}))
+    assert errs[True][1000] <= 1e-5
+    assert errs[True][1000] < errs[False][1000]
 
 
 def _pd_controller(xs, hover):
