@@ -194,6 +194,19 @@ int scg_rollout(scg_handle* h, const scg_step_io* io, int64_t n, int32_t steps, 
 int scg_eval_constraints(scg_handle* h, const float* state, const float* action, float* c_val,
                          uint8_t* violation, int64_t ld, int64_t n, void* stream);
 
+/* ---- next row: returns / GAE over a device-resident rollout ------------------
+ * Replaces compute_returns_and_advantages (controllers/ppo/ppo_utils.py:428-456).  All arrays are device
+ * pointers, time-major planes [T][ld] (the PPOBuffer scheme's (T, N, 1) arrays, ppo_utils.py:308-336);
+ * last_val is [n].  term_val may be NULL (no time-limit bootstrap).  rew_out (nullable) receives
+ * rew + gamma * term_val, the reference's in-place update (:443).  stats (nullable, [2] doubles, zeroed by the
+ * caller) accumulates sum(adv) and sum(adv^2) for the advantage normalisation of ppo.py:288. */
+int scg_gae(const float* rew, const float* val, const float* mask, const float* term_val, const float* last_val,
+            float* ret, float* adv, float* rew_out, double* stats, int32_t T, int64_t n, int64_t ld, float gamma,
+            float gae_lambda, int32_t use_gae, void* stream);
+/* adv <- (adv - mean) / (std + eps), population statistics from `stats` (device memory, no host sync). */
+int scg_normalize_advantages(float* adv, const double* stats, int32_t T, int64_t n, int64_t ld, float eps,
+                             void* stream);
+
 /* Introspection */
 int scg_num_constraints(const scg_handle* h);
 int scg_obs_dim(const scg_handle* h);

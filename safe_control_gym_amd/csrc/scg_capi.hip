@@ -422,6 +422,27 @@ int scg_eval_constraints(scg_handle* h, const float* state, const float* action,
     return SCG_OK;
 }
 
+int scg_gae(const float* rew, const float* val, const float* mask, const float* term_val, const float* last_val,
+            float* ret, float* adv, float* rew_out, double* stats, int32_t T, int64_t n, int64_t ld, float gamma,
+            float gae_lambda, int32_t use_gae, void* stream) {
+    if (!rew || !val || !mask || !last_val || !ret || !adv) return fail(SCG_ERR_INVALID, "scg_gae: null argument");
+    if (T < 1 || n < 0 || ld < n) return fail(SCG_ERR_INVALID, "scg_gae: need T >= 1 and 0 <= n <= ld");
+    if (n == 0) return SCG_OK;
+    if (n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_gae: n > 2^30");
+    HIP_TRY(launch_gae(rew, val, mask, term_val, last_val, ret, adv, rew_out, stats, T, n, ld, gamma, gae_lambda,
+                       use_gae, (hipStream_t)stream));
+    return SCG_OK;
+}
+
+int scg_normalize_advantages(float* adv, const double* stats, int32_t T, int64_t n, int64_t ld, float eps,
+                             void* stream) {
+    if (!adv || !stats) return fail(SCG_ERR_INVALID, "scg_normalize_advantages: null argument");
+    if (T < 1 || n < 0 || ld < n) return fail(SCG_ERR_INVALID, "scg_normalize_advantages: need T >= 1 and 0 <= n <= ld");
+    if (n == 0) return SCG_OK;
+    HIP_TRY(launch_normalize(adv, stats, T, n, ld, eps, (hipStream_t)stream));
+    return SCG_OK;
+}
+
 int scg_num_constraints(const scg_handle* h) { return h ? h->n_con_rows : 0; }
 
 int scg_obs_dim(const scg_handle* h) { return h ? h->obs_dim : 0; }

@@ -127,6 +127,10 @@ hipError_t launch_reset(int system, const KParams& p, const KTables* tb, float* 
                         float* ep_return, int32_t* ep_length, float* obs, const uint8_t* mask,
                         const float* reset_state, const float* ref, uint32_t reset_serial, int64_t ld,
                         int64_t n, hipStream_t s);
+hipError_t launch_gae(const float* rew, const float* val, const float* mask, const float* term_val,
+                      const float* last_val, float* ret, float* adv, float* rew_out, double* stats, int T, int64_t n,
+                      int64_t ld, float gamma, float lam, int use_gae, hipStream_t s);
+hipError_t launch_normalize(float* adv, const double* stats, int T, int64_t n, int64_t ld, float eps, hipStream_t s);
 hipError_t launch_eval_constraints(int system, const ConTable* ct, const float* state, const float* action,
                                    float* c_val, uint8_t* violation, int64_t ld, int64_t n, hipStream_t s);
 }  // namespace scg

@@ -1,0 +1,105 @@
+// Returns / GAE advantages over a device-resident rollout.
+//
+// Replaces compute_returns_and_advantages (controllers/ppo/ppo_utils.py:428-456) -- a Python loop over T with
+// (N,1) NumPy temporaries on host copies of the rollout -- for rollouts that never leave the GPU.  Layout is
+// the PPOBuffer scheme's (T, N, 1) arrays (ppo_utils.py:308-336) stored time-major: plane t holds the N envs of
+// step t, so one lane per env walks t = T-1 .. 0 with fully coalesced 256-byte wave transactions.
+// HBM-bound: 4 reads + 2 writes of 4 bytes per (t, env) = 24 B (28 B when the time-limit-compensated rewards are
+// written back, as the reference's in-place `rews += gamma * terminal_vals` does, :443).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "scg_device.h"
+
+namespace scg {
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void scg_gae_kernel(const float* __restrict__ rew, const float* __restrict__ val,
+                                                      const float* __restrict__ mask, const float* __restrict__ term_val,
+                                                      const float* __restrict__ last_val, float* __restrict__ ret_out,
+                                                      float* __restrict__ adv_out, float* __restrict__ rew_out,
+                                                      double* __restrict__ stats, int T, uint32_t n, int64_t ld,
+                                                      float gamma, float lam, int use_gae) {
+    double s1 = 0.0, s2 = 0.0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        float ret = last_val[i];                     // ppo_utils.py:440: ret, adv = last_val, 0
+        float v_next = ret;                          // vals[T] = last_val (:441)
+        float adv = 0.f;
+        // software pipeline: the four loads of step t-1 are issued before the arithmetic of step t
+        int t = T - 1;
+        float r = rew[(int64_t)t * ld + i], v = val[(int64_t)t * ld + i], m = mask[(int64_t)t * ld + i];
+        float tv = term_val ? term_val[(int64_t)t * ld + i] : 0.f;
+        for (; t >= 0; --t) {
+            float rn = 0.f, vn = 0.f, mn = 0.f, tvn = 0.f;
+            if (t > 0) {
+                const int64_t o = (int64_t)(t - 1) * ld + i;
+                rn = rew[o]; vn = val[o]; mn = mask[o];
+                tvn = term_val ? term_val[o] : 0.f;
+            }
+            const float rr = fmaf(gamma, tv, r);                              // :443 rews += gamma * terminal_vals
+            const float gm = gamma * m;
+            ret = fmaf(gm, ret, rr);                                          // :446
+            if (use_gae) {
+                const float td = fmaf(gm, v_next, rr) - v;                    // :450
+                adv = fmaf(adv * lam, gm, td);                                // :451
+            } else {
+                adv = ret - v;                                                // :448
+            }
+            const int64_t o = (int64_t)t * ld + i;
+            ret_out[o] = ret;
+            adv_out[o] = adv;
+            if (rew_out) rew_out[o] = rr;
+            s1 += (double)adv;
+            s2 += (double)adv * (double)adv;
+            v_next = v;
+            r = rn; v = vn; m = mn; tv = tvn;
+        }
+    }
+    if (stats) {
+        s1 = wave_sum_d(s1);
+        s2 = wave_sum_d(s2);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&stats[0], s1);
+            atomicAdd(&stats[1], s2);
+        }
+    }
+}
+
+// adv <- (adv - mean) / (std + eps) with the population statistics accumulated by scg_gae_kernel (ppo.py:288).
+__global__ __launch_bounds__(256) void scg_normalize_kernel(float* __restrict__ adv, const double* __restrict__ stats,
+                                                            int T, uint32_t n, int64_t ld, float eps) {
+    const double count = (double)T * (double)n;
+    const double mean = stats[0] / count;
+    double var = stats[1] / count - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float mu = (float)mean, inv = (float)(1.0 / (sqrt(var) + (double)eps));
+    const int64_t total = (int64_t)T * ld;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        if ((uint32_t)(e % ld) < n) adv[e] = (adv[e] - mu) * inv;
+    }
+}
+
+hipError_t launch_gae(const float* rew, const float* val, const float* mask, const float* term_val,
+                      const float* last_val, float* ret, float* adv, float* rew_out, double* stats, int T, int64_t n,
+                      int64_t ld, float gamma, float lam, int use_gae, hipStream_t s) {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(scg_gae_kernel, dim3((unsigned)blocks), dim3(256), 0, s, rew, val, mask, term_val, last_val, ret,
+                       adv, rew_out, stats, T, (uint32_t)n, ld, gamma, lam, use_gae);
+    return hipGetLastError();
+}
+
+hipError_t launch_normalize(float* adv, const double* stats, int T, int64_t n, int64_t ld, float eps, hipStream_t s) {
+    int64_t blocks = ((int64_t)T * ld + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(scg_normalize_kernel, dim3((unsigned)blocks), dim3(256), 0, s, adv, stats, T, (uint32_t)n, ld, eps);
+    return hipGetLastError();
+}
+
+}  // namespace scg
