@@ -1,64 +1,52 @@
 """The ``VecEnv`` protocol (reference: env_wrappers/vectorized_env/vec_env.py:16-227) over a batched env."""
-from abc import ABC, abstractmethod
 
 
-class VecEnv(ABC):
-    closed = False
-    viewer = None
+def _must_override(name):
+    def method(self, *args, **kwargs):
+        raise NotImplementedError('%s.%s()' % (type(self).__name__, name))
+    method.__name__ = name
+    return method
+
+
+class VecEnv:
+    """Batched-environment protocol: one ``step(actions[N, nu])`` advances N envs (vec_env.py:16-162).
+
+    Sub-classes provide ``reset``, ``step_async``, ``step_wait``, ``get_attr``, ``set_attr``, ``env_method``.
+    """
+    closed, viewer = False, None
     metadata = {'render.modes': []}
 
     def __init__(self, num_envs, observation_space, action_space):
-        self.num_envs = num_envs
-        self.observation_space = observation_space
-        self.action_space = action_space
+        self.num_envs, self.observation_space, self.action_space = num_envs, observation_space, action_space
 
-    @abstractmethod
-    def reset(self):
-        pass
-
-    @abstractmethod
-    def step_async(self, actions):
-        pass
-
-    @abstractmethod
-    def step_wait(self):
-        pass
-
-    def close_extras(self):
-        pass
-
-    def close(self):
-        if self.closed:
-            return
-        self.close_extras()
-        self.closed = True
+    reset = _must_override('reset')
+    step_async = _must_override('step_async')
+    step_wait = _must_override('step_wait')
+    get_attr = _must_override('get_attr')
+    set_attr = _must_override('set_attr')
+    env_method = _must_override('env_method')
 
     def step(self, actions):
+        """Synchronous step = step_async + step_wait (vec_env.py:83-90)."""
         self.step_async(actions)
         return self.step_wait()
+
+    def close_extras(self):
+        """Hook for sub-classes; runs once from close()."""
+
+    def close(self):
+        if not self.closed:
+            self.close_extras()
+            self.closed = True
 
     @property
     def unwrapped(self):
         return self.venv.unwrapped if isinstance(self, VecEnvWrapper) else self
 
-    @abstractmethod
-    def get_attr(self, attr_name, indices=None):
-        pass
-
-    @abstractmethod
-    def set_attr(self, attr_name, values, indices=None):
-        pass
-
-    @abstractmethod
-    def env_method(self, method_name, method_args=None, method_kwargs=None, indices=None):
-        pass
-
     def _get_indices(self, indices):
         if indices is None:
-            indices = range(self.num_envs)
-        elif isinstance(indices, int):
-            indices = [indices]
-        return indices
+            return range(self.num_envs)
+        return [indices] if isinstance(indices, int) else indices
 
 
 class DeviceVecEnv(VecEnv):
