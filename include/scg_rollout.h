@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SCG_ABI_VERSION 1
+#define SCG_ABI_VERSION 2
 #define SCG_MAX_NX 12        /* quadrotor.py:625  (3-D: nx = 12) */
 #define SCG_MAX_NU 4         /* quadrotor.py:625  (3-D: nu = 4)  */
 #define SCG_MAX_NV 16        /* constrained variable: [state ; raw action], constraints.py:58-63 */
@@ -99,6 +99,11 @@ typedef struct scg_config {
     int32_t auto_reset;              /* dummy_vec_env.py:41-47 fused into step */
     double init_state[SCG_MAX_NX];
     double init_rand_low[SCG_MAX_NX], init_rand_high[SCG_MAX_NX];  /* low == high == 0: dim not randomised */
+    /* per-env inertial randomisation: quadrotor.py:455-467 (value = nominal + U(low, high) per reset) over
+     * (M, Ixx, Iyy, Izz); cartpole: (pole_length, pole_mass, cart_mass, -) per tests/scripts/verbose_api.yaml:40-54 */
+    int32_t randomized_inertial;
+    int32_t reserved2;
+    double inertial_rand_low[4], inertial_rand_high[4];
     uint64_t seed;                   /* Philox key */
     int64_t env_index_base;          /* global index of this shard's env 0 (seed + rank analogue,
                                         env_wrappers/vectorized_env/__init__.py:29) */
@@ -130,6 +135,9 @@ typedef struct scg_step_io {
     const float* obs_noise;          /* nullable [nx][ld] added to obs only (quadrotor.py:879-880) */
     const float* reset_state;        /* nullable [nx][ld] per-env nominal reset state (overrides cfg.init_state) */
     /* in/out */
+    float* inertial;                 /* nullable [4][ld] per-env (M, Ixx, Iyy, Izz) | (pole_length, pole_mass,
+                                        cart_mass, -); read every step, re-drawn on auto-reset when
+                                        cfg.randomized_inertial */
     float* state;                    /* [nx][ld] */
     float* state_lo;                 /* nullable [nx][ld] compensation residual (state = hi + lo) */
     int32_t* step_count;             /* [n] ctrl_step_counter */
@@ -168,11 +176,12 @@ int scg_set_constraints(scg_handle* h, const scg_constraint_row* rows, int32_t n
 
 /* Replaces Quadrotor.reset (quadrotor.py:356-504) + RecordEpisodeStatistics.reset
  * (record_episode_statistics.py:132-140) for the lanes where mask != 0 (all lanes if mask NULL).
- * Writes state (nominal + Philox uniform offsets), zeroes step_count / ep_return / ep_length, and
+ * Writes state (nominal + Philox uniform offsets) and, if inertial != NULL, the per-env inertial
+ * properties (nominal, + Philox offsets when cfg.randomized_inertial); zeroes step_count / ep_return / ep_length, and
  * if obs != NULL the extended observation; if c_val != NULL the state-only constraint values are
  * NOT produced here (reset-time only_state values come from scg_eval_constraints). */
 int scg_reset(scg_handle* h, float* state, float* state_lo, int32_t* step_count, float* ep_return,
-              int32_t* ep_length, float* obs, const uint8_t* mask, const float* reset_state,
+              int32_t* ep_length, float* obs, const uint8_t* mask, const float* reset_state, float* inertial,
               uint32_t reset_serial, int64_t ld, int64_t n, void* stream);
 
 /* Replaces Quadrotor.step (quadrotor.py:507-558) + BenchmarkEnv.after_step

@@ -65,3 +65,12 @@ def reset_offsets(seed, env_index, reset_serial, low, high):
             if d < nx:
                 out[d] = low[d] + (high[d] - low[d]) * u[w]
     return out
+
+
+def inertial_offsets(seed, env_index, reset_serial, low, high):
+    """Uniform offsets for the 4 inertial properties: Philox block 15 of the same (env, serial) counter."""
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)
+    ctr = np.array([env_index & 0xFFFFFFFF, (env_index >> 32) & 0xFFFFFFFF, reset_serial & 0xFFFFFFFF, 15], dtype=np.uint32)
+    u = uniform01(philox4x32_10(ctr, key))
+    low, high = np.asarray(low, dtype=np.float64), np.asarray(high, dtype=np.float64)
+    return low + (high - low) * u

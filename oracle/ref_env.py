@@ -87,7 +87,7 @@ class RefEnv:
                  # analytic-engine args
                  integrator='rk4', substeps=1, motor_map=True,
                  # oracle-only plumbing
-                 reset_sampler=None, env_index=0):
+                 reset_sampler=None, env_index=0, inertial_sampler=None):
         self.system = system
         self.NAME = 'cartpole' if system == 'cartpole' else 'quadrotor'
         self.nx, self.nu = rm.NX[system], rm.NU[system]
@@ -116,6 +116,7 @@ class RefEnv:
         self.done_on_out_of_bound = done_on_out_of_bound
         self.integrator, self.substeps, self.use_motor_map = integrator, int(substeps), motor_map
         self.reset_sampler, self.env_index = reset_sampler, env_index
+        self.inertial_sampler = inertial_sampler      # (env_index, episode) -> offsets added to (M, Ixx, Iyy, Izz)
         self.episode_index = -1
         # quadrotor.py:185-200
         if info_mse_metric_state_weight is None:
@@ -250,6 +251,15 @@ class RefEnv:
         self.current_raw_input_action = None
         self.current_preprocessed_action = None
         self.episode_index += 1
+        if self.inertial_sampler is not None:                   # quadrotor.py:455-467: nominal + draw, every reset
+            if not hasattr(self, '_nominal_params'):
+                self._nominal_params = self.params
+            off = self.inertial_sampler(self.env_index, self.episode_index)
+            n = self._nominal_params
+            if self.system == 'cartpole':
+                self.params = rm.CartPoleParams(n.l + off[0], n.m + off[1], n.M + off[2])
+            else:
+                self.params = rm.QuadParams(n.m + off[0], n.ixx + off[1], n.iyy + off[2], n.izz + off[3])
         init = self.init_nominal.copy()
         if self.RANDOMIZED_INIT:                                # benchmark_env.py:297-307 (adds to nominal)
             offs = self.reset_sampler(self.env_index, self.episode_index)

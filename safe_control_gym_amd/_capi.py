@@ -7,7 +7,7 @@ module raises.  Struct layouts mirror the header field for field; ``load()`` cro
 import ctypes as C
 import os
 
-SCG_ABI_VERSION = 1
+SCG_ABI_VERSION = 2
 SCG_MAX_NX = 12
 SCG_MAX_NU = 4
 SCG_MAX_NV = 16
@@ -53,6 +53,8 @@ class ScgConfig(C.Structure):
         ('randomized_init', _i32), ('auto_reset', _i32),
         ('init_state', _dbl * SCG_MAX_NX),
         ('init_rand_low', _dbl * SCG_MAX_NX), ('init_rand_high', _dbl * SCG_MAX_NX),
+        ('randomized_inertial', _i32), ('reserved2', _i32),
+        ('inertial_rand_low', _dbl * 4), ('inertial_rand_high', _dbl * 4),
         ('seed', C.c_uint64),
         ('env_index_base', C.c_int64),
     ]
@@ -72,7 +74,7 @@ class ScgStepIO(C.Structure):
         ('ld', C.c_int64),
         ('action', _fp), ('action_disturbance', _fp), ('dynamics_force', _fp), ('obs_noise', _fp),
         ('reset_state', _fp),
-        ('state', _fp), ('state_lo', _fp), ('step_count', _fp), ('ep_return', _fp), ('ep_length', _fp),
+        ('inertial', _fp), ('state', _fp), ('state_lo', _fp), ('step_count', _fp), ('ep_return', _fp), ('ep_length', _fp),
         ('obs', _fp), ('reward', _fp), ('done', _fp), ('constraint_values', _fp),
         ('constraint_violation', _fp), ('truncated', _fp), ('goal_reached', _fp), ('mse', _fp),
         ('terminal_obs', _fp), ('last_ep_return', _fp), ('last_ep_length', _fp), ('stats', _fp),
@@ -124,7 +126,7 @@ def load():
     lib.scg_destroy.argtypes = [C.c_void_p]
     lib.scg_set_reference.argtypes = [C.c_void_p, C.POINTER(_dbl), _i32]
     lib.scg_set_constraints.argtypes = [C.c_void_p, C.POINTER(ScgConstraintRow), _i32, C.POINTER(_dbl), _i32]
-    lib.scg_reset.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_uint32, C.c_int64,
+    lib.scg_reset.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_uint32, C.c_int64,
                               C.c_int64, C.c_void_p]
     lib.scg_step.argtypes = [C.c_void_p, C.POINTER(ScgStepIO), C.c_int64, C.c_void_p]
     lib.scg_rollout.argtypes = [C.c_void_p, C.POINTER(ScgStepIO), C.c_int64, _i32, C.c_int64, _i32, C.c_void_p]

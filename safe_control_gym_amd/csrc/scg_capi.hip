@@ -88,6 +88,7 @@ static void derive_params(scg_handle* h) {
     if (c.use_constraint_penalty) f |= F_PENALTY;
     if (c.randomized_init) f |= F_RAND_INIT;
     if (c.auto_reset) f |= F_AUTO_RESET;
+    if (c.randomized_inertial) f |= F_RAND_INERTIAL;
     if (c.task == SCG_TRAJ_TRACKING) f |= F_TRACKING;
     if (c.cost == SCG_QUADRATIC) f |= F_QUADRATIC;
     if (c.integrator == SCG_EULER) f |= F_EULER;
@@ -170,6 +171,17 @@ static void derive_tables(const scg_handle* h, KTables& t) {
         t.init_span[j] = (float)(c.init_rand_high[j] - c.init_rand_low[j]);
     }
     t.phd = h->phd;
+    t.arm = c.arm;
+    t.kmkf = c.system != SCG_CARTPOLE ? c.km / c.kf : 0.0;
+    const double nominal[4] = {c.system == SCG_CARTPOLE ? c.pole_length : c.mass,
+                               c.system == SCG_CARTPOLE ? c.pole_mass : c.ixx,
+                               c.system == SCG_CARTPOLE ? c.cart_mass : c.iyy,
+                               c.system == SCG_CARTPOLE ? 0.0 : c.izz};
+    for (int q = 0; q < 4; ++q) {
+        t.inertial_nominal[q] = (float)nominal[q];
+        t.inertial_lo[q] = (float)c.inertial_rand_low[q];
+        t.inertial_span[q] = (float)(c.inertial_rand_high[q] - c.inertial_rand_low[q]);
+    }
     for (int j = 0; j < nu; ++j) { t.act_low_d[j] = c.act_low[j]; t.act_high_d[j] = c.act_high[j]; }
     for (int a = 0; a < SCG_MAX_NX * SCG_MAX_NX; ++a) t.Q[a] = (float)c.Q[a];
     for (int a = 0; a < SCG_MAX_NU * SCG_MAX_NU; ++a) t.R[a] = (float)c.R[a];
@@ -209,6 +221,16 @@ int scg_create(const scg_config* cfg, scg_handle** out) {
             return fail(SCG_ERR_INVALID, "scg_create: non-positive physical constant");
     } else if (!(cfg->pole_length > 0 && cfg->pole_mass > 0 && cfg->cart_mass > 0)) {
         return fail(SCG_ERR_INVALID, "scg_create: non-positive cartpole constant");
+    }
+
+    if (cfg->randomized_inertial) {
+        const double nominal[4] = {cfg->system == SCG_CARTPOLE ? cfg->pole_length : cfg->mass,
+                                   cfg->system == SCG_CARTPOLE ? cfg->pole_mass : cfg->ixx,
+                                   cfg->system == SCG_CARTPOLE ? cfg->cart_mass : cfg->iyy,
+                                   cfg->system == SCG_CARTPOLE ? 1.0 : cfg->izz};
+        for (int q = 0; q < 4; ++q)
+            if (!(nominal[q] + cfg->inertial_rand_low[q] > 0.0) || cfg->inertial_rand_high[q] < cfg->inertial_rand_low[q])
+                return fail(SCG_ERR_INVALID, "scg_create: randomised inertial property %d can become non-positive", q);
     }
 
     scg_handle* h = new (std::nothrow) scg_handle();
@@ -365,7 +387,7 @@ int scg_set_constraints(scg_handle* h, const scg_constraint_row* rows, int32_t n
 }
 
 int scg_reset(scg_handle* h, float* state, float* state_lo, int32_t* step_count, float* ep_return,
-              int32_t* ep_length, float* obs, const uint8_t* mask, const float* reset_state,
+              int32_t* ep_length, float* obs, const uint8_t* mask, const float* reset_state, float* inertial,
               uint32_t reset_serial, int64_t ld, int64_t n, void* stream) {
     if (!h || !state || !step_count) return fail(SCG_ERR_INVALID, "scg_reset: null argument");
     if (n < 0 || ld < n) return fail(SCG_ERR_INVALID, "scg_reset: need 0 <= n <= ld (n=%lld ld=%lld)", (long long)n, (long long)ld);
@@ -374,7 +396,7 @@ int scg_reset(scg_handle* h, float* state, float* state_lo, int32_t* step_count,
     if ((h->kp.flags & F_TRACKING) && h->kp.obs_goal_horizon > 0 && obs && !h->d_ref)
         return fail(SCG_ERR_INVALID, "scg_reset: traj_tracking needs scg_set_reference() first");
     HIP_TRY(launch_reset(h->system, h->kp, h->d_tb, state, state_lo, step_count, ep_return, ep_length, obs, mask,
-                         reset_state, h->d_ref, reset_serial, ld, n, (hipStream_t)stream));
+                         reset_state, inertial, h->d_ref, reset_serial, ld, n, (hipStream_t)stream));
     return SCG_OK;
 }
 

@@ -22,6 +22,7 @@ enum Flags : uint32_t {
     F_QUADRATIC = 1u << 10,     // Cost.QUADRATIC (else RL_REWARD)
     F_EULER = 1u << 11,         // explicit Euler instead of RK4
     F_REF_IN_LDS = 1u << 12,    // reference table staged in LDS (else read through L1/L2)
+    F_RAND_INERTIAL = 1u << 13, // per-env inertial properties re-drawn at every reset
 };
 
 // Physical constants of the model, in the real type the integrator runs in: float in the kernarg block for
@@ -77,6 +78,8 @@ struct KTables {
     float oob_low[SCG_MAX_NX], oob_high[SCG_MAX_NX];
     float init_state[SCG_MAX_NX], init_lo[SCG_MAX_NX], init_span[SCG_MAX_NX];
     PhysT<double> phd;          // double-precision physical constants (precise mode only)
+    float inertial_nominal[4], inertial_lo[4], inertial_span[4];   // (M, Ixx, Iyy, Izz) | (pole_length, pole_mass, cart_mass, -)
+    double arm, kmkf;           // l and KM/KF, to rebuild the per-env constants
     double act_low_d[SCG_MAX_NU], act_high_d[SCG_MAX_NU];
     // full Q / R (only read when F_Q_DIAG is clear)
     float Q[SCG_MAX_NX * SCG_MAX_NX];
@@ -123,9 +126,9 @@ namespace scg {
 LaunchGeom step_geometry(const KParams& p, int system, int64_t n, int num_cus);
 hipError_t launch_step(int system, const KParams& p, const scg_step_io& io, const KTables* tb,
                        const ConTable* ct, const float* ref, int64_t n, int num_cus, hipStream_t s);
-hipError_t launch_reset(int system, const KParams& p, const KTables* tb, float* state, float* state_lo, int32_t* step_count,
-                        float* ep_return, int32_t* ep_length, float* obs, const uint8_t* mask,
-                        const float* reset_state, const float* ref, uint32_t reset_serial, int64_t ld,
+hipError_t launch_reset(int system, const KParams& p, const KTables* tb, float* state, float* state_lo,
+                        int32_t* step_count, float* ep_return, int32_t* ep_length, float* obs, const uint8_t* mask,
+                        const float* reset_state, float* inertial, const float* ref, uint32_t reset_serial, int64_t ld,
                         int64_t n, hipStream_t s);
 hipError_t launch_gae(const float* rew, const float* val, const float* mask, const float* term_val,
                       const float* last_val, float* ret, float* adv, float* rew_out, double* stats, int T, int64_t n,

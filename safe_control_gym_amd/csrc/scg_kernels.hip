@@ -484,6 +484,43 @@ __device__ __forceinline__ void load_goal(const KParams& p, const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------
+// per-env inertial properties (domain randomisation, quadrotor.py:455-475)
+// ------------------------------------------------------------------------------------------
+// value = nominal + U(low, high), one Philox block (counter word 3 = 15, distinct from the state blocks 0..2)
+__device__ __forceinline__ void draw_inertial(const KParams& p, const KTables* __restrict__ tb, uint32_t i,
+                                              uint32_t serial, float (&prop)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) prop[q] = tb->inertial_nominal[q];
+    if (p.flags & F_RAND_INERTIAL) {
+        const uint64_t g = (uint64_t)(p.env_base + (int64_t)i);
+        uint32_t w[4];
+        philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), serial, 15u, p.seed_lo, p.seed_hi, w);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            prop[q] += fmaf(tb->inertial_span[q], (float)(w[q] >> 8) * 5.9604644775390625e-8f, tb->inertial_lo[q]);
+    }
+}
+
+// Physical constants of ONE env from its (M, Ixx, Iyy, Izz) | (pole_length, pole_mass, cart_mass) planes;
+// everything that does not depend on them is copied from the shared block.
+template <int SYS, class T>
+__device__ __forceinline__ PhysT<T> phys_of_env(const PhysT<T>& shared, const KTables* __restrict__ tb,
+                                                const float (&prop)[4]) {
+    PhysT<T> c = shared;
+    if constexpr (SYS == SCG_CARTPOLE) {
+        const T l = (T)prop[0], m = (T)prop[1], M = (T)prop[2];
+        c.cp_l = l; c.cp_m = m; c.cp_inv_Mm = (T)1 / (m + M); c.cp_ml = m * l;
+    } else {
+        const T m = (T)prop[0], ixx = (T)prop[1], iyy = (T)prop[2], izz = (T)prop[3];
+        c.inv_m = (T)1 / m;
+        c.inv_ixx = (T)1 / ixx; c.inv_iyy = (T)1 / iyy; c.inv_izz = (T)1 / izz;
+        c.cxx = (izz - iyy) * c.inv_ixx; c.cyy = (ixx - izz) * c.inv_iyy; c.czz = (iyy - ixx) * c.inv_izz;
+        c.l_s2_iyy = c.arm_s2 * c.inv_iyy;
+    }
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------
 // the fused step kernel
 // ------------------------------------------------------------------------------------------
 // Addressing: the env index is a 32-bit lane value and every plane base (array + j*ld) is
@@ -589,8 +626,15 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         //      advance: _advance_simulation replaced by fixed-step integration of the prior model.
         //      RT = float, or double in the precise mode (state = hi + lo float32 planes, fp64 constants).
         float a_clip[NU];
-        auto advance = [&](auto tag, const auto& ph) {
+        auto advance = [&](auto tag, const auto& ph_shared) {
             using RT = decltype(tag);
+            auto ph = ph_shared;
+            if (EXTRA && io.inertial) {
+                float prop[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) prop[q] = ldp(PL(io.inertial, q), i4);
+                ph = phys_of_env<SYS, RT>(ph_shared, tb, prop);
+            }
             RT u[NU];
 #pragma unroll
             for (int j = 0; j < NU; ++j) {
@@ -800,6 +844,12 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                 }
                 t_out = 0;
                 epr = 0.f; epl = 0;
+                if (EXTRA && io.inertial && (p.flags & F_RAND_INERTIAL)) {
+                    float prop[4];
+                    draw_inertial(p, tb, i, io.reset_serial, prop);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) stp(PLS(io.inertial, q), i4, prop[q]);
+                }
             }
         }
 
@@ -1307,6 +1357,7 @@ __global__ __launch_bounds__(kBlock) void scg_reset_kernel(const KParams p, cons
                                                            int32_t* __restrict__ ep_length, float* __restrict__ obs,
                                                            const uint8_t* __restrict__ mask,
                                                            const float* __restrict__ reset_state,
+                                                           float* __restrict__ inertial,
                                                            const float* __restrict__ ref, uint32_t serial,
                                                            int64_t ld, uint32_t n) {
     constexpr int NX = Dim<SYS>::NX;
@@ -1320,6 +1371,12 @@ __global__ __launch_bounds__(kBlock) void scg_reset_kernel(const KParams p, cons
         if (state_lo) {
 #pragma unroll
             for (int j = 0; j < NX; ++j) stp(PL(state_lo, j), i4, 0.f);
+        }
+        if (inertial) {
+            float prop[4];
+            draw_inertial(p, tb, i, serial, prop);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) stp(PL(inertial, q), i4, prop[q]);
         }
         stp(step_count, i4, 0);
         if (ep_return) stp(ep_return, i4, 0.f);
@@ -1403,7 +1460,7 @@ LaunchGeom step_geometry(const KParams& p, int system, int64_t n, int num_cus) {
 
 // Which instantiation covers this call.
 static uint32_t features_needed(const KParams& p, const scg_step_io& io) {
-    const bool extra = io.action_disturbance || io.dynamics_force || io.obs_noise || io.obs || io.truncated ||
+    const bool extra = io.inertial || io.action_disturbance || io.dynamics_force || io.obs_noise || io.obs || io.truncated ||
                        io.goal_reached || io.mse || io.terminal_obs || io.last_ep_return || io.last_ep_length ||
                        io.stats || (p.flags & F_NORMALIZED) || !(p.flags & F_Q_DIAG);
     if (extra) return FT_TRACK | FT_CON | FT_EXTRA;
@@ -1491,8 +1548,8 @@ hipError_t launch_step(int system, const KParams& p, const scg_step_io& io, cons
 
 hipError_t launch_reset(int system, const KParams& p, const KTables* tb, float* state, float* state_lo,
                         int32_t* step_count, float* ep_return, int32_t* ep_length, float* obs,
-                        const uint8_t* mask, const float* reset_state, const float* ref, uint32_t serial,
-                        int64_t ld, int64_t n64, hipStream_t s) {
+                        const uint8_t* mask, const float* reset_state, float* inertial, const float* ref,
+                        uint32_t serial, int64_t ld, int64_t n64, hipStream_t s) {
     const uint32_t n = (uint32_t)n64;
     int64_t blocks = (n64 + kBlock - 1) / kBlock;
     if (blocks < 1) blocks = 1;
@@ -1500,16 +1557,16 @@ hipError_t launch_reset(int system, const KParams& p, const KTables* tb, float* 
     dim3 grid((unsigned)blocks), block(kBlock);
     switch (system) {
         case SCG_QUAD_1D:
-            hipLaunchKernelGGL(scg_reset_kernel<SCG_QUAD_1D>, grid, block, 0, s, p, tb, state, state_lo, step_count, ep_return, ep_length, obs, mask, reset_state, ref, serial, ld, n);
+            hipLaunchKernelGGL(scg_reset_kernel<SCG_QUAD_1D>, grid, block, 0, s, p, tb, state, state_lo, step_count, ep_return, ep_length, obs, mask, reset_state, inertial, ref, serial, ld, n);
             break;
         case SCG_QUAD_2D:
-            hipLaunchKernelGGL(scg_reset_kernel<SCG_QUAD_2D>, grid, block, 0, s, p, tb, state, state_lo, step_count, ep_return, ep_length, obs, mask, reset_state, ref, serial, ld, n);
+            hipLaunchKernelGGL(scg_reset_kernel<SCG_QUAD_2D>, grid, block, 0, s, p, tb, state, state_lo, step_count, ep_return, ep_length, obs, mask, reset_state, inertial, ref, serial, ld, n);
             break;
         case SCG_QUAD_3D:
-            hipLaunchKernelGGL(scg_reset_kernel<SCG_QUAD_3D>, grid, block, 0, s, p, tb, state, state_lo, step_count, ep_return, ep_length, obs, mask, reset_state, ref, serial, ld, n);
+            hipLaunchKernelGGL(scg_reset_kernel<SCG_QUAD_3D>, grid, block, 0, s, p, tb, state, state_lo, step_count, ep_return, ep_length, obs, mask, reset_state, inertial, ref, serial, ld, n);
             break;
         case SCG_CARTPOLE:
-            hipLaunchKernelGGL(scg_reset_kernel<SCG_CARTPOLE>, grid, block, 0, s, p, tb, state, state_lo, step_count, ep_return, ep_length, obs, mask, reset_state, ref, serial, ld, n);
+            hipLaunchKernelGGL(scg_reset_kernel<SCG_CARTPOLE>, grid, block, 0, s, p, tb, state, state_lo, step_count, ep_return, ep_length, obs, mask, reset_state, inertial, ref, serial, ld, n);
             break;
         default:
             return hipErrorInvalidValue;

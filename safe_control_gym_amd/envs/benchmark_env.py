@@ -18,7 +18,6 @@ What differs from the reference, by necessity of batching:
   * the physics is the reference's own prior model integrated with its own RK4,
     not PyBullet; reset randomisation draws from a counter-based Philox stream, not MT19937.
 """
-import math
 import os
 from enum import Enum
 
@@ -159,9 +158,6 @@ class BenchmarkEnv:
         self.PRIOR_PROP = prior_prop
         self.INERTIAL_PROP = inertial_prop
         self.RANDOMIZED_INERTIAL_PROP = randomized_inertial_prop
-        if randomized_inertial_prop:
-            raise NotImplementedError('[ERROR] randomized_inertial_prop: per-env inertial randomisation is a '
-                                      '"next" row of the scope table (SURVEY.md 8f rank 3).')
         if inertial_prop_randomization_info is not None:
             self.INERTIAL_PROP_RAND_INFO = inertial_prop_randomization_info
         self.NORMALIZED_RL_ACTION_SPACE = normalized_rl_action_space
@@ -316,6 +312,21 @@ class BenchmarkEnv:
         cfg.obs_goal_horizon = int(self.obs_goal_horizon)
         cfg.randomized_init = int(bool(self.RANDOMIZED_INIT))
         cfg.auto_reset = int(self.AUTO_RESET)
+        cfg.randomized_inertial = int(bool(self.RANDOMIZED_INERTIAL_PROP))
+        if self.RANDOMIZED_INERTIAL_PROP:
+            for q, key in enumerate(self._INERTIAL_KEYS):
+                info = self.INERTIAL_PROP_RAND_INFO.get(key) if key is not None else None
+                if info is None:
+                    continue
+                info = dict(info)
+                distrib = info.pop('distrib')
+                if distrib != 'uniform' or info.pop('args', []):
+                    raise NotImplementedError("[ERROR] only 'uniform' low/high inertial randomisation runs on the device "
+                                              '(got %r for %s).' % (distrib, key))
+                lo, hi = float(info.get('low', 0.0)), float(info.get('high', 1.0))
+                if self._inertial_nominal()[q] + lo <= 0:       # quadrotor.py:464-465
+                    raise ValueError('[ERROR] in reset(), negative randomized inertial properties.')
+                cfg.inertial_rand_low[q], cfg.inertial_rand_high[q] = lo, hi
         cfg.seed = self._seed & 0xFFFFFFFFFFFFFFFF
         cfg.env_index_base = self.ENV_INDEX_BASE
         self._fill_system_config(cfg)
@@ -351,6 +362,8 @@ class BenchmarkEnv:
         b['done'] = torch.zeros(ld, dtype=torch.uint8, device=dev)
         if self.COMPENSATED_STATE:
             b['state_lo'] = torch.zeros((nx, ld), dtype=f32, device=dev)
+        if self.RANDOMIZED_INERTIAL_PROP:
+            b['inertial'] = torch.zeros((4, ld), dtype=f32, device=dev)
         if self.TRACK_EPISODE_STATS:
             b['ep_return'] = torch.zeros(ld, dtype=f32, device=dev)
             b['ep_length'] = torch.zeros(ld, dtype=torch.int32, device=dev)
@@ -393,6 +406,11 @@ class BenchmarkEnv:
     @property
     def pyb_step_counter(self):
         return self.ctrl_step_counter * self.PYB_STEPS_PER_CTRL
+
+    @property
+    def inertial_properties(self):
+        """[N, 4] per-env (M, Ixx, Iyy, Izz) | (pole_length, pole_mass, cart_mass, -) when randomized_inertial_prop."""
+        return self._bufs['inertial'][:, :self.num_envs].T
 
     @property
     def episode_return(self):
@@ -479,7 +497,7 @@ class BenchmarkEnv:
         else:
             info['symbolic_constraints'] = {}
         info['initial_state_randomization'] = self.INIT_STATE_RAND_INFO if self.RANDOMIZED_INIT else {}
-        info['inertial_prop_randomization'] = {}
+        info['inertial_prop_randomization'] = self.INERTIAL_PROP_RAND_INFO if self.RANDOMIZED_INERTIAL_PROP else {}
         info['disturbances'] = self.DISTURBANCES
         return info
 

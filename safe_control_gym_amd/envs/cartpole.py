@@ -51,6 +51,7 @@ class CartPole(BenchmarkEnv):
         'num_cycles': 1, 'trajectory_plane': 'zx', 'trajectory_position_offset': [0, 0], 'trajectory_scale': 0.2,
     }
     _LABELS = ['init_x', 'init_x_dot', 'init_theta', 'init_theta_dot']
+    _INERTIAL_KEYS = ('pole_length', 'pole_mass', 'cart_mass', None)
 
     def __init__(self, init_state=None, inertial_prop=None, obs_goal_horizon=0, rew_state_weight=1.0,
                  rew_act_weight=0.0001, rew_exponential=True, done_on_out_of_bound=True,
@@ -122,6 +123,9 @@ class CartPole(BenchmarkEnv):
             mul = 1 + self.obs_goal_horizon if self.TASK == Task.TRAJ_TRACKING else 2
         self.observation_space = Box(low=np.concatenate([low] * mul), high=np.concatenate([high] * mul),
                                      dtype=np.float32)
+
+    def _inertial_nominal(self):
+        return [self.EFFECTIVE_POLE_LENGTH, self.POLE_MASS, self.CART_MASS, 1.0]
 
     def _fill_system_config(self, cfg):
         cfg.gravity = self.GRAVITY_ACC

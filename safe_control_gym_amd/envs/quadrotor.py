@@ -17,7 +17,6 @@ from enum import IntEnum
 
 import numpy as np
 
-from safe_control_gym_amd import _capi
 from safe_control_gym_amd.envs.benchmark_env import BenchmarkEnv, Cost, Task
 from safe_control_gym_amd.envs.constraints import GENERAL_CONSTRAINTS
 from safe_control_gym_amd.envs.spaces import Box
@@ -65,6 +64,7 @@ class Quadrotor(BenchmarkEnv):
         'num_cycles': 1, 'trajectory_plane': 'zx', 'trajectory_position_offset': [0.5, 0],
         'trajectory_scale': -0.5, 'proj_point': [0, 0, 0.5], 'proj_normal': [0, 1, 1],
     }
+    _INERTIAL_KEYS = ('M', 'Ixx', 'Iyy', 'Izz')
     _LABELS = {                                 # quadrotor.py:207-212
         QuadType.ONE_D: ['init_x', 'init_x_dot'],
         QuadType.TWO_D: ['init_x', 'init_x_dot', 'init_z', 'init_z_dot', 'init_theta', 'init_theta_dot'],
@@ -138,6 +138,10 @@ class Quadrotor(BenchmarkEnv):
         for k, name in enumerate(labels):
             setattr(self, name.upper(), nominal[k])
         self.INIT_STATE_RAND_INFO = {k: v for k, v in self.INIT_STATE_RAND_INFO.items() if k in labels}  # :227-229
+        # inertial randomisation only of what the quad type has (quadrotor.py:231-239)
+        keep = {QuadType.ONE_D: ('M',), QuadType.TWO_D: ('M', 'Iyy'), QuadType.THREE_D: ('M', 'Ixx', 'Iyy', 'Izz')}
+        self.INERTIAL_PROP_RAND_INFO = {k: v for k, v in self.INERTIAL_PROP_RAND_INFO.items()
+                                        if k in keep[self.QUAD_TYPE]}
         self._setup_symbolic()
         # goals (quadrotor.py:261-329)
         self.U_GOAL = np.ones(self.action_dim) * self.MASS * self.GRAVITY_ACC / self.action_dim
@@ -230,6 +234,9 @@ class Quadrotor(BenchmarkEnv):
                       Izz=self.J[2, 2], gamma=self.KM / self.KF)
         self.symbolic = AnalyticModel({1: 'quad1d', 2: 'quad2d', 3: 'quad3d'}[self.SYSTEM], consts,
                                       self.CTRL_TIMESTEP)
+
+    def _inertial_nominal(self):
+        return [self.MASS, self.J[0, 0], self.J[1, 1], self.J[2, 2]]
 
     # ------------------------------------------------------------------ C-ABI constants
     def _fill_system_config(self, cfg):
