@@ -542,7 +542,10 @@ enum Feat : uint32_t {
                      // are run-time decisions again.
 };
 
-template <int SYS, bool COMP, uint32_t FT>
+// STRIDED: the grid is smaller than the batch and every lane walks several envs (LDS-staged table, tuning
+// caps).  The default launch covers the batch exactly; compiling that case WITHOUT a loop keeps the ~50 kernarg
+// pointers and ~45 scalars from being loop-carried (they were hoisted and spilled: ~90 v_readlane per env-step).
+template <int SYS, bool COMP, uint32_t FT, bool STRIDED>
 __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io,
                                                           const KTables* __restrict__ tb,
                                                           const ConTable* __restrict__ ct,
@@ -603,11 +606,11 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         __syncthreads();
     }
 
-    for (; i < n; i += stride) {
+    if (i < n) do {
         const uint32_t i4 = i * 4u;
         const uint32_t inext = i + stride;
         LaneIn nxt;
-        if (SCG_PREFETCH && inext < n) load_lane(nxt, inext);
+        if (STRIDED && SCG_PREFETCH && inext < n) load_lane(nxt, inext);
         // ---- this lane's inputs (NX+NU+1 independent 256-B wave transactions were issued together)
         float x[NX], a_raw[NU], xlo[COMP ? NX : 1];
 #pragma unroll
@@ -892,9 +895,12 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         }
 
         // ---- next grid-stride iteration's inputs
-        if (SCG_PREFETCH) cur = nxt;
-        else if (inext < n) load_lane(cur, inext);
-    }
+        if (STRIDED) {
+            if (SCG_PREFETCH) cur = nxt;
+            else if (inext < n) load_lane(cur, inext);
+            i = inext;
+        }
+    } while (STRIDED && i < n);
 
     if (EXTRA && io.stats) {
         st_rew = wave_sum(st_rew); st_done = wave_sum(st_done); st_viol = wave_sum(st_viol);
@@ -1474,8 +1480,14 @@ template <int SYS, bool COMP>
 static void launch_step_ft(uint32_t ft, const LaunchGeom& g, const KParams& p, const scg_step_io& io,
                            const KTables* tb, const ConTable* ct, const float* ref, uint32_t n, hipStream_t s) {
 #define SCG_LAUNCH(FTV)                                                                                   \
-    hipLaunchKernelGGL((scg_step_kernel<SYS, COMP, (FTV)>), dim3(g.grid), dim3(g.block), g.lds_bytes, s, \
-                       p, io, tb, ct, ref, n)
+    do {                                                                                                  \
+        if ((int64_t)g.grid * g.block >= (int64_t)n)                                                      \
+            hipLaunchKernelGGL((scg_step_kernel<SYS, COMP, (FTV), false>), dim3(g.grid), dim3(g.block),   \
+                               g.lds_bytes, s, p, io, tb, ct, ref, n);                                    \
+        else                                                                                              \
+            hipLaunchKernelGGL((scg_step_kernel<SYS, COMP, (FTV), true>), dim3(g.grid), dim3(g.block),    \
+                               g.lds_bytes, s, p, io, tb, ct, ref, n);                                    \
+    } while (0)
     switch (ft) {
         case 0: SCG_LAUNCH(0u); break;
         case FT_TRACK: SCG_LAUNCH(FT_TRACK); break;
