@@ -10,9 +10,11 @@ build() { # name, extra flags...
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared "$@" -o "$out/$name.so" "$src/scg_kernels.hip" "$src/scg_gae.hip" "$src/scg_capi.hip" &
 }
 build base -fno-slp-vectorize
-build slp
-build pf -fno-slp-vectorize -DSCG_PREFETCH=1
-build w6 -fno-slp-vectorize -DSCG_MIN_WAVES=6
+build nont -fno-slp-vectorize -DSCG_NT=0
+build b128 -fno-slp-vectorize -DSCG_BLOCK=128
+build b512 -fno-slp-vectorize -DSCG_BLOCK=512
+wait
 build fasttrig -fno-slp-vectorize -DSCG_FAST_TRIG=1
+build slp
 wait
 ls -la "$out"

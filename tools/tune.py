@@ -39,16 +39,12 @@ def main():
         if f.endswith('.so'):
             arms.append((f[:-3], os.path.join(vdir, f), {}))
     base = os.path.join(vdir, 'base.so')
-    for e in ({'SCG_PACKED': '0'}, {'SCG_PACKED': '1', 'SCG_PACKED_BLOCKS_PER_CU': '100000'}):
-        arms.append(('base_' + '_'.join('%s%s' % (k[4:].lower(), v) for k, v in e.items()), base, e))
-    for pad in (0, 8, 16, 24):
-        arms.append(('base_pad%d' % pad, base, {'SCG_PACKED': '0', 'SCG_LD_PAD': str(pad)}))
-    pf = os.path.join(vdir, 'pf.so')
-    for cap in (4, 5, 8, 100000):
-        arms.append(('pf_cap%d' % cap, pf, {'SCG_PACKED': '0', 'SCG_GRID_CAP_PER_CU': str(cap)}))
-    for v in ('slp', 'w6', 'fasttrig'):
-        arms.append((v + '_unpacked', os.path.join(vdir, v + '.so'), {'SCG_PACKED': '0'}))
-    arms = [x for x in arms if not (x[2] == {} )]
+    for pad in (0, 9, 17, 25):
+        arms.append(('base_pad%d' % pad, base, {'SCG_LD_PAD': str(pad)}))
+    arms.append(('base_lds', base, {'SCG_REF_IN_LDS': '1'}))
+    for v in ('nont', 'b128', 'b512', 'fasttrig', 'slp'):
+        arms.append((v, os.path.join(vdir, v + '.so'), {'SCG_LD_PAD': '17'}))
+    arms = [x for x in arms if x[2] != {}]
     if a.arms:
         keep = set(a.arms.split(','))
         arms = [x for x in arms if x[0] in keep]
