@@ -121,6 +121,7 @@ def main():
     ap.add_argument('--episode-stats', action='store_true', help='track episode returns at 1 GPU too (B += 16)')
     ap.add_argument('--action-period', type=int, default=300)
     ap.add_argument('--python-loop', action='store_true', help='also time env.step() called from Python per step')
+    ap.add_argument('--fused', action='store_true', help='also time the one-launch multi-step rollout (own byte count)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--env-kw', action='append', default=[], help='extra make() kwargs key=value (yaml), for experiments')
@@ -194,6 +195,22 @@ def main():
         torch.cuda.synchronize()
         py_value = n * args.steps / (time.perf_counter() - t1)
 
+    fused = None
+    if args.fused and world == 1:
+        env.rollout(actions, steps=50, fused=True)
+        torch.cuda.synchronize()
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record()
+        env.rollout(actions, steps=args.steps, fused=True)
+        f1.record()
+        torch.cuda.synchronize()
+        fms = f0.elapsed_time(f1)
+        fbytes = 4 * nu                                  # per env-step: the action plane only (state stays in registers)
+        fused = {'value': n * args.steps / (fms * 1e-3), 'unit': 'env-steps/s', 'us_per_step': fms * 1e3 / args.steps,
+                 'bytes_per_env_step': fbytes, 'achieved_GBs': fbytes * n * args.steps / (fms * 1e-3) / 1e9,
+                 'note': 'scg_rollout_fused: ONE launch for all steps, envs stay in registers; not comparable with the '
+                         'per-step roofline above (its algorithmic bytes are 4*nu per env-step); VALU-bound'}
+
     if rank == 0:
         kernel_us = dev_ms * 1e3 / args.steps            # HIP-event time over the timed region / launches
         achieved = bytes_per * n / (kernel_us * 1e-6) / 1e9
@@ -218,6 +235,8 @@ def main():
         }
         if py_value is not None:
             out['python_step_api_value'] = py_value
+        if fused is not None:
+            out['fused_rollout'] = fused
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, wname)
         print(json.dumps(out))

@@ -198,6 +198,14 @@ int scg_step(scg_handle* h, const scg_step_io* io, int64_t n, void* stream);
 int scg_rollout(scg_handle* h, const scg_step_io* io, int64_t n, int32_t steps, int64_t action_stride,
                 int32_t action_period, void* stream);
 
+/* Same contract and same results as scg_rollout(), but ONE launch: each lane keeps its env in registers for all
+ * `steps` steps and reads only the step's action plane (4*nu bytes per env-step instead of 8*nx + 4*nu + 13).  Taken
+ * for the lean configurations (no disturbance planes / separate obs / per-step info outputs / precise mode); anything
+ * else silently runs scg_rollout().  The per-step Gym contract (obs, reward, done of EVERY step) is not produced:
+ * this is for open-loop rollouts (random-action benchmarks, shooting), not for a policy in the loop. */
+int scg_rollout_fused(scg_handle* h, const scg_step_io* io, int64_t n, int32_t steps, int64_t action_stride,
+                      int32_t action_period, void* stream);
+
 /* ConstraintList.get_values (constraints.py:503-520) on explicit buffers: state [nx][ld],
  * action [nu][ld] (nullable -> only_state semantics: input rows are written as NaN), out [nc][ld]. */
 int scg_eval_constraints(scg_handle* h, const float* state, const float* action, float* c_val,

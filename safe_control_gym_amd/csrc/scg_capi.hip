@@ -434,6 +434,24 @@ int scg_rollout(scg_handle* h, const scg_step_io* io, int64_t n, int32_t steps, 
     return SCG_OK;
 }
 
+int scg_rollout_fused(scg_handle* h, const scg_step_io* io, int64_t n, int32_t steps, int64_t action_stride,
+                      int32_t action_period, void* stream) {
+    if (!h || !io) return fail(SCG_ERR_INVALID, "scg_rollout_fused: null argument");
+    if (io->struct_size != sizeof(scg_step_io)) return fail(SCG_ERR_INVALID, "scg_rollout_fused: bad struct_size");
+    if (steps < 0 || action_period < 1 || action_stride < 0)
+        return fail(SCG_ERR_INVALID, "scg_rollout_fused: need steps >= 0, action_period >= 1, action_stride >= 0");
+    if (steps == 0 || n == 0) return SCG_OK;
+    if (!fused_rollout_ok(h->kp, *io)) return scg_rollout(h, io, n, steps, action_stride, action_period, stream);
+    if (n < 0 || io->ld < n || n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_rollout_fused: bad n / ld");
+    if (!io->action || !io->state || !io->step_count || !io->reward || !io->done)
+        return fail(SCG_ERR_INVALID, "scg_rollout_fused: action, state, step_count, reward and done are mandatory");
+    if ((h->kp.flags & F_TRACKING) && !h->d_ref)
+        return fail(SCG_ERR_INVALID, "scg_rollout_fused: traj_tracking needs scg_set_reference() first");
+    HIP_TRY(launch_rollout_fused(h->system, h->kp, *io, h->d_tb, h->d_con, h->d_ref, n, steps, action_stride,
+                                 action_period, h->num_cus, (hipStream_t)stream));
+    return SCG_OK;
+}
+
 int scg_eval_constraints(scg_handle* h, const float* state, const float* action, float* c_val,
                          uint8_t* violation, int64_t ld, int64_t n, void* stream) {
     if (!h || !state) return fail(SCG_ERR_INVALID, "scg_eval_constraints: null argument");

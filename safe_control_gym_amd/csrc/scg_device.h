@@ -126,6 +126,10 @@ namespace scg {
 LaunchGeom step_geometry(const KParams& p, int system, int64_t n, int num_cus);
 hipError_t launch_step(int system, const KParams& p, const scg_step_io& io, const KTables* tb,
                        const ConTable* ct, const float* ref, int64_t n, int num_cus, hipStream_t s);
+bool fused_rollout_ok(const KParams& p, const scg_step_io& io);
+hipError_t launch_rollout_fused(int system, const KParams& p, const scg_step_io& io, const KTables* tb,
+                                const ConTable* ct, const float* ref, int64_t n, int32_t steps, int64_t stride,
+                                int32_t period, int num_cus, hipStream_t s);
 hipError_t launch_reset(int system, const KParams& p, const KTables* tb, float* state, float* state_lo,
                         int32_t* step_count, float* ep_return, int32_t* ep_length, float* obs, const uint8_t* mask,
                         const float* reset_state, float* inertial, const float* ref, uint32_t reset_serial, int64_t ld,

@@ -545,13 +545,25 @@ enum Feat : uint32_t {
 // STRIDED: the grid is smaller than the batch and every lane walks several envs (LDS-staged table, tuning
 // caps).  The default launch covers the batch exactly; compiling that case WITHOUT a loop keeps the ~50 kernarg
 // pointers and ~45 scalars from being loop-carried (they were hoisted and spilled: ~90 v_readlane per env-step).
-template <int SYS, bool COMP, uint32_t FT, bool STRIDED>
+//
+// MODE 2 (fused rollout, scg_rollout_fused): the lane keeps its env in registers for ro.steps consecutive steps;
+// step k reads only its action plane (io.action + (k % ro.period) * ro.stride) and the outputs are stored after the
+// last step -- the same values scg_rollout() leaves behind, with 16 B instead of 125 B of HBM traffic per env-step.
+struct RolloutArgs {
+    int32_t steps, period;
+    int64_t stride;
+};
+constexpr int MODE_SINGLE = 0, MODE_STRIDED = 1, MODE_FUSED = 2;
+
+template <int SYS, bool COMP, uint32_t FT, int MODE>
 __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io,
                                                           const KTables* __restrict__ tb,
                                                           const ConTable* __restrict__ ct,
-                                                          const float* __restrict__ ref, const uint32_t n) {
+                                                          const float* __restrict__ ref, const uint32_t n,
+                                                          const RolloutArgs ro) {
     constexpr int NX = Dim<SYS>::NX, NU = Dim<SYS>::NU, NV = NX + NU;
     constexpr bool EXTRA = (FT & FT_EXTRA) != 0;
+    constexpr bool STRIDED = MODE == MODE_STRIDED, FUSED = MODE == MODE_FUSED;
     extern __shared__ __align__(16) float s_ref[];
 
     const bool tracking = EXTRA ? ((p.flags & F_TRACKING) != 0) : ((FT & FT_TRACK) != 0);
@@ -606,17 +618,26 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         __syncthreads();
     }
 
+    int kstep = 0;                                   // fused rollout: index of the step being computed
     if (i < n) do {
         const uint32_t i4 = i * 4u;
         const uint32_t inext = i + stride;
         LaneIn nxt;
         if (STRIDED && SCG_PREFETCH && inext < n) load_lane(nxt, inext);
+        const bool last = !FUSED || (kstep + 1 >= ro.steps);         // outputs are stored after the last fused step
+        const uint32_t serial = io.reset_serial + (FUSED ? (uint32_t)kstep : 0u);
         // ---- this lane's inputs (NX+NU+1 independent 256-B wave transactions were issued together)
         float x[NX], a_raw[NU], xlo[COMP ? NX : 1];
 #pragma unroll
         for (int j = 0; j < NX; ++j) x[j] = cur.x[j];
+        if (FUSED && kstep > 0) {
+            const float* act = io.action + (int64_t)(kstep % ro.period) * ro.stride;
 #pragma unroll
-        for (int j = 0; j < NU; ++j) a_raw[j] = cur.a_raw[j];
+            for (int j = 0; j < NU; ++j) a_raw[j] = ldp(PL(act, j), i4);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) a_raw[j] = cur.a_raw[j];
+        }
         if (COMP) {
 #pragma unroll
             for (int j = 0; j < NX; ++j) xlo[j] = cur.xlo[j];
@@ -779,12 +800,12 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
             for (int j = 0; j < NX; ++j) v[j] = x[j];
 #pragma unroll
             for (int j = 0; j < NU; ++j) v[NX + j] = a_raw[j];              // RAW action (constraints.py:167-168)
-            const ConFlags cf = eval_constraints<NV, false>(ct, v, io.constraint_values, ld, i);
+            const ConFlags cf = eval_constraints<NV, false>(ct, v, last ? io.constraint_values : nullptr, ld, i);
             violated = cf.violated;
             if (violated && (p.flags & F_DONE_VIOL)) done = true;           // :444-445
             if (!(p.flags & F_QUADRATIC) && (p.flags & F_PENALTY) && cf.almost)
                 rew += p.constraint_penalty;                                // :454-456
-            if (io.constraint_violation) stp(io.constraint_violation, i, (uint8_t)(violated ? 1 : 0));
+            if (last && io.constraint_violation) stp(io.constraint_violation, i, (uint8_t)(violated ? 1 : 0));
         }
         bool truncated = false;
         if (t1 >= p.ctrl_steps) { truncated = !done; done = true; }         // :460-462
@@ -794,8 +815,10 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         epr += rew;
         epl += 1;
 
-        stp(io.reward, i4, rew);
-        stp(io.done, i, (uint8_t)(done ? 1 : 0));
+        if (last) {
+            stp(io.reward, i4, rew);
+            stp(io.done, i, (uint8_t)(done ? 1 : 0));
+        }
 
         if (EXTRA && io.stats) {
             st_rew += rew; st_done += done ? 1.f : 0.f; st_viol += violated ? 1.f : 0.f;
@@ -837,7 +860,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         const bool need_reset = done && (p.flags & F_AUTO_RESET);
         if (__ballot(need_reset)) {                                         // wave-uniform
             float xr[NX];
-            reset_state_coop<NX>(p, tb, io.reset_state, ld, i, io.reset_serial, need_reset, coop_scratch, xr);
+            reset_state_coop<NX>(p, tb, io.reset_state, ld, i, serial, need_reset, coop_scratch, xr);
             if (need_reset) {
 #pragma unroll
                 for (int j = 0; j < NX; ++j) x[j] = xr[j];
@@ -849,23 +872,29 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                 epr = 0.f; epl = 0;
                 if (EXTRA && io.inertial && (p.flags & F_RAND_INERTIAL)) {
                     float prop[4];
-                    draw_inertial(p, tb, i, io.reset_serial, prop);
+                    draw_inertial(p, tb, i, serial, prop);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) stp(PLS(io.inertial, q), i4, prop[q]);
                 }
             }
         }
 
-        // ---- stores
+        // ---- stores (a fused rollout keeps the env in registers until its last step)
+        if (last) {
 #pragma unroll
-        for (int j = 0; j < NX; ++j) stp(PLS(io.state, j), i4, x[j]);
-        if (COMP) {
+            for (int j = 0; j < NX; ++j) stp(PLS(io.state, j), i4, x[j]);
+            if (COMP) {
 #pragma unroll
-            for (int j = 0; j < NX; ++j) stp(PLS(io.state_lo, j), i4, xlo[j]);
+                for (int j = 0; j < NX; ++j) stp(PLS(io.state_lo, j), i4, xlo[j]);
+            }
+            stp(io.step_count, i4, t_out);
+            if (io.ep_return) stp(io.ep_return, i4, epr);
+            if (io.ep_length) stp(io.ep_length, i4, epl);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) cur.x[j] = x[j];
+            cur.t = t_out; cur.epr = epr; cur.epl = epl;
         }
-        stp(io.step_count, i4, t_out);
-        if (io.ep_return) stp(io.ep_return, i4, epr);
-        if (io.ep_length) stp(io.ep_length, i4, epl);
 
         // ---- _get_observation + extend_obs (quadrotor.py:878-884, benchmark_env.py:406-420)
         if (EXTRA && io.obs) {
@@ -900,7 +929,8 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
             else if (inext < n) load_lane(cur, inext);
             i = inext;
         }
-    } while (STRIDED && i < n);
+        ++kstep;
+    } while ((STRIDED && i < n) || (FUSED && kstep < ro.steps));
 
     if (EXTRA && io.stats) {
         st_rew = wave_sum(st_rew); st_done = wave_sum(st_done); st_viol = wave_sum(st_viol);
@@ -1481,12 +1511,13 @@ static void launch_step_ft(uint32_t ft, const LaunchGeom& g, const KParams& p, c
                            const KTables* tb, const ConTable* ct, const float* ref, uint32_t n, hipStream_t s) {
 #define SCG_LAUNCH(FTV)                                                                                   \
     do {                                                                                                  \
+        const RolloutArgs ro{1, 1, 0};                                                                    \
         if ((int64_t)g.grid * g.block >= (int64_t)n)                                                      \
-            hipLaunchKernelGGL((scg_step_kernel<SYS, COMP, (FTV), false>), dim3(g.grid), dim3(g.block),   \
-                               g.lds_bytes, s, p, io, tb, ct, ref, n);                                    \
+            hipLaunchKernelGGL((scg_step_kernel<SYS, COMP, (FTV), MODE_SINGLE>), dim3(g.grid),            \
+                               dim3(g.block), g.lds_bytes, s, p, io, tb, ct, ref, n, ro);                 \
         else                                                                                              \
-            hipLaunchKernelGGL((scg_step_kernel<SYS, COMP, (FTV), true>), dim3(g.grid), dim3(g.block),    \
-                               g.lds_bytes, s, p, io, tb, ct, ref, n);                                    \
+            hipLaunchKernelGGL((scg_step_kernel<SYS, COMP, (FTV), MODE_STRIDED>), dim3(g.grid),           \
+                               dim3(g.block), g.lds_bytes, s, p, io, tb, ct, ref, n, ro);                 \
     } while (0)
     switch (ft) {
         case 0: SCG_LAUNCH(0u); break;
@@ -1543,6 +1574,42 @@ static void launch_step_sys(LaunchGeom g, const KParams& p, const scg_step_io& i
     }
     if (io.state_lo) launch_step_ft<SYS, true>(ft, g, p, io, tb, ct, ref, n, s);
     else launch_step_ft<SYS, false>(ft, g, p, io, tb, ct, ref, n, s);
+}
+
+// Fused multi-step rollout: lean tiers, float state, table gathered from global memory, exact-cover grid.
+bool fused_rollout_ok(const KParams& p, const scg_step_io& io) {
+    return !(features_needed(p, io) & FT_EXTRA) && !io.state_lo && !(p.flags & F_REF_IN_LDS);
+}
+
+template <int SYS>
+static void launch_fused_sys(const KParams& p, const scg_step_io& io, const KTables* tb, const ConTable* ct,
+                             const float* ref, uint32_t n, const RolloutArgs& ro, int lds_bytes, hipStream_t s) {
+    const uint32_t ft = features_needed(p, io);
+    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+#define SCG_LAUNCHF(FTV) \
+    hipLaunchKernelGGL((scg_step_kernel<SYS, false, (FTV), MODE_FUSED>), grid, block, lds_bytes, s, p, io, tb, ct, ref, n, ro)
+    switch (ft) {
+        case 0: SCG_LAUNCHF(0u); break;
+        case FT_TRACK: SCG_LAUNCHF(FT_TRACK); break;
+        case FT_CON: SCG_LAUNCHF(FT_CON); break;
+        default: SCG_LAUNCHF(FT_TRACK | FT_CON); break;
+    }
+#undef SCG_LAUNCHF
+}
+
+hipError_t launch_rollout_fused(int system, const KParams& p, const scg_step_io& io, const KTables* tb,
+                                const ConTable* ct, const float* ref, int64_t n, int32_t steps, int64_t stride,
+                                int32_t period, int num_cus, hipStream_t s) {
+    const LaunchGeom g = step_geometry(p, system, n, num_cus);
+    const RolloutArgs ro{steps, period, stride};
+    switch (system) {
+        case SCG_QUAD_1D: launch_fused_sys<SCG_QUAD_1D>(p, io, tb, ct, ref, (uint32_t)n, ro, g.lds_bytes, s); break;
+        case SCG_QUAD_2D: launch_fused_sys<SCG_QUAD_2D>(p, io, tb, ct, ref, (uint32_t)n, ro, g.lds_bytes, s); break;
+        case SCG_QUAD_3D: launch_fused_sys<SCG_QUAD_3D>(p, io, tb, ct, ref, (uint32_t)n, ro, g.lds_bytes, s); break;
+        case SCG_CARTPOLE: launch_fused_sys<SCG_CARTPOLE>(p, io, tb, ct, ref, (uint32_t)n, ro, g.lds_bytes, s); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_step(int system, const KParams& p, const scg_step_io& io, const KTables* tb,

@@ -82,15 +82,16 @@ class Engine:
         with torch.cuda.device(self.device):
             _capi.check(self.lib.scg_step(self.handle, C.byref(io), n, self._stream()), 'scg_step')
 
-    def rollout(self, bufs, n, ld, serial, steps, actions):
-        """``steps`` launches; ``actions`` is a contiguous [period, nu, ld] float32 tensor used cyclically."""
+    def rollout(self, bufs, n, ld, serial, steps, actions, fused=False):
+        """``steps`` launches (or one fused launch); ``actions`` is a contiguous [period, nu, ld] float32 tensor
+        used cyclically."""
         io = self._bind(bufs, ld)
         io.action = actions.data_ptr()
         io.reset_serial = serial & 0xffffffff
         period, stride = actions.shape[0], actions.shape[1] * actions.shape[2]
         with torch.cuda.device(self.device):
-            _capi.check(self.lib.scg_rollout(self.handle, C.byref(io), n, steps, stride, period, self._stream()),
-                        'scg_rollout')
+            fn = self.lib.scg_rollout_fused if fused else self.lib.scg_rollout
+            _capi.check(fn(self.handle, C.byref(io), n, steps, stride, period, self._stream()), 'scg_rollout')
 
     def eval_constraints(self, env, action_soa):
         """[N, num_device_rows] values of this engine's constraint table on env's state."""

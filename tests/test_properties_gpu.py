@@ -113,6 +113,17 @@ def test_rollout_equals_step_loop_and_stats(gpu):
     c_env.rollout(acts, steps=K)
     assert torch.equal(a_env.state, c_env.state) and torch.equal(a_env.episode_return, c_env.episode_return)
     assert torch.equal(a_env.ctrl_step_counter, c_env.ctrl_step_counter)
+    # the fused multi-step launch leaves exactly the same buffers behind (lean configuration)
+    kw_lean = dict(kw, info_level='minimal')
+    d_env, e_env = scg.make('quadrotor', num_envs=n, **kw_lean), scg.make('quadrotor', num_envs=n, **kw_lean)
+    d_env.reset(); e_env.reset()
+    d_env.rollout(acts, steps=K)
+    e_env.rollout(acts, steps=K, fused=True)
+    torch.cuda.synchronize()
+    assert torch.equal(d_env.state, e_env.state) and torch.equal(d_env.ctrl_step_counter, e_env.ctrl_step_counter)
+    assert torch.equal(d_env.episode_return, e_env.episode_return) and torch.equal(d_env.episode_length, e_env.episode_length)
+    assert torch.equal(d_env._bufs['reward'], e_env._bufs['reward']) and torch.equal(d_env._bufs['done'], e_env._bufs['done'])
+    assert torch.equal(a_env.state, d_env.state)
 
 
 def test_vec_env_protocol_and_episode_statistics(gpu):
