@@ -150,3 +150,41 @@ def test_vec_env_protocol_and_episode_statistics(gpu):
     per_env = info['n'][0]
     assert 'constraint_values' in per_env and 'mse' in per_env
     venv.close()
+
+
+def test_c_abi_edge_cases(gpu):
+    """Empty, ragged and over-size inputs and misuse at the C boundary: status codes, never a crash."""
+    import ctypes as C
+    from safe_control_gym_amd import _capi
+    env = scg.make('quadrotor', quad_type=3, num_envs=300, device='cuda', seed=1, task='traj_tracking', cost='quadratic',
+                   ctrl_freq=60, pyb_freq=240, info_level='minimal')
+    env.reset()
+    lib, eng = _capi.load(), env._engine
+    io = eng._bind(dict(env._bufs, reset_state=None), env._ld)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    before = env.state.clone()
+    assert lib.scg_step(eng.handle, C.byref(io), 0, stream) == 0                     # empty batch: nothing happens
+    torch.cuda.synchronize()
+    assert torch.equal(env.state, before)
+    assert lib.scg_step(eng.handle, C.byref(io), -1, stream) == -1
+    assert lib.scg_step(eng.handle, C.byref(io), env._ld + 1, stream) == -1         # n > ld
+    assert b'ld' in lib.scg_last_error()
+    io.ld = (1 << 30) + 64
+    assert lib.scg_step(eng.handle, C.byref(io), (1 << 30) + 1, stream) == -1       # beyond the 32-bit lane offsets
+    io.ld = env._ld
+    saved, io.reward = io.reward, None
+    assert lib.scg_step(eng.handle, C.byref(io), 300, stream) == -1                 # mandatory output missing
+    io.reward = saved
+    io.struct_size = 8
+    assert lib.scg_step(eng.handle, C.byref(io), 300, stream) == -1
+    io.struct_size = C.sizeof(_capi.ScgStepIO)
+    assert lib.scg_rollout(eng.handle, C.byref(io), 300, 3, 0, 0, stream) == -1     # action_period must be >= 1
+    assert lib.scg_step(eng.handle, C.byref(io), 300, stream) == 0                  # and the handle still works
+    torch.cuda.synchronize()
+    assert not torch.equal(env.state, before)
+    # a stabilisation handle refuses a reference table; a tracking one refuses too few rows for the quadratic cost
+    tab = (C.c_double * (12 * 10))()
+    assert lib.scg_set_reference(eng.handle, tab, 10) == -1 and b'rows' in lib.scg_last_error()
+    stab = scg.make('quadrotor', quad_type=2, num_envs=4, device='cuda')
+    stab.reset()
+    assert lib.scg_set_reference(stab._engine.handle, tab, 10) == -1
