@@ -37,7 +37,7 @@ namespace scg {
 #define SCG_PACKED_BLOCKS_PER_CU 2   // packed kernel grid cap: resident workgroups per CU (2 waves per SIMD)
 #endif
 #ifndef SCG_NT
-#define SCG_NT 1               // nontemporal hint on the streamed planes (measured -5% kernel time)
+#define SCG_NT 1               // nontemporal hint on the streamed planes: 0 none, 1 loads+stores (measured -5%), 2 stores only, 3 loads only
 #endif
 constexpr int kBlock = SCG_BLOCK;
 #if SCG_MIN_WAVES > 0
@@ -76,7 +76,7 @@ __device__ __forceinline__ T* uptr(T* p) {       // pin a wave-uniform pointer i
 }
 template <class T>
 __device__ __forceinline__ T ldp(const T* base, uint32_t boff) {
-#if SCG_NT
+#if SCG_NT == 1 || SCG_NT == 3
     return __builtin_nontemporal_load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + boff));
 #else
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + boff);
@@ -84,7 +84,7 @@ __device__ __forceinline__ T ldp(const T* base, uint32_t boff) {
 }
 template <class T>
 __device__ __forceinline__ void stp(T* base, uint32_t boff, T v) {
-#if SCG_NT
+#if SCG_NT == 1 || SCG_NT == 2
     __builtin_nontemporal_store(v, reinterpret_cast<T*>(reinterpret_cast<char*>(base) + boff));
 #else
     *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + boff) = v;

@@ -10,11 +10,8 @@ build() { # name, extra flags...
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared "$@" -o "$out/$name.so" "$src/scg_kernels.hip" "$src/scg_gae.hip" "$src/scg_capi.hip" &
 }
 build base -fno-slp-vectorize
-build nont -fno-slp-vectorize -DSCG_NT=0
+build nt2 -fno-slp-vectorize -DSCG_NT=2
+build nt3 -fno-slp-vectorize -DSCG_NT=3
 build b128 -fno-slp-vectorize -DSCG_BLOCK=128
-build b512 -fno-slp-vectorize -DSCG_BLOCK=512
-wait
-build fasttrig -fno-slp-vectorize -DSCG_FAST_TRIG=1
-build slp
 wait
 ls -la "$out"

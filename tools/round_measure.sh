@@ -9,11 +9,13 @@ mkdir -p "$out"
 cd "$root"
 echo "== tests"; tools/run_gpu_tests.sh > "$out/gpu_tests.log" 2>&1; tail -4 "$out/gpu_tests.log"
 echo "== smoke"; python __graft_entry__.py smoke 2>&1 | tail -1
-echo "== bench c4"; python bench.py --python-loop > "$out/bench_c4.json" 2> "$out/bench_c4.err"; cat "$out/bench_c4.json"
+echo "== bench c4"; python bench.py --python-loop --fused > "$out/bench_c4.json" 2> "$out/bench_c4.err"; cat "$out/bench_c4.json"
 echo "== bench c4 + episode stats (the C5 per-GPU shard)"; python bench.py --episode-stats --no-cpu-baseline > "$out/bench_c5shard.json" 2>/dev/null; cat "$out/bench_c5shard.json"
-echo "== bench c3"; python bench.py --workload c3 --envs-per-gpu 262144 --steps 5000 > "$out/bench_c3.json" 2>/dev/null; cat "$out/bench_c3.json"
-echo "== bench c2"; python bench.py --workload c2 --envs-per-gpu 65536 --steps 10000 > "$out/bench_c2.json" 2>/dev/null; cat "$out/bench_c2.json"
+echo "== bench c3"; python bench.py --workload c3 --envs-per-gpu 262144 --steps 5000 --fused > "$out/bench_c3.json" 2>/dev/null; cat "$out/bench_c3.json"
+echo "== bench c2"; python bench.py --workload c2 --envs-per-gpu 65536 --steps 10000 --fused > "$out/bench_c2.json" 2>/dev/null; cat "$out/bench_c2.json"
 echo "== N sweep"; for e in 10 12 14 16 18 20 22; do python bench.py --envs-per-gpu $((1<<e)) --steps 2000 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read()); print('N=2^$e  %.3e env-steps/s  %.2f us/step  frac %.3f' % (j['value'], j['roofline']['kernel_us_per_launch'], j['roofline']['frac']))"; done | tee "$out/n_sweep.txt"
+echo "== precise mode"; python bench.py --no-cpu-baseline --steps 1500 --env-kw compensated_state=true > "$out/bench_c4_precise.json" 2>/dev/null; python -c "import json; j=json.load(open('$out/bench_c4_precise.json')); print('precise mode %.3e env-steps/s %.2f us' % (j['value'], j['roofline']['kernel_us_per_launch']))"
+echo "== gae"; python tools/bench_gae.py 2>/dev/null | tail -1 | tee "$out/bench_gae.json"
 echo "== 2 ranks sharing this GPU over gloo (rehearsal of the N>1 path)"
 SCG_SINGLE_DEVICE=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 600 --warmup 50 --envs-per-gpu 524288 > "$out/bench_2rank_rehearsal.json" 2> "$out/bench_2rank.err"; tail -1 "$out/bench_2rank_rehearsal.json"
 echo "== rocprof kernel trace"

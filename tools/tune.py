@@ -38,12 +38,8 @@ def main():
     for f in sorted(os.listdir(vdir)):
         if f.endswith('.so'):
             arms.append((f[:-3], os.path.join(vdir, f), {}))
-    base = os.path.join(vdir, 'base.so')
-    for pad in (0, 9, 17, 25):
-        arms.append(('base_pad%d' % pad, base, {'SCG_LD_PAD': str(pad)}))
-    arms.append(('base_lds', base, {'SCG_REF_IN_LDS': '1'}))
-    for v in ('nont', 'b128', 'b512', 'fasttrig', 'slp'):
-        arms.append((v, os.path.join(vdir, v + '.so'), {'SCG_LD_PAD': '17'}))
+    for v in ('base', 'nt2', 'nt3', 'b128'):
+        arms.append((v + '_', os.path.join(vdir, v + '.so'), {'SCG_LD_PAD': '17'}))
     arms = [x for x in arms if x[2] != {}]
     if a.arms:
         keep = set(a.arms.split(','))
