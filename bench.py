@@ -218,7 +218,9 @@ def main():
         tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get(args.workload if (world == 1 and not args.episode_stats) else 'c5', {}).get('bytes_per_launch')
+                rec = json.load(f).get(args.workload if (world == 1 and not args.episode_stats) else 'c5', {})
+            if rec.get('envs', 1 << 20) == n and not args.env_kw:       # counters were collected at this size only
+                traffic = rec.get('bytes_per_launch')
         out = {
             'metric': 'env-steps/sec at N parallel envs, 1/2/4/8 GPUs; % HBM-BW roofline',
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

@@ -190,7 +190,7 @@ class BenchmarkEnv:
         self.RESEED_ON_RESET = kwargs.get('reseed_on_reset', False)
         self._bufs = None
         self._serial = 0
-        self.current_raw_input_action = None
+        self._raw_action = None
 
     # ------------------------------------------------------------------ seeding
     def seed(self, seed=None):
@@ -359,7 +359,7 @@ class BenchmarkEnv:
         b['action'] = torch.zeros((nu, ld), dtype=f32, device=dev)
         b['step_count'] = torch.zeros(ld, dtype=torch.int32, device=dev)
         b['reward'] = torch.zeros(ld, dtype=f32, device=dev)
-        b['done'] = torch.zeros(ld, dtype=torch.uint8, device=dev)
+        b['done'] = torch.zeros(ld, dtype=torch.bool, device=dev)          # the kernel writes 0 / 1 bytes
         if self.COMPENSATED_STATE:
             b['state_lo'] = torch.zeros((nx, ld), dtype=f32, device=dev)
         if self.RANDOMIZED_INERTIAL_PROP:
@@ -374,15 +374,34 @@ class BenchmarkEnv:
             b['obs'] = torch.zeros((self.obs_dim, ld), dtype=f32, device=dev)
         if self.INFO_LEVEL == 'full':
             b['mse'] = torch.zeros(ld, dtype=f32, device=dev)
-            b['truncated'] = torch.zeros(ld, dtype=torch.uint8, device=dev)
+            b['truncated'] = torch.zeros(ld, dtype=torch.bool, device=dev)
             b['terminal_obs'] = torch.zeros((self.obs_dim, ld), dtype=f32, device=dev)
             if self.TASK == Task.STABILIZATION and self.COST == Cost.QUADRATIC:
-                b['goal_reached'] = torch.zeros(ld, dtype=torch.uint8, device=dev)
+                b['goal_reached'] = torch.zeros(ld, dtype=torch.bool, device=dev)
             if self.TRACK_EPISODE_STATS:
                 b['last_ep_return'] = torch.zeros(ld, dtype=f32, device=dev)
                 b['last_ep_length'] = torch.zeros(ld, dtype=torch.int32, device=dev)
         self._bufs = b
         self._reset_state_buf = None
+        self._bound = False
+        # output views are created once: step() hands out the same zero-copy views of the buffers every call
+        info = {}
+        if 'mse' in b:
+            info['mse'] = b['mse'][:n]
+        if 'goal_reached' in b:
+            info['goal_reached'] = b['goal_reached'][:n]
+        if self.constraints is not None:
+            info['constraint_values'] = self.constraints.fold(b['constraint_values'][:, :n].T) \
+                if self.constraints.num_device_rows == self.constraints.num_constraints else None
+            info['constraint_violation'] = b['constraint_violation'][:n]
+        if 'truncated' in b:
+            info['TimeLimit.truncated'] = b['truncated'][:n]
+        if 'terminal_obs' in b:
+            info['terminal_observation'] = b['terminal_obs'][:, :n].T
+        if 'last_ep_return' in b:
+            info['episode'] = {'r': b['last_ep_return'][:n], 'l': b['last_ep_length'][:n]}
+        self._info_views = info
+        self._out_views = ((b['obs'] if 'obs' in b else b['state'])[:, :n].T, b['reward'][:n], b['done'][:n])
 
     # ------------------------------------------------------------------ views
     @property
@@ -420,6 +439,11 @@ class BenchmarkEnv:
     def episode_length(self):
         return self._bufs['ep_length'][:self.num_envs]
 
+    @property
+    def current_raw_input_action(self):
+        """[N, nu] view of the last raw action (benchmark_env.py:431 keeps it for the input constraints)."""
+        return None if self._raw_action is None else self._raw_action[:, :self.num_envs].T
+
     def _raw_action_soa(self):
         return getattr(self, '_raw_action', None) if getattr(self, '_raw_action', None) is not None else self._bufs['action']
 
@@ -442,10 +466,10 @@ class BenchmarkEnv:
         io = dict(self._bufs)
         io['reset_state'] = self._reset_state_buf
         self._engine.rollout(io, self.num_envs, self._ld, self._serial, steps, actions, fused=fused)
+        self._bound = False
         self._serial += steps
         k = (steps - 1) % actions.shape[0]
         self._raw_action = actions[k]
-        self.current_raw_input_action = actions[k][:, :self.num_envs].T
 
     @property
     def plane_stride(self):
@@ -461,6 +485,7 @@ class BenchmarkEnv:
         buf = torch.zeros((self.state_dim, self._ld), dtype=torch.float32, device=self.device)
         buf[:, :self.num_envs] = t.T
         self._reset_state_buf = buf
+        self._bound = False
 
     # ------------------------------------------------------------------ reset / step
     def _obs_view(self):
@@ -473,7 +498,7 @@ class BenchmarkEnv:
             self.seed(self.RND_SEED)
         self._ensure_engine()
         self.initial_reset = True
-        self.current_raw_input_action = None
+        self._raw_action = None
         for mode in self.disturbances:
             self.disturbances[mode].reset(self)
         if self.adversary_disturbance is not None:
@@ -483,6 +508,7 @@ class BenchmarkEnv:
             m = torch.zeros(self._ld, dtype=torch.uint8, device=self.device)
             m[:self.num_envs] = torch.as_tensor(mask, device=self.device).to(torch.uint8)
         self._engine.reset(self._bufs, m, self._reset_state_buf, self._serial, self.num_envs, self._ld)
+        self._bound = False
         self._serial += 1
         obs = self._obs_view()
         if self.INFO_IN_RESET:
@@ -533,38 +559,32 @@ class BenchmarkEnv:
         self._check_initial_reset()
         act = self._load_action(action)
         self._raw_action = act
-        self.current_raw_input_action = act[:, :self.num_envs].T
         b = self._bufs
-        io = dict(b)
-        io['action'] = act
-        io['reset_state'] = self._reset_state_buf
-        # disturbances (quadrotor.py:526-548,835-838,879-880): noise planes generated on device
-        if 'action' in self.disturbances or self.adversary_disturbance == 'action':
-            io['action_disturbance'] = self._disturbance_plane('action', self.action_dim)
-        if 'dynamics' in self.disturbances or self.adversary_disturbance == 'dynamics':
-            io['dynamics_force'] = self._dynamics_force_plane()
-        if 'observation' in self.disturbances:
-            io['obs_noise'] = self._disturbance_plane('observation', self.state_dim)
-        self._engine.step(io, self.num_envs, self._ld, self._serial)
+        if self.disturbances or self.adversary_disturbance is not None:
+            # disturbances (quadrotor.py:526-548,835-838,879-880): noise planes generated on device
+            io = dict(b)
+            io['action'] = act
+            io['reset_state'] = self._reset_state_buf
+            if 'action' in self.disturbances or self.adversary_disturbance == 'action':
+                io['action_disturbance'] = self._disturbance_plane('action', self.action_dim)
+            if 'dynamics' in self.disturbances or self.adversary_disturbance == 'dynamics':
+                io['dynamics_force'] = self._dynamics_force_plane()
+            if 'observation' in self.disturbances:
+                io['obs_noise'] = self._disturbance_plane('observation', self.state_dim)
+            self._engine.step(io, self.num_envs, self._ld, self._serial)
+            self._bound = False
+        else:
+            if not self._bound:
+                io = dict(b)
+                io['reset_state'] = self._reset_state_buf
+                self._engine.bind_static(io, self._ld)
+                self._bound = True
+            self._engine.step_bound(act, self.num_envs, self._serial)
         self._serial += 1
-        n = self.num_envs
-        obs = self._obs_view()
-        rew = b['reward'][:n]
-        done = b['done'][:n].bool()
-        info = {}
-        if 'mse' in b:
-            info['mse'] = b['mse'][:n]
-        if 'goal_reached' in b:
-            info['goal_reached'] = b['goal_reached'][:n].bool()
-        if self.constraints is not None:
-            info['constraint_values'] = self.constraints.fold(b['constraint_values'][:, :n].T)
-            info['constraint_violation'] = b['constraint_violation'][:n]
-        if 'truncated' in b:
-            info['TimeLimit.truncated'] = b['truncated'][:n].bool()
-        if 'terminal_obs' in b:
-            info['terminal_observation'] = b['terminal_obs'][:, :n].T
-        if 'last_ep_return' in b:
-            info['episode'] = {'r': b['last_ep_return'][:n], 'l': b['last_ep_length'][:n]}
+        obs, rew, done = self._out_views
+        info = dict(self._info_views)
+        if info.get('constraint_values', 0) is None:                 # folded constraints (|y| - bound): needs a max()
+            info['constraint_values'] = self.constraints.fold(b['constraint_values'][:, :self.num_envs].T)
         if self.INFO_LEVEL == 'full':
             info['n'] = LazyInfoList(info, done)
         return obs, rew, done, info

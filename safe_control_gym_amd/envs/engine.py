@@ -82,6 +82,24 @@ class Engine:
         with torch.cuda.device(self.device):
             _capi.check(self.lib.scg_step(self.handle, C.byref(io), n, self._stream()), 'scg_step')
 
+    def bind_static(self, bufs, ld):
+        """Bind the long-lived buffers once; ``step_bound`` then only swaps the action pointer and the serial."""
+        self._bind(bufs, ld)
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+
+    def step_bound(self, action, n, serial):
+        """Hot path of env.step(): ~3 ctypes stores and one foreign call."""
+        io = self._io
+        io.action = action.data_ptr()
+        io.reset_serial = serial & 0xffffffff
+        if torch.cuda.current_device() == self._dev_index:
+            status = self.lib.scg_step(self.handle, C.byref(io), n, self._stream())
+        else:
+            with torch.cuda.device(self.device):
+                status = self.lib.scg_step(self.handle, C.byref(io), n, self._stream())
+        if status != 0:
+            _capi.check(status, 'scg_step')
+
     def rollout(self, bufs, n, ld, serial, steps, actions, fused=False):
         """``steps`` launches (or one fused launch); ``actions`` is a contiguous [period, nu, ld] float32 tensor
         used cyclically."""
