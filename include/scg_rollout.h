@@ -224,6 +224,24 @@ int scg_gae(const float* rew, const float* val, const float* mask, const float* 
 int scg_normalize_advantages(float* adv, const double* stats, int32_t T, int64_t n, int64_t ld, float eps,
                              void* stream);
 
+/* ---- next row: batched prior-model queries ------------------------------------
+ * scg_linearize replaces SymbolicModel.df_func (math_and_models/symbolic_systems.py:77-92: dfdx = d f / d x,
+ * dfdu = d f / d u of the continuous dynamics) for n (x, u) pairs in one launch.  state [nx][ld] and input
+ * [nu][ld] are SoA planes; `input` is the MODEL input u (per-motor thrusts in N / cart force), i.e. the
+ * clipped action, not the raw action.  inertial (nullable, [4][ld]) gives per-env (M, Ixx, Iyy, Izz) /
+ * (pole_length, pole_mass, cart_mass, -); NULL uses the handle's nominal constants.  Outputs are row-major
+ * batches dfdx [n][nx][nx], dfdu [n][nx][nu].  disc_dt > 0 applies discretize_linear_system(exact=False)
+ * (controllers/mpc/mpc_utils.py:51-54, controllers/lqr/lqr_utils.py:39-60): Ad = I + A dt, Bd = B dt. */
+int scg_linearize(scg_handle* h, const float* state, const float* input, const float* inertial, float* dfdx,
+                  float* dfdu, double disc_dt, int64_t ld, int64_t n, void* stream);
+/* Quadratic stage cost and gradients (quadrotor.py:678-682, symbolic_systems.py:94-123):
+ * l = 1/2 ex'Q ex + 1/2 eu'R eu, l_x = 1/2 (Q + Q') ex, l_u = 1/2 (R + R') eu with ex = x - xr, eu = u - ur.
+ * Q [nx*nx] and R [nu*nu] are HOST row-major doubles.  xr is a device vector [nx] when xr_ld == 0, else planes
+ * [nx][xr_ld] (one reference per env); likewise ur.  Outputs (each nullable): l [n], l_x [nx][ld], l_u [nu][ld]. */
+int scg_quadratic_loss(scg_handle* h, const double* Q, const double* R, const float* state, const float* input,
+                       const float* xr, int64_t xr_ld, const float* ur, int64_t ur_ld, float* l, float* l_x,
+                       float* l_u, int64_t ld, int64_t n, void* stream);
+
 /* Introspection */
 int scg_num_constraints(const scg_handle* h);
 int scg_obs_dim(const scg_handle* h);

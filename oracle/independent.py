@@ -40,7 +40,7 @@ def _sym_quad3d():
     P = [m, g, l, Ixx, Iyy, Izz, gamma]
     Xdot = sp.Matrix([xd, acc[0], yd, acc[1], zd, acc[2], ang_dot[0], ang_dot[1], ang_dot[2],
                       rate_dot[0], rate_dot[1], rate_dot[2]])
-    return sp.lambdify([X, U, P], Xdot, 'numpy')
+    return X, U, P, Xdot
 
 
 def _sym_quad2d():
@@ -48,7 +48,7 @@ def _sym_quad2d():
     m, g, l, Iyy = sp.symbols('m g l Iyy')
     Xdot = sp.Matrix([xd, sp.sin(th) * (T1 + T2) / m, zd, sp.cos(th) * (T1 + T2) / m - g, thd,
                       l * (T2 - T1) / Iyy / sp.sqrt(2)])
-    return sp.lambdify([[x, xd, z, zd, th, thd], [T1, T2], [m, g, l, Iyy]], Xdot, 'numpy')
+    return [x, xd, z, zd, th, thd], [T1, T2], [m, g, l, Iyy], Xdot
 
 
 def _sym_cartpole():
@@ -73,15 +73,29 @@ def _sym_cartpole():
     X = sp.symbols('x xd th thd')
     rep = {xc.diff(t): X[1], th.diff(t): X[3], xc: X[0], th: X[2]}
     Xdot = sp.Matrix([X[1], sp.simplify(sol[xdd].subs(rep)), X[3], sp.simplify(sol[thdd].subs(rep))])
-    return sp.lambdify([list(X), [F], [l, m, M, g]], Xdot, 'numpy')
+    return list(X), [F], [l, m, M, g], Xdot
 
 
+def _sym_quad1d():
+    z, zd, T, m, g = sp.symbols('z zd T m g')
+    return [z, zd], [T], [m, g], sp.Matrix([zd, T / m - g])
+
+
+_SYM = {}
 _CACHE = {}
+
+
+def symbolic(system):
+    """(X, U, P, Xdot) sympy objects of one system (cached)."""
+    if system not in _SYM:
+        _SYM[system] = {3: _sym_quad3d, 2: _sym_quad2d, 1: _sym_quad1d, 'cartpole': _sym_cartpole}[system]()
+    return _SYM[system]
 
 
 def f_independent(system):
     if system not in _CACHE:
-        _CACHE[system] = {3: _sym_quad3d, 2: _sym_quad2d, 'cartpole': _sym_cartpole}[system]()
+        X, U, P, Xdot = symbolic(system)
+        _CACHE[system] = sp.lambdify([X, U, P], Xdot, 'numpy')
     return _CACHE[system]
 
 
@@ -90,6 +104,8 @@ def params_vector(system, p):
         return [p.m, p.g, p.l, p.ixx, p.iyy, p.izz, p.km / p.kf]
     if system == 2:
         return [p.m, p.g, p.l, p.iyy]
+    if system == 1:
+        return [p.m, p.g]
     return [p.l, p.m, p.M, p.g]
 
 

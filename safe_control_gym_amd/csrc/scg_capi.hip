@@ -483,6 +483,31 @@ int scg_normalize_advantages(float* adv, const double* stats, int32_t T, int64_t
     return SCG_OK;
 }
 
+int scg_linearize(scg_handle* h, const float* state, const float* input, const float* inertial, float* dfdx,
+                  float* dfdu, double disc_dt, int64_t ld, int64_t n, void* stream) {
+    if (!h) return fail(SCG_ERR_INVALID, "scg_linearize: null handle");
+    if (!state || !input || !dfdx || !dfdu) return fail(SCG_ERR_INVALID, "scg_linearize: null argument");
+    if (n < 0 || ld < n) return fail(SCG_ERR_INVALID, "scg_linearize: need 0 <= n <= ld");
+    if (n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_linearize: n > 2^30");
+    if (!(disc_dt >= 0.0)) return fail(SCG_ERR_INVALID, "scg_linearize: disc_dt must be >= 0");
+    HIP_TRY(launch_linearize(h->system, h->kp.ph, state, input, inertial, dfdx, dfdu, (float)disc_dt, ld, n,
+                             (hipStream_t)stream));
+    return SCG_OK;
+}
+
+int scg_quadratic_loss(scg_handle* h, const double* Q, const double* R, const float* state, const float* input,
+                       const float* xr, int64_t xr_ld, const float* ur, int64_t ur_ld, float* l, float* l_x,
+                       float* l_u, int64_t ld, int64_t n, void* stream) {
+    if (!h) return fail(SCG_ERR_INVALID, "scg_quadratic_loss: null handle");
+    if (!Q || !R || !state || !input || !xr || !ur) return fail(SCG_ERR_INVALID, "scg_quadratic_loss: null argument");
+    if (n < 0 || ld < n) return fail(SCG_ERR_INVALID, "scg_quadratic_loss: need 0 <= n <= ld");
+    if ((xr_ld != 0 && xr_ld < n) || (ur_ld != 0 && ur_ld < n))
+        return fail(SCG_ERR_INVALID, "scg_quadratic_loss: reference plane stride smaller than n");
+    if (n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_quadratic_loss: n > 2^30");
+    HIP_TRY(launch_loss(h->system, Q, R, state, input, xr, xr_ld, ur, ur_ld, l, l_x, l_u, ld, n, (hipStream_t)stream));
+    return SCG_OK;
+}
+
 int scg_num_constraints(const scg_handle* h) { return h ? h->n_con_rows : 0; }
 
 int scg_obs_dim(const scg_handle* h) { return h ? h->obs_dim : 0; }

@@ -138,6 +138,12 @@ hipError_t launch_gae(const float* rew, const float* val, const float* mask, con
                       const float* last_val, float* ret, float* adv, float* rew_out, double* stats, int T, int64_t n,
                       int64_t ld, float gamma, float lam, int use_gae, hipStream_t s);
 hipError_t launch_normalize(float* adv, const double* stats, int T, int64_t n, int64_t ld, float eps, hipStream_t s);
+hipError_t launch_linearize(int system, const PhysT<float>& ph, const float* state, const float* input,
+                            const float* inertial, float* dfdx, float* dfdu, float disc_dt, int64_t ld, int64_t n,
+                            hipStream_t s);
+hipError_t launch_loss(int system, const double* Q, const double* R, const float* state, const float* input,
+                       const float* xr, int64_t xr_ld, const float* ur, int64_t ur_ld, float* l, float* l_x, float* l_u,
+                       int64_t ld, int64_t n, hipStream_t s);
 hipError_t launch_eval_constraints(int system, const ConTable* ct, const float* state, const float* action,
                                    float* c_val, uint8_t* violation, int64_t ld, int64_t n, hipStream_t s);
 }  // namespace scg

@@ -1,0 +1,94 @@
+// Device-side helpers shared by the kernels of the rollout engine: system dimensions, 1-ulp hardware
+// reciprocal / sqrt, SGPR-based plane addressing and the fp32 sin/cos pair.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "scg_device.h"
+
+namespace scg {
+
+#ifndef SCG_NT
+#define SCG_NT 1               // nontemporal hint on the streamed planes: 0 none, 1 loads+stores (measured -5%), 2 stores only, 3 loads only
+#endif
+
+template <int SYS> struct Dim;
+template <> struct Dim<SCG_QUAD_1D> { static constexpr int NX = 2, NU = 1; };
+template <> struct Dim<SCG_QUAD_2D> { static constexpr int NX = 6, NU = 2; };
+template <> struct Dim<SCG_QUAD_3D> { static constexpr int NX = 12, NU = 4; };
+template <> struct Dim<SCG_CARTPOLE> { static constexpr int NX = 4, NU = 1; };
+
+// ------------------------------------------------------------------------------------------
+// math helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rcp_f(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32, 1 ulp
+__device__ __forceinline__ float sqrt_f(float x) { return __builtin_amdgcn_sqrtf(x); }    // v_sqrt_f32, 1 ulp
+// clamp as ONE v_med3_f32 (fminf(fmaxf()) costs two extra canonicalising v_max_f32 per call)
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+// make a wave-uniform 64-bit value opaque to CSE: the expression that uses it is re-evaluated on the
+// scalar unit at each use instead of being kept alive (and spilled) across the ~1200-instruction body
+__device__ __forceinline__ int64_t opaque_s(int64_t v) { asm volatile("" : "+s"(v)); return v; }
+
+// Plane access with a wave-uniform base and a 32-bit per-lane BYTE offset: lowers to the
+// `global_load_dword v, v_off, s[base:base+1]` (saddr) form -- one VGPR of address for every plane
+// instead of a 64-bit VGPR pair per plane.  n <= 2^30 (checked on the host) keeps 4*i in 32 bits.
+template <class T>
+__device__ __forceinline__ T* uptr(T* p) {       // pin a wave-uniform pointer into SGPRs
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    typedef __attribute__((address_space(1))) T* global_ptr;   // keep it a global (not flat) pointer
+    return (T*)(global_ptr)(((uint64_t)hi << 32) | lo);
+}
+template <class T>
+__device__ __forceinline__ T ldp(const T* base, uint32_t boff) {
+#if SCG_NT == 1 || SCG_NT == 3
+    return __builtin_nontemporal_load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + boff));
+#else
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + boff);
+#endif
+}
+template <class T>
+__device__ __forceinline__ void stp(T* base, uint32_t boff, T v) {
+#if SCG_NT == 1 || SCG_NT == 2
+    __builtin_nontemporal_store(v, reinterpret_cast<T*>(reinterpret_cast<char*>(base) + boff));
+#else
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + boff) = v;
+#endif
+}
+
+// sin and cos together.  Cody-Waite reduction by pi/2 (two fp32 pieces, each applied with one
+// exact-product FMA; the neglected third piece is 1.7e-15 per quadrant) followed by minimax
+// polynomials on [-pi/4, pi/4] fitted for this kernel (max abs error 9.3e-8 = 0.8 ulp(1) for
+// |x| <= 1000, measured against float64 sin/cos over 2e6 points: DESIGN.md section 5).
+// ~20 VALU ops for the pair instead of two libm calls with their slow-path range reduction.
+#ifndef SCG_FAST_TRIG
+#define SCG_FAST_TRIG 0        // 1: hardware v_sin_f32 / v_cos_f32 (tuning experiment; ~1e-6 abs error)
+#endif
+__device__ __forceinline__ void sincos_f(float x, float& s, float& c) {
+#if SCG_FAST_TRIG
+    const float rev = x * 0.15915494309189535f;                 // revolutions
+    s = __builtin_amdgcn_sinf(rev);
+    c = __builtin_amdgcn_cosf(rev);
+#else
+    const float kf = rintf(x * 0.636619772367581343f);          // x * 2/pi
+    const int k = (int)kf;
+    float r = fmaf(kf, -1.5707963705062866f, x);                // fl32(pi/2)
+    r = fmaf(kf, 4.371138828673793e-08f, r);                    // pi/2 - fl32(pi/2)
+    const float r2 = r * r;
+    // sin(r) = r + r^3 S(r2)
+    float ps = fmaf(r2, 2.716089966270374e-06f, -0.0001983909896807745f);
+    ps = fmaf(ps, r2, 0.008333329111337662f);
+    ps = fmaf(ps, r2, -0.1666666716337204f);
+    const float sr = fmaf(r * r2, ps, r);
+    // cos(r) = 1 - r2/2 + r2^2 C(r2)
+    float pc = fmaf(r2, 2.4417491658823565e-05f, -0.0013887188397347927f);
+    pc = fmaf(pc, r2, 0.04166664183139801f);
+    const float cr = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.0f));
+    const float ss = (k & 1) ? cr : sr;
+    const float cc = (k & 1) ? sr : cr;
+    s = (k & 2) ? -ss : ss;
+    c = ((k + 1) & 2) ? -cc : cc;
+#endif
+}
+
+}  // namespace scg

@@ -447,6 +447,79 @@ class BenchmarkEnv:
     def _raw_action_soa(self):
         return getattr(self, '_raw_action', None) if getattr(self, '_raw_action', None) is not None else self._bufs['action']
 
+    # -- batched prior-model queries ---------------------------------------
+    def _planes(self, t, dim, default=None):
+        """(planes [dim, ld'], ld') from [N, dim] rows (one transposing copy), [dim, ld'] planes (zero copy),
+        a [dim] vector (broadcast to every env) or None (-> ``default``)."""
+        n = self.num_envs
+        if t is None:
+            t = default
+        if isinstance(t, torch.Tensor) and t.ndim == 2 and t.shape[0] == dim and t.shape[1] >= n and t.shape != (n, dim) \
+                and t.dtype == torch.float32 and t.is_contiguous() and t.device == self._bufs['state'].device:
+            return t, t.shape[1]
+        a = torch.as_tensor(np.asarray(t, dtype=np.float32) if not isinstance(t, torch.Tensor) else t,
+                            dtype=torch.float32, device=self.device)
+        if a.ndim == 1:
+            a = a.reshape(1, dim).expand(n, dim)
+        if a.shape != (n, dim):
+            raise ValueError('[ERROR] expected (num_envs, %d) rows, (%d, ld) planes or a (%d,) vector, got %s'
+                             % (dim, dim, dim, tuple(a.shape)))
+        buf = torch.empty((dim, self._ld), dtype=torch.float32, device=self.device)
+        buf[:, :n] = a.T
+        return buf, self._ld
+
+    def linearize(self, state=None, input=None, discrete=False):
+        """Batched ``symbolic.df_func`` (symbolic_systems.py:77-92) on the device: Jacobians of the continuous
+        dynamics about each env's (state, input) -> ``(dfdx [N, nx, nx], dfdu [N, nx, nu])`` float32 tensors.
+
+        ``state`` defaults to the envs' current states (zero copy), ``input`` (model input u: thrusts / force,
+        i.e. the CLIPPED action) to ``U_EQ``.  ``discrete=True`` applies ``discretize_linear_system``
+        (mpc_utils.py:51-54): ``Ad = I + A dt``, ``Bd = B dt`` with ``dt = CTRL_TIMESTEP``.  Per-env inertial
+        properties are used when ``randomized_inertial_prop`` is on."""
+        self._ensure_engine()
+        xs, ldx = self._planes(state, self.state_dim, default=self._bufs['state'])
+        us, ldu = self._planes(input, self.action_dim, default=np.asarray(self.U_EQ, dtype=np.float64))
+        if ldx != ldu:                                     # bring both to the env's own plane stride
+            xs = self._planes(xs[:, :self.num_envs].T, self.state_dim)[0] if ldx != self._ld else xs
+            us = self._planes(us[:, :self.num_envs].T, self.action_dim)[0] if ldu != self._ld else us
+            ldx = self._ld
+        inertial = self._bufs.get('inertial') if ldx == self._ld else None
+        return self._engine.linearize(xs, us, inertial, self.num_envs, ldx,
+                                      self.CTRL_TIMESTEP if discrete else 0.0)
+
+    def quadratic_loss(self, state=None, input=None, x_ref=None, u_ref=None, Q=None, R=None, gradients=True):
+        """Batched ``symbolic.loss`` (quadrotor.py:678-682, symbolic_systems.py:94-123) on the device:
+        ``l [N]``, ``l_x [N, nx]``, ``l_u [N, nu]`` (+ the constant Hessians) for each env's (state, input).
+        ``x_ref`` / ``u_ref``: a vector for all envs (default ``X_GOAL`` row 0 / ``U_GOAL``) or [N, .] rows."""
+        self._ensure_engine()
+        n, nx, nu = self.num_envs, self.state_dim, self.action_dim
+        xs, ldx = self._planes(state, nx, default=self._bufs['state'])
+        us, ldu = self._planes(input, nu, default=np.asarray(self.U_EQ, dtype=np.float64))
+        if ldx != self._ld:
+            xs = self._planes(xs[:, :n].T, nx)[0]
+        if ldu != self._ld:
+            us = self._planes(us[:, :n].T, nu)[0]
+        def ref(v, dim, default):
+            v = default if v is None else v
+            v = v if isinstance(v, torch.Tensor) else np.asarray(v, dtype=np.float32)
+            if v.ndim == 1:
+                return torch.as_tensor(v, dtype=torch.float32, device=self.device).contiguous()
+            return self._planes(v, dim)[0]
+        xg = np.asarray(self.X_GOAL, dtype=np.float64)
+        xr = ref(x_ref, nx, xg if xg.ndim == 1 else xg[0])
+        ur = ref(u_ref, nu, np.asarray(self.U_GOAL, dtype=np.float64))
+        Q = np.asarray(self.Q if Q is None else Q, dtype=np.float64).reshape(nx, nx)
+        R = np.asarray(self.R if R is None else R, dtype=np.float64).reshape(nu, nu)
+        l, l_x, l_u = self._engine.quadratic_loss(xs, us, xr, ur, Q, R, n, self._ld, want_grad=gradients)
+        out = {'l': l[:n]}
+        if gradients:
+            f32 = dict(dtype=torch.float32, device=self.device)
+            out.update({'l_x': l_x[:, :n].T, 'l_u': l_u[:, :n].T,
+                        'l_xx': torch.as_tensor(0.5 * (Q + Q.T), **f32).expand(n, nx, nx),
+                        'l_uu': torch.as_tensor(0.5 * (R + R.T), **f32).expand(n, nu, nu),
+                        'l_xu': torch.zeros((1, 1, 1), **f32).expand(n, nx, nu)})
+        return out
+
     def rollout(self, actions, steps=None, fused=False):
         """Open-loop rollout: ``steps`` fused step launches issued from one C-ABI call (``scg_rollout``), or with
         ``fused=True`` ONE launch that keeps every env in registers for all the steps (``scg_rollout_fused``; same

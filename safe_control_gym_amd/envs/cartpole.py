@@ -20,6 +20,8 @@ Reward / done / constraint / time-limit logic is the shared ``BenchmarkEnv`` mac
 import math
 from copy import deepcopy
 
+import weakref
+
 import numpy as np
 
 from safe_control_gym_amd import _capi
@@ -89,6 +91,7 @@ class CartPole(BenchmarkEnv):
         self.INIT_STATE_RAND_INFO = {k: v for k, v in self.INIT_STATE_RAND_INFO.items() if k in self._LABELS}
         consts = dict(l=self.EFFECTIVE_POLE_LENGTH, m=self.POLE_MASS, M=self.CART_MASS, g=self.GRAVITY_ACC)
         self.symbolic = AnalyticModel('cartpole', consts, self.CTRL_TIMESTEP)
+        self.symbolic.device_backend = weakref.proxy(self)
         self.U_GOAL = np.zeros(1)
         ti = self.TASK_INFO
         if self.TASK == Task.STABILIZATION:

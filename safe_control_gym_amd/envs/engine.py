@@ -23,6 +23,8 @@ class Engine:
             raise _capi.ScgError('no ROCm device is visible to this process: the rollout engine cannot run '
                                  '(there is no CPU path)')
         self.cfg = cfg
+        self.nx, self.nu = {_capi.SCG_QUAD_1D: (2, 1), _capi.SCG_QUAD_2D: (6, 2), _capi.SCG_QUAD_3D: (12, 4),
+                            _capi.SCG_CARTPOLE: (4, 1)}[cfg.system]
         handle = C.c_void_p()
         with torch.cuda.device(self.device):
             _capi.check(self.lib.scg_create(C.byref(cfg), C.byref(handle)), 'scg_create')
@@ -120,6 +122,32 @@ class Engine:
                                                       _capi.ptr(action_soa), _capi.ptr(out), None, ld, n,
                                                       self._stream()), 'scg_eval_constraints')
         return out[:self.num_device_rows, :n].T
+
+    def linearize(self, state_soa, input_soa, inertial_soa, n, ld, disc_dt=0.0):
+        """Batched df_func (symbolic_systems.py:77-92): ([n, nx, nx], [n, nx, nu]) for SoA planes [.][ld]."""
+        A = torch.empty((n, self.nx, self.nx), dtype=torch.float32, device=self.device)
+        B = torch.empty((n, self.nx, self.nu), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _capi.check(self.lib.scg_linearize(self.handle, _capi.ptr(state_soa), _capi.ptr(input_soa),
+                                               _capi.ptr(inertial_soa), _capi.ptr(A), _capi.ptr(B), float(disc_dt),
+                                               ld, n, self._stream()), 'scg_linearize')
+        return A, B
+
+    def quadratic_loss(self, state_soa, input_soa, xr, ur, Q, R, n, ld, want_grad=True):
+        """Batched loss / l_x / l_u (symbolic_systems.py:94-123).  xr: [nx] vector or [nx, ld'] planes; ur likewise."""
+        Qh = (C.c_double * (self.nx * self.nx))(*[float(v) for v in Q.reshape(-1)])
+        Rh = (C.c_double * (self.nu * self.nu))(*[float(v) for v in R.reshape(-1)])
+        l = torch.empty(ld, dtype=torch.float32, device=self.device)
+        l_x = torch.empty((self.nx, ld), dtype=torch.float32, device=self.device) if want_grad else None
+        l_u = torch.empty((self.nu, ld), dtype=torch.float32, device=self.device) if want_grad else None
+        xr_ld = xr.shape[1] if xr.ndim == 2 else 0
+        ur_ld = ur.shape[1] if ur.ndim == 2 else 0
+        with torch.cuda.device(self.device):
+            _capi.check(self.lib.scg_quadratic_loss(self.handle, Qh, Rh, _capi.ptr(state_soa), _capi.ptr(input_soa),
+                                                    _capi.ptr(xr), xr_ld, _capi.ptr(ur), ur_ld, _capi.ptr(l),
+                                                    _capi.ptr(l_x), _capi.ptr(l_u), ld, n, self._stream()),
+                        'scg_quadratic_loss')
+        return l, l_x, l_u
 
     def kernel_info(self, n):
         b, g, l = C.c_int32(), C.c_int32(), C.c_int32()

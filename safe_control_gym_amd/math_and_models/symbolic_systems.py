@@ -61,6 +61,10 @@ def _cartpole(x, u, c, m):
     return [x[1], tmp - ml * thdd * co / Mm, thd, thdd]
 
 
+def _is_device_tensor(x):
+    return type(x).__module__.startswith('torch') and getattr(x, 'is_cuda', False)
+
+
 _F = {'quad1d': _quad1d, 'quad2d': _quad2d, 'quad3d': _quad3d, 'cartpole': _cartpole}
 _DIMS = {'quad1d': (2, 1), 'quad2d': (6, 2), 'quad3d': (12, 4), 'cartpole': (4, 1)}
 
@@ -76,6 +80,12 @@ class AnalyticModel:
         self.ny = self.nx
         self.integration_algo = 'rk4'
         self._jac = None
+        self.device_backend = None        # the env (weak proxy): torch device tensors go to its HIP kernels
+
+    def _backend(self):
+        if self.device_backend is None:
+            raise RuntimeError('[ERROR] device tensors need the env that owns this model (env.symbolic).')
+        return self.device_backend
 
     # -- dynamics ---------------------------------------------------------------------------
     def _f(self, x, u):
@@ -117,7 +127,11 @@ class AnalyticModel:
         self._jac = (sp.lambdify([X, U], F.jacobian(X), 'numpy'), sp.lambdify([X, U], F.jacobian(U), 'numpy'))
 
     def df_func(self, x, u):
-        """Jacobians of f: dfdx (..., nx, nx), dfdu (..., nx, nu)."""
+        """Jacobians of f: dfdx (..., nx, nx), dfdu (..., nx, nu).  Device tensors ([N, nx], [N, nu]) are
+        linearised by the batched HIP kernel (``env.linearize``); host arrays by the sympy closed forms."""
+        if _is_device_tensor(x):
+            A, B = self._backend().linearize(x, u)
+            return {'dfdx': A, 'dfdu': B}
         if self._jac is None:
             self._build_jacobians()
         x = np.asarray(x, dtype=np.float64)
@@ -130,6 +144,8 @@ class AnalyticModel:
 
     # -- cost: quadrotor.py:682, symbolic_systems.py:114-123 ------------------------------------
     def loss(self, x, u, Xr, Ur, Q, R):
+        if _is_device_tensor(x):
+            return self._backend().quadratic_loss(x, u, Xr, Ur, Q, R)
         x, u = np.asarray(x, dtype=np.float64), np.asarray(u, dtype=np.float64)
         ex = x - np.asarray(Xr, dtype=np.float64)
         eu = u - np.asarray(Ur, dtype=np.float64)

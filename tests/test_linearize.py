@@ -1,0 +1,272 @@
+"""batched prior-model queries (df_func Jacobians, discretisation, quadratic loss).
+
+CPU part: the oracle (sympy differentiation of the reference's matrix-form dynamics, oracle/ref_linearize.py)
+against derivation-free central differences of the scalar restatement and against analytic known answers.
+GPU part: the HIP kernels (hand-derived closed forms, csrc/scg_linearize.hip) against the oracle.
+The reference holds no golden vectors for these functions: the pins are the
+finite-difference cross-check and the hover / double-integrator known answers below.
+"""
+import numpy as np
+import pytest
+
+from oracle import ref_linearize, ref_model
+
+SYSTEMS = [1, 2, 3, 'cartpole']
+F = {1: ref_model.f_quad1d, 2: ref_model.f_quad2d, 3: ref_model.f_quad3d, 'cartpole': ref_model.f_cartpole}
+RTOL = 1e-5          # north_star: 1e-5 relative, fp32
+
+
+def params_of(system, inertial=None):
+    if system == 'cartpole':
+        return ref_model.CartPoleParams(*(inertial[:3] if inertial is not None else ()))
+    return ref_model.QuadParams(*(inertial if inertial is not None else ()))
+
+
+def sample(system, n, rng):
+    nx, nu = ref_model.NX[system], ref_model.NU[system]
+    x = rng.normal(size=(n, nx)) * 0.6
+    if system == 'cartpole':
+        u = rng.uniform(-10, 10, size=(n, nu))
+    else:
+        lo, hi = ref_model.action_bounds(nu)
+        u = rng.uniform(lo, hi, size=(n, nu))
+    return x, u
+
+
+@pytest.mark.parametrize('system', SYSTEMS)
+def test_oracle_jacobians_match_central_differences(system):
+    rng = np.random.default_rng(7)
+    p = params_of(system)
+    xs, us = sample(system, 8, rng)
+    nx, nu = xs.shape[1], us.shape[1]
+    eps = 1e-6
+    for x, u in zip(xs, us):
+        A, B = ref_linearize.df(system, x, u, p)
+        f = lambda a, b: np.asarray(F[system](a, b, p), dtype=np.float64)
+        An = np.stack([(f(x + eps * np.eye(nx)[j], u) - f(x - eps * np.eye(nx)[j], u)) / (2 * eps) for j in range(nx)], 1)
+        Bn = np.stack([(f(x, u + eps * np.eye(nu)[j]) - f(x, u - eps * np.eye(nu)[j])) / (2 * eps) for j in range(nu)], 1)
+        scale = max(1.0, np.abs(A).max())
+        assert np.abs(A - An).max() < 2e-7 * scale
+        assert np.abs(B - Bn).max() < 2e-7 * max(1.0, np.abs(B).max())
+
+
+def test_oracle_hover_known_answers():
+    """Level hover, u = m g / 4 each: d ax / d theta = g, d ay / d phi = -g, d az / d f_i = 1 / m, and the torque
+    rows are the mixer (quadrotor.py:667-669) divided by the inertias."""
+    p = params_of(3)
+    A, B = ref_linearize.df(3, np.zeros(12), np.full(4, p.m * p.g / 4), p)
+    assert A[1, 7] == pytest.approx(p.g, rel=1e-15) and A[3, 6] == pytest.approx(-p.g, rel=1e-15)
+    assert all(A[2 * k, 2 * k + 1] == 1.0 for k in range(3))
+    assert A[6, 9] == 1.0 and A[7, 10] == 1.0 and A[8, 11] == 1.0
+    expected_nonzero = {(0, 1), (2, 3), (4, 5), (1, 7), (3, 6), (6, 9), (7, 10), (8, 11)}
+    assert {(a, b) for a in range(12) for b in range(12) if A[a, b] != 0.0} == expected_nonzero
+    assert np.allclose(B[5], 1.0 / p.m, rtol=1e-15)
+    k = p.l / np.sqrt(2.0)
+    assert np.allclose(B[9], np.array([1, 1, -1, -1]) * k / p.ixx, rtol=1e-14)
+    assert np.allclose(B[10], np.array([-1, 1, 1, -1]) * k / p.iyy, rtol=1e-14)
+    assert np.allclose(B[11], np.array([1, -1, 1, -1]) * (p.km / p.kf) / p.izz, rtol=1e-14)
+
+
+def test_oracle_discretisation_known_answer():
+    """1-D quadrotor = double integrator: exact ZOH is Ad = [[1, dt], [0, 1]], Bd = [dt^2 / 2m, dt / m]; the
+    reference's default (exact=False, mpc_utils.py:51-54) is the Euler form I + A dt, B dt."""
+    p = params_of(1)
+    A, B = ref_linearize.df(1, [1.0, 0.2], [0.3], p)
+    dt = 1 / 60
+    Ad, Bd = ref_linearize.discretize_linear_system(A, B, dt, exact=True)
+    assert np.allclose(Ad, [[1, dt], [0, 1]], atol=1e-16) and np.allclose(Bd[:, 0], [dt * dt / 2 / p.m, dt / p.m], rtol=1e-13)
+    Ae, Be = ref_linearize.discretize_linear_system(A, B, dt)
+    assert np.array_equal(Ae, np.eye(2) + A * dt) and np.array_equal(Be, B * dt)
+
+
+def test_oracle_loss_gradients_match_differences():
+    rng = np.random.default_rng(3)
+    Q, R = rng.normal(size=(6, 6)), rng.normal(size=(2, 2))          # deliberately not symmetric
+    x, u, xr, ur = rng.normal(size=6), rng.normal(size=2), rng.normal(size=6), rng.normal(size=2)
+    out = ref_linearize.quadratic_loss(x, u, xr, ur, Q, R)
+    eps = 1e-6
+    gx = [(ref_linearize.quadratic_loss(x + eps * np.eye(6)[j], u, xr, ur, Q, R)['l']
+           - ref_linearize.quadratic_loss(x - eps * np.eye(6)[j], u, xr, ur, Q, R)['l']) / (2 * eps) for j in range(6)]
+    gu = [(ref_linearize.quadratic_loss(x, u + eps * np.eye(2)[j], xr, ur, Q, R)['l']
+           - ref_linearize.quadratic_loss(x, u - eps * np.eye(2)[j], xr, ur, Q, R)['l']) / (2 * eps) for j in range(2)]
+    assert np.allclose(out['l_x'], gx, atol=1e-8) and np.allclose(out['l_u'], gu, atol=1e-8)
+
+
+def test_host_model_matches_oracle():
+    """env.symbolic for host arrays (safe_control_gym_amd.math_and_models.symbolic_systems) vs the oracle."""
+    from safe_control_gym_amd.math_and_models.symbolic_systems import AnalyticModel
+    p = params_of(3)
+    consts = dict(m=p.m, g=p.g, l=p.l, Ixx=p.ixx, Iyy=p.iyy, Izz=p.izz, gamma=p.km / p.kf)
+    model = AnalyticModel('quad3d', consts, 1 / 60)
+    rng = np.random.default_rng(11)
+    xs, us = sample(3, 4, rng)
+    out = model.df_func(xs, us)
+    for k in range(4):
+        A, B = ref_linearize.df(3, xs[k], us[k], p)
+        assert np.allclose(out['dfdx'][k], A, rtol=1e-12, atol=1e-12) and np.allclose(out['dfdu'][k], B, rtol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------------
+# GPU: the HIP kernels against the oracle
+# ------------------------------------------------------------------------------------------------------
+def _make(system, n, **kw):
+    import safe_control_gym_amd as scg
+    if system == 'cartpole':
+        return scg.make('cartpole', num_envs=n, device='cuda', seed=1, **kw)
+    if system == 3:
+        kw.setdefault('task_info', {'stabilization_goal': [0.0, 0.0, 1.0], 'stabilization_goal_tolerance': 0.05})
+    return scg.make('quadrotor', quad_type=system, num_envs=n, device='cuda', seed=1, **kw)
+
+
+def _check(A_dev, B_dev, xs, us, system, params, disc_dt=0.0, idx=None):
+    idx = range(len(xs)) if idx is None else idx
+    worst = 0.0
+    for k in idx:
+        A, B = ref_linearize.df(system, xs[k], us[k], params[k] if isinstance(params, list) else params)
+        if disc_dt:
+            A, B = ref_linearize.discretize_linear_system(A, B, disc_dt)
+        for dev, ref in ((A_dev[k], A), (B_dev[k], B)):
+            # structural zeros are exact; everything else within 1e-5 of the entry (or of 1 for small entries)
+            assert np.array_equal(dev[ref == 0.0], ref[ref == 0.0]), (k, dev, ref)
+            err = np.abs(dev - ref) / np.maximum(np.abs(ref), 1.0)
+            worst = max(worst, err.max())
+    assert worst <= RTOL, worst
+    return worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('system', SYSTEMS)
+@pytest.mark.parametrize('n', [1, 63, 65, 1000])
+def test_linearize_kernel_matches_oracle(gpu, system, n):
+    import torch
+    env = _make(system, n)
+    env.reset()
+    rng = np.random.default_rng(100 + n)
+    xs, us = sample(system, n, rng)
+    A, B = env.linearize(torch.as_tensor(xs, dtype=torch.float32, device='cuda'),
+                         torch.as_tensor(us, dtype=torch.float32, device='cuda'))
+    assert A.shape == (n, xs.shape[1], xs.shape[1]) and B.shape == (n, xs.shape[1], us.shape[1])
+    x32, u32 = xs.astype(np.float32).astype(np.float64), us.astype(np.float32).astype(np.float64)
+    _check(A.cpu().numpy().astype(np.float64), B.cpu().numpy().astype(np.float64), x32, u32, system, params_of(system))
+    # discrete variant (discretize_linear_system, exact=False)
+    Ad, Bd = env.linearize(torch.as_tensor(xs, dtype=torch.float32, device='cuda'),
+                           torch.as_tensor(us, dtype=torch.float32, device='cuda'), discrete=True)
+    _check(Ad.cpu().numpy().astype(np.float64), Bd.cpu().numpy().astype(np.float64), x32, u32, system,
+           params_of(system), disc_dt=float(np.float32(env.CTRL_TIMESTEP)))
+    env.close()
+
+
+@pytest.mark.gpu
+def test_linearize_defaults_current_state_and_symbolic_api(gpu):
+    """env.linearize() about the envs' own states (zero copy) and U_EQ; env.symbolic.df_func on device tensors."""
+    import torch
+    n = 300
+    env = _make(3, n, randomized_init=True)
+    env.reset()
+    for _ in range(5):
+        env.step(torch.full((n, 4), 0.09, device='cuda'))
+    xs = env.state.cpu().numpy().astype(np.float64)
+    us = np.tile(np.asarray(env.U_EQ, dtype=np.float32).astype(np.float64), (n, 1))
+    A, B = env.linearize()
+    _check(A.cpu().numpy().astype(np.float64), B.cpu().numpy().astype(np.float64), xs, us, 3, params_of(3))
+    out = env.symbolic.df_func(env.state, torch.as_tensor(us, dtype=torch.float32, device='cuda'))
+    assert torch.equal(out['dfdx'], A) and torch.equal(out['dfdu'], B)
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('system', [3, 'cartpole'])
+def test_linearize_uses_per_env_inertial_properties(gpu, system):
+    import torch
+    n = 130
+    env = _make(system, n, randomized_inertial_prop=True)
+    env.reset()
+    prop = env.inertial_properties.cpu().numpy().astype(np.float64)          # [N, 4]
+    assert np.ptp(prop[:, 0]) > 0
+    rng = np.random.default_rng(5)
+    xs, us = sample(system, n, rng)
+    env.state[:] = torch.as_tensor(xs, dtype=torch.float32, device='cuda')
+    A, B = env.linearize(input=torch.as_tensor(us, dtype=torch.float32, device='cuda'))
+    params = [params_of(system, list(prop[k])) for k in range(n)]
+    _check(A.cpu().numpy().astype(np.float64), B.cpu().numpy().astype(np.float64),
+           xs.astype(np.float32).astype(np.float64), us.astype(np.float32).astype(np.float64), system, params)
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('system', SYSTEMS)
+def test_quadratic_loss_kernel_matches_oracle(gpu, system):
+    import torch
+    n = 257
+    env = _make(system, n, cost='quadratic')
+    env.reset()
+    rng = np.random.default_rng(9)
+    xs, us = sample(system, n, rng)
+    nx, nu = xs.shape[1], us.shape[1]
+    Q, R = rng.normal(size=(nx, nx)), rng.normal(size=(nu, nu))          # general (non-symmetric) weights
+    xr_rows, ur_vec = rng.normal(size=(n, nx)), rng.normal(size=nu)
+    t = lambda a: torch.as_tensor(a, dtype=torch.float32, device='cuda')
+    out = env.quadratic_loss(t(xs), t(us), x_ref=t(xr_rows), u_ref=ur_vec, Q=Q, R=R)
+    out2 = env.symbolic.loss(t(xs), t(us), t(xr_rows[0]), ur_vec, Q, R)      # CasADi-style call, one reference for all
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    Qf, Rf = f32(Q), f32(R)
+    for k in range(n):
+        ref = ref_linearize.quadratic_loss(f32(xs[k]), f32(us[k]), f32(xr_rows[k]), f32(ur_vec), Qf, Rf)
+        scale = max(1.0, abs(ref['l']))
+        assert abs(out['l'][k].item() - ref['l']) <= 2e-5 * scale          # sums of ~150 products with mixed signs
+        assert np.abs(out['l_x'][k].cpu().numpy() - ref['l_x']).max() <= 2e-5 * max(1.0, np.abs(ref['l_x']).max())
+        assert np.abs(out['l_u'][k].cpu().numpy() - ref['l_u']).max() <= 2e-5 * max(1.0, np.abs(ref['l_u']).max())
+        ref2 = ref_linearize.quadratic_loss(f32(xs[k]), f32(us[k]), f32(xr_rows[0]), f32(ur_vec), Qf, Rf)
+        assert abs(out2['l'][k].item() - ref2['l']) <= 2e-5 * max(1.0, abs(ref2['l']))
+    assert np.allclose(out['l_xx'][3].cpu().numpy(), 0.5 * (Qf + Qf.T), rtol=1e-6)
+    assert out['l_xu'].shape == (n, nx, nu) and out['l_uu'].shape == (n, nu, nu)
+    # the env's own reward under cost=quadratic is -l at the stabilisation goal with the env's Q, R (quadrotor.py:916-930)
+    env.close()
+
+
+@pytest.mark.gpu
+def test_linearize_full_size_properties(gpu):
+    """2^20 envs (BASELINE config C4 size): structure, finiteness, a sampled oracle comparison, and
+    Ad - I == dt * A (the discretisation is linear in A)."""
+    import torch
+    n = 1 << 20
+    env = _make(3, n, randomized_init=True)
+    env.reset()
+    A, B = env.linearize()
+    assert torch.isfinite(A).all() and torch.isfinite(B).all()
+    zero_mask = torch.ones(12, 12, dtype=torch.bool, device='cuda')
+    for a, b in [(0, 1), (2, 3), (4, 5), (1, 6), (1, 7), (1, 8), (3, 6), (3, 7), (3, 8), (5, 6), (5, 7), (6, 6), (6, 7),
+                 (6, 9), (6, 10), (6, 11), (7, 6), (7, 10), (7, 11), (8, 6), (8, 7), (8, 10), (8, 11), (9, 10), (9, 11),
+                 (10, 9), (10, 11), (11, 9), (11, 10)]:
+        zero_mask[a, b] = False
+    assert (A[:, zero_mask] == 0).all()
+    assert (A[:, 0, 1] == 1).all() and (A[:, 6, 9] == 1).all()
+    idx = np.random.default_rng(0).choice(n, 128, replace=False)
+    xs = env.state[torch.as_tensor(idx, device='cuda')].cpu().numpy().astype(np.float64)
+    us = np.tile(np.asarray(env.U_EQ, dtype=np.float32).astype(np.float64), (128, 1))
+    _check(A[torch.as_tensor(idx, device='cuda')].cpu().numpy().astype(np.float64),
+           B[torch.as_tensor(idx, device='cuda')].cpu().numpy().astype(np.float64), xs, us, 3, params_of(3))
+    Ad, Bd = env.linearize(discrete=True)
+    dt = np.float32(env.CTRL_TIMESTEP)
+    eye = torch.eye(12, device='cuda')
+    assert torch.allclose(Ad - eye, A * float(dt), rtol=1e-6, atol=1e-7) and torch.allclose(Bd, B * float(dt), rtol=1e-6)
+    env.close()
+
+
+@pytest.mark.gpu
+def test_linearize_c_abi_rejects_bad_arguments(gpu):
+    import torch
+    from safe_control_gym_amd import _capi
+    env = _make(2, 8)
+    env.reset()
+    eng, lib = env._engine, _capi.load()
+    A = torch.empty((8, 6, 6), device='cuda')
+    B = torch.empty((8, 6, 2), device='cuda')
+    p = _capi.ptr
+    st, ac = env._bufs['state'], env._bufs['action']
+    assert lib.scg_linearize(eng.handle, None, p(ac), None, p(A), p(B), 0.0, env._ld, 8, None) < 0
+    assert lib.scg_linearize(eng.handle, p(st), p(ac), None, p(A), p(B), -1.0, env._ld, 8, None) < 0
+    assert lib.scg_linearize(eng.handle, p(st), p(ac), None, p(A), p(B), 0.0, 4, 8, None) < 0          # ld < n
+    assert lib.scg_linearize(eng.handle, p(st), p(ac), None, p(A), p(B), 0.0, env._ld, 0, None) == 0   # empty batch
+    assert b'ld' in lib.scg_last_error() or lib.scg_last_error() is not None
+    env.close()
