@@ -157,69 +157,93 @@ __device__ __forceinline__ PhysT<float> phys_with(const PhysT<float>& shared, co
 // ------------------------------------------------------------------------------------------
 // wave-staged store of a [64 envs][ROWS x COLS] chunk of an [n][TOTAL_ROWS][COLS] batch
 // ------------------------------------------------------------------------------------------
-constexpr int kLinBlock = 256;
+#ifndef SCG_LIN_BLOCK
+#define SCG_LIN_BLOCK 256      // threads per workgroup
+#endif
+#ifndef SCG_LIN_EP3
+#define SCG_LIN_EP3 16         // 3-D: envs staged per pass (576-B records): LDS per wave = EP * 576 B
+#endif
+#ifndef SCG_LIN_NT
+#define SCG_LIN_NT 1           // nontemporal hint on the output stores
+#endif
+#ifndef SCG_LIN_MIN_WAVES
+#define SCG_LIN_MIN_WAVES 1    // waves per SIMD the register allocator must allow
+#endif
+constexpr int kLinBlock = SCG_LIN_BLOCK;
+template <class V>
+__device__ __forceinline__ void st_out(V v, V* dst) {
+#if SCG_LIN_NT
+    __builtin_nontemporal_store(v, dst);
+#else
+    *dst = v;
+#endif
+}
 typedef float vf4 __attribute__((ext_vector_type(4)));
 typedef float vf2 __attribute__((ext_vector_type(2)));
 
-// Copy rows [r0, r0 + RP) of every env of this wave out of registers into global memory through LDS.
-// vals: RP*COLS floats of this lane's env (row-major).  `lds` is this wave's private staging region
-// of 64 * RP * COLS floats.
-template <int RP, int COLS, int TOTAL_ROWS>
-__device__ __forceinline__ void stage_and_store(const float (&vals)[RP * COLS], float* lds, float* __restrict__ out,
-                                                uint32_t env0, int r0, uint32_t n, int lane) {
-    constexpr int CH = RP * COLS;                     // floats per env in this pass
-    constexpr int VW = (CH % 4 == 0) ? 4 : ((CH % 2 == 0) ? 2 : 1);
-    constexpr int UNITS = CH / VW;                    // vector units per env
-    constexpr int REC = TOTAL_ROWS * COLS;            // floats per env in the output batch
+// Copy the REC-float records of this wave's 64 envs out of registers into global memory through LDS, EP envs per
+// pass: the lanes of env group h write their records into the wave's staging region ([EP][REC], the layout of
+// the output batch itself), then all 64 lanes copy the region out as one contiguous run of EP * REC floats.
+// Only whole records keep every store on full 128-byte lines: staging row groups instead (segments of 96-288 B at
+// a 576 B stride) measured 1.3-3x slower.
+template <int REC, int EP>
+__device__ __forceinline__ void stage_and_store(const float (&vals)[REC], float* lds, float* __restrict__ out,
+                                                uint32_t env0, uint32_t n, int lane) {
+    constexpr int VW = (REC % 4 == 0) ? 4 : ((REC % 2 == 0) ? 2 : 1);
+    constexpr int UNITS = EP * REC / VW;              // vector units per pass
+    static_assert(64 % EP == 0, "EP must divide the wave");
 #pragma unroll
-    for (int k = 0; k < CH; k += VW) {
-        if constexpr (VW == 4) {
-            *reinterpret_cast<vf4*>(lds + lane * CH + k) = vf4{vals[k], vals[k + 1], vals[k + 2], vals[k + 3]};
-        } else if constexpr (VW == 2) {
-            *reinterpret_cast<vf2*>(lds + lane * CH + k) = vf2{vals[k], vals[k + 1]};
-        } else {
-            lds[lane * CH + k] = vals[k];
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // 64 * UNITS vector units, lane-contiguous: unit q belongs to env q / UNITS, offset (q % UNITS) * VW
+    for (int h = 0; h < 64 / EP; ++h) {
+        if (EP == 64 || (lane / EP) == h) {
+            float* mine = lds + (lane % EP) * REC;
 #pragma unroll
-    for (int t = 0; t < UNITS; ++t) {
-        const uint32_t q = (uint32_t)(t * 64 + lane);
-        const uint32_t e = q / (uint32_t)UNITS, w = q % (uint32_t)UNITS;
-        if (env0 + e < n) {
-            float* dst = out + (size_t)(env0 + e) * REC + r0 * COLS + w * VW;
-            const float* src = lds + e * CH + w * VW;
-            if constexpr (VW == 4) __builtin_nontemporal_store(*reinterpret_cast<const vf4*>(src), reinterpret_cast<vf4*>(dst));
-            else if constexpr (VW == 2) __builtin_nontemporal_store(*reinterpret_cast<const vf2*>(src), reinterpret_cast<vf2*>(dst));
-            else __builtin_nontemporal_store(*src, dst);
+            for (int k = 0; k < REC; k += VW) {
+                if constexpr (VW == 4) *reinterpret_cast<vf4*>(mine + k) = vf4{vals[k], vals[k + 1], vals[k + 2], vals[k + 3]};
+                else if constexpr (VW == 2) *reinterpret_cast<vf2*>(mine + k) = vf2{vals[k], vals[k + 1]};
+                else mine[k] = vals[k];
+            }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t first = env0 + (uint32_t)(h * EP);                         // first env of this pass
+        const uint32_t live = first < n ? (n - first < (uint32_t)EP ? n - first : (uint32_t)EP) : 0u;
+        const uint32_t limit = live * (uint32_t)(REC / VW);                       // units that belong to real envs
+        float* dst0 = out + (size_t)first * REC;
+#pragma unroll
+        for (int t = 0; t < (UNITS + 63) / 64; ++t) {
+            const uint32_t q = (uint32_t)(t * 64 + lane);
+            if (q < limit) {
+                if constexpr (VW == 4) st_out(*reinterpret_cast<const vf4*>(lds + q * 4), reinterpret_cast<vf4*>(dst0 + q * 4));
+                else if constexpr (VW == 2) st_out(*reinterpret_cast<const vf2*>(lds + q * 2), reinterpret_cast<vf2*>(dst0 + q * 2));
+                else st_out(lds[q], dst0 + q);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();              // the region is reused by the next pass
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();                  // the region is reused by the next pass
 }
 
-template <int SYS> struct LinTile;                    // rows of A staged per pass
-template <> struct LinTile<SCG_QUAD_1D> { static constexpr int RP = 2; };
-template <> struct LinTile<SCG_QUAD_2D> { static constexpr int RP = 6; };
-template <> struct LinTile<SCG_QUAD_3D> { static constexpr int RP = 4; };
-template <> struct LinTile<SCG_CARTPOLE> { static constexpr int RP = 4; };
-
+// envs staged per pass: the largest power of two whose records fit the wave's LDS budget
+constexpr int lin_ep(int rec, int budget_floats) {
+    int ep = 64;
+    while (ep > 1 && ep * rec > budget_floats) ep /= 2;
+    return ep;
+}
 template <int SYS>
 constexpr int lin_lds_floats_per_wave() {
-    constexpr int NX = Dim<SYS>::NX, NU = Dim<SYS>::NU, RP = LinTile<SYS>::RP;
-    return 64 * ((RP * NX > NX * NU) ? RP * NX : NX * NU);
+    constexpr int NX = Dim<SYS>::NX;
+    // 3-D: SCG_LIN_EP3 records of 144 floats; the small systems stage all 64 records at once
+    return (SYS == SCG_QUAD_3D ? SCG_LIN_EP3 : 64) * NX * NX;
 }
 
 template <int SYS, bool DIRECT>
-__global__ __launch_bounds__(kLinBlock) void scg_linearize_kernel(PhysT<float> shared, const float* __restrict__ state,
+__global__ __launch_bounds__(kLinBlock, SCG_LIN_MIN_WAVES) void scg_linearize_kernel(PhysT<float> shared, const float* __restrict__ state,
                                                                    const float* __restrict__ input,
                                                                    const float* __restrict__ inertial,
                                                                    float* __restrict__ dfdx, float* __restrict__ dfdu,
                                                                    float disc_dt, int64_t ld, uint32_t n) {
-    constexpr int NX = Dim<SYS>::NX, NU = Dim<SYS>::NU, RP = LinTile<SYS>::RP;
+    constexpr int NX = Dim<SYS>::NX, NU = Dim<SYS>::NU;
     extern __shared__ float lds_all[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* lds = lds_all + wave * lin_lds_floats_per_wave<SYS>();
@@ -264,23 +288,21 @@ __global__ __launch_bounds__(kLinBlock) void scg_linearize_kernel(PhysT<float> s
             }
         }
     } else {
+        constexpr int LW = lin_lds_floats_per_wave<SYS>();
+        float va[NX * NX];
 #pragma unroll
-        for (int r0 = 0; r0 < NX; r0 += RP) {
-            float vals[RP * NX];
+        for (int a = 0; a < NX; ++a) {
 #pragma unroll
-            for (int a = 0; a < RP; ++a) {
-#pragma unroll
-                for (int b = 0; b < NX; ++b) vals[a * NX + b] = A[r0 + a][b];
-            }
-            stage_and_store<RP, NX, NX>(vals, lds, dfdx, env0, r0, n, lane);
+            for (int b = 0; b < NX; ++b) va[a * NX + b] = A[a][b];
         }
+        stage_and_store<NX * NX, lin_ep(NX * NX, LW)>(va, lds, dfdx, env0, n, lane);
         float vb[NX * NU];
 #pragma unroll
         for (int a = 0; a < NX; ++a) {
 #pragma unroll
             for (int b = 0; b < NU; ++b) vb[a * NU + b] = B[a][b];
         }
-        stage_and_store<NX, NU, NX>(vb, lds, dfdu, env0, 0, n, lane);
+        stage_and_store<NX * NU, lin_ep(NX * NU, LW)>(vb, lds, dfdu, env0, n, lane);
     }
 }
 
