@@ -27,13 +27,14 @@
 extern "C" {
 #endif
 
-#define SCG_ABI_VERSION 2
+#define SCG_ABI_VERSION 3
 #define SCG_MAX_NX 12        /* quadrotor.py:625  (3-D: nx = 12) */
 #define SCG_MAX_NU 4         /* quadrotor.py:625  (3-D: nu = 4)  */
 #define SCG_MAX_NV 16        /* constrained variable: [state ; raw action], constraints.py:58-63 */
 #define SCG_MAX_CONSTRAINT_ROWS 64
 #define SCG_MAX_QUADRATIC 4
 #define SCG_MAX_GOAL_HORIZON 8
+#define SCG_MAX_DISTURBANCES 4       /* per disturbance mode */
 
 typedef enum scg_status {
     SCG_OK = 0,
@@ -143,6 +144,8 @@ typedef struct scg_step_io {
     int32_t* step_count;             /* [n] ctrl_step_counter */
     float* ep_return;                /* nullable [n] running episode return (record_episode_statistics.py:145) */
     int32_t* ep_length;              /* nullable [n] */
+    uint32_t* episode_id;            /* nullable [n] serial of the reset that began the env's episode; needed only
+                                        when a disturbance draws its step_offset per episode */
     /* out */
     float* obs;                      /* nullable [obs_dim][ld]; NULL when obs aliases state */
     float* reward;                   /* [n] */
@@ -162,6 +165,28 @@ typedef struct scg_step_io {
     uint32_t reserved1;
 } scg_step_io;
 
+/* One entry of a DisturbanceList (envs/disturbances.py:46-84), evaluated inside the step kernel.
+ * mode: where it is added -- SCG_DIST_ACTION: on the clipped thrusts before the motor map (quadrotor.py:835-836,
+ * dim nu); SCG_DIST_DYNAMICS: external force on the CoM (quadrotor.py:526-548; dim 1: z (quadrotor) / cart force
+ * (cartpole), 2: (x, z), 3: (x, y, z)); SCG_DIST_OBSERVATION: on the observed state (quadrotor.py:879-880, dim nx).
+ * kind: ImpulseDisturbance (:89-143), StepDisturbance (:146-184), UniformNoise (:186-212), WhiteNoise (:215-248),
+ * PeriodicNoise (:260-288).  Random draws are Philox4x32-10 streams keyed like the reset draws (seed; env index,
+ * step serial), one stream per (mode, entry): the reference draws from env.np_random (MT19937) instead. */
+enum { SCG_DIST_ACTION = 0, SCG_DIST_DYNAMICS = 1, SCG_DIST_OBSERVATION = 2 };
+enum { SCG_DIST_IMPULSE = 0, SCG_DIST_STEP = 1, SCG_DIST_UNIFORM = 2, SCG_DIST_WHITE_NOISE = 3, SCG_DIST_PERIODIC = 4 };
+typedef struct scg_disturbance {
+    int32_t mode, kind;
+    int32_t step_offset;             /* impulse / step: >= 0 fixed; -1: drawn per episode in [0, max_step) (:128-131) */
+    int32_t max_step;                /* int(EPISODE_LEN_SEC / CTRL_TIMESTEP) (:116) */
+    int32_t duration;                /* impulse (:119-122) */
+    int32_t has_mask;
+    double magnitude, decay_rate;    /* impulse / step */
+    double scale, frequency;         /* periodic: scale sin(2 pi frequency t + phase), t = ctrl step * CTRL_TIMESTEP */
+    double low[SCG_MAX_NX];          /* uniform: lower bounds; white_noise: std */
+    double high[SCG_MAX_NX];         /* uniform: upper bounds */
+    double mask[SCG_MAX_NX];         /* multiplies the noise when has_mask (:139-140) */
+} scg_disturbance;
+
 /* Replaces Quadrotor.__init__ (quadrotor.py:148) for a batch: copies constants to the device. */
 int scg_create(const scg_config* cfg, scg_handle** out);
 int scg_destroy(scg_handle* h);
@@ -178,11 +203,16 @@ int scg_set_constraints(scg_handle* h, const scg_constraint_row* rows, int32_t n
  * (record_episode_statistics.py:132-140) for the lanes where mask != 0 (all lanes if mask NULL).
  * Writes state (nominal + Philox uniform offsets) and, if inertial != NULL, the per-env inertial
  * properties (nominal, + Philox offsets when cfg.randomized_inertial); zeroes step_count / ep_return / ep_length, and
- * if obs != NULL the extended observation; if c_val != NULL the state-only constraint values are
+ * if obs != NULL the extended observation (+ the observation disturbances, quadrotor.py:879-880 via :497), if
+ * episode_id != NULL the episode id (= reset_serial); if c_val != NULL the state-only constraint values are
  * NOT produced here (reset-time only_state values come from scg_eval_constraints). */
 int scg_reset(scg_handle* h, float* state, float* state_lo, int32_t* step_count, float* ep_return,
               int32_t* ep_length, float* obs, const uint8_t* mask, const float* reset_state, float* inertial,
-              uint32_t reset_serial, int64_t ld, int64_t n, void* stream);
+              uint32_t* episode_id, uint32_t reset_serial, int64_t ld, int64_t n, void* stream);
+
+/* Passive disturbances (benchmark_env.py _setup_disturbances; yaml key `disturbances`): host pointer, at most
+ * SCG_MAX_DISTURBANCES entries per mode, applied in list order.  n = 0 clears them. */
+int scg_set_disturbances(scg_handle* h, const scg_disturbance* entries, int32_t n);
 
 /* Replaces Quadrotor.step (quadrotor.py:507-558) + BenchmarkEnv.after_step
  * (benchmark_env.py:422-463) + the DummyVecEnv auto-reset (dummy_vec_env.py:34-49) +
@@ -252,6 +282,7 @@ int scg_version(void);
 int scg_sizeof_config(void);
 int scg_sizeof_step_io(void);
 int scg_sizeof_constraint_row(void);
+int scg_sizeof_disturbance(void);
 
 #ifdef __cplusplus
 }

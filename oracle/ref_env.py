@@ -202,6 +202,7 @@ class RefEnv:
         self.action_disturbance = None      # (nu,) added after clip, before motor map (quadrotor.py:835-838)
         self.dynamics_force = None          # world-frame (3,) force (quadrotor.py:526-548)
         self.obs_noise = None               # (nx,) added to obs (quadrotor.py:879-880)
+        self.disturbance_model = None       # oracle.ref_disturbances.RefDisturbanceModel: fills the three hooks
 
     # ------------------------------------------------------------------ spaces
     def _set_action_space(self):
@@ -267,6 +268,8 @@ class RefEnv:
                 if label in self.INIT_STATE_RAND_INFO:
                     init[j] += offs[j]
         self.state = init
+        if self.disturbance_model is not None:
+            self.disturbance_model.on_reset(self)
         obs = self._get_observation()
         info = {'x_reference': self.X_GOAL, 'u_reference': self.U_GOAL}
         if self.constraints is not None:                        # benchmark_env.py:381-382
@@ -275,6 +278,8 @@ class RefEnv:
 
     # ------------------------------------------------------------------ step
     def step(self, action):
+        if self.disturbance_model is not None:
+            self.disturbance_model.on_step(self)
         thrust = self.before_step(action)
         fext = (0.0, 0.0, 0.0)
         if self.dynamics_force is not None:

@@ -128,12 +128,13 @@ class CartPoleParams:
 
 def f_cartpole(x, u, p, fext=(0.0, 0.0, 0.0)):
     """Textbook (Barto/Florian) cart-pole, state (x, x_dot, theta, theta_dot), input force F.
-    Parity unpinned: there is no CartPole env in /root/reference."""
+    Parity unpinned: there is no CartPole env in /root/reference.
+    An external (disturbance) force fext[0] acts on the cart along x, next to the input force."""
     x_dot, theta, theta_dot = x[1], x[2], x[3]
     Mm = p.m + p.M
     ml = p.m * p.l
     s, c = math.sin(theta), math.cos(theta)
-    tmp = (u[0] + ml * theta_dot * theta_dot * s) / Mm
+    tmp = (u[0] + fext[0] + ml * theta_dot * theta_dot * s) / Mm
     theta_dd = (p.g * s - c * tmp) / (p.l * (4.0 / 3.0 - p.m * c * c / Mm))
     x_dd = tmp - ml * theta_dd * c / Mm
     return [x_dot, x_dd, theta_dot, theta_dd]

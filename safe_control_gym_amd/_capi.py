@@ -7,18 +7,21 @@ module raises.  Struct layouts mirror the header field for field; ``load()`` cro
 import ctypes as C
 import os
 
-SCG_ABI_VERSION = 2
+SCG_ABI_VERSION = 3
 SCG_MAX_NX = 12
 SCG_MAX_NU = 4
 SCG_MAX_NV = 16
 SCG_MAX_CONSTRAINT_ROWS = 64
 SCG_MAX_QUADRATIC = 4
 SCG_MAX_GOAL_HORIZON = 8
+SCG_MAX_DISTURBANCES = 4
 
 SCG_QUAD_1D, SCG_QUAD_2D, SCG_QUAD_3D, SCG_CARTPOLE = 1, 2, 3, 4
 SCG_RK4, SCG_EULER = 0, 1
 SCG_STABILIZATION, SCG_TRAJ_TRACKING = 0, 1
 SCG_RL_REWARD, SCG_QUADRATIC = 0, 1
+SCG_DIST_ACTION, SCG_DIST_DYNAMICS, SCG_DIST_OBSERVATION = 0, 1, 2
+SCG_DIST_IMPULSE, SCG_DIST_STEP, SCG_DIST_UNIFORM, SCG_DIST_WHITE_NOISE, SCG_DIST_PERIODIC = 0, 1, 2, 3, 4
 
 _dbl = C.c_double
 _i32 = C.c_int32
@@ -75,6 +78,7 @@ class ScgStepIO(C.Structure):
         ('action', _fp), ('action_disturbance', _fp), ('dynamics_force', _fp), ('obs_noise', _fp),
         ('reset_state', _fp),
         ('inertial', _fp), ('state', _fp), ('state_lo', _fp), ('step_count', _fp), ('ep_return', _fp), ('ep_length', _fp),
+        ('episode_id', _fp),
         ('obs', _fp), ('reward', _fp), ('done', _fp), ('constraint_values', _fp),
         ('constraint_violation', _fp), ('truncated', _fp), ('goal_reached', _fp), ('mse', _fp),
         ('terminal_obs', _fp), ('last_ep_return', _fp), ('last_ep_length', _fp), ('stats', _fp),
@@ -82,10 +86,18 @@ class ScgStepIO(C.Structure):
     ]
 
 
+class ScgDisturbance(C.Structure):
+    _fields_ = [
+        ('mode', _i32), ('kind', _i32), ('step_offset', _i32), ('max_step', _i32), ('duration', _i32), ('has_mask', _i32),
+        ('magnitude', _dbl), ('decay_rate', _dbl), ('scale', _dbl), ('frequency', _dbl),
+        ('low', _dbl * SCG_MAX_NX), ('high', _dbl * SCG_MAX_NX), ('mask', _dbl * SCG_MAX_NX),
+    ]
+
+
 EXPORTS = (
-    'scg_create', 'scg_destroy', 'scg_set_reference', 'scg_set_constraints', 'scg_reset', 'scg_step', 'scg_rollout', 'scg_rollout_fused',
+    'scg_create', 'scg_destroy', 'scg_set_reference', 'scg_set_constraints', 'scg_set_disturbances', 'scg_reset', 'scg_step', 'scg_rollout', 'scg_rollout_fused',
     'scg_eval_constraints', 'scg_gae', 'scg_normalize_advantages', 'scg_linearize', 'scg_quadratic_loss', 'scg_num_constraints', 'scg_obs_dim', 'scg_kernel_info', 'scg_last_error',
-    'scg_version', 'scg_sizeof_config', 'scg_sizeof_step_io', 'scg_sizeof_constraint_row',
+    'scg_version', 'scg_sizeof_config', 'scg_sizeof_step_io', 'scg_sizeof_constraint_row', 'scg_sizeof_disturbance',
 )
 
 
@@ -126,7 +138,8 @@ def load():
     lib.scg_destroy.argtypes = [C.c_void_p]
     lib.scg_set_reference.argtypes = [C.c_void_p, C.POINTER(_dbl), _i32]
     lib.scg_set_constraints.argtypes = [C.c_void_p, C.POINTER(ScgConstraintRow), _i32, C.POINTER(_dbl), _i32]
-    lib.scg_reset.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_uint32, C.c_int64,
+    lib.scg_set_disturbances.argtypes = [C.c_void_p, C.POINTER(ScgDisturbance), _i32]
+    lib.scg_reset.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_uint32, C.c_int64,
                               C.c_int64, C.c_void_p]
     lib.scg_step.argtypes = [C.c_void_p, C.POINTER(ScgStepIO), C.c_int64, C.c_void_p]
     lib.scg_rollout.argtypes = [C.c_void_p, C.POINTER(ScgStepIO), C.c_int64, _i32, C.c_int64, _i32, C.c_void_p]
@@ -146,7 +159,7 @@ def load():
     if lib.scg_version() != SCG_ABI_VERSION:
         raise ScgError('libscg_rollout.so ABI %d != binding ABI %d' % (lib.scg_version(), SCG_ABI_VERSION))
     for struct, fn in ((ScgConfig, lib.scg_sizeof_config), (ScgStepIO, lib.scg_sizeof_step_io),
-                       (ScgConstraintRow, lib.scg_sizeof_constraint_row)):
+                       (ScgConstraintRow, lib.scg_sizeof_constraint_row), (ScgDisturbance, lib.scg_sizeof_disturbance)):
         if C.sizeof(struct) != fn():
             raise ScgError('%s layout mismatch: ctypes %d bytes, library %d bytes'
                            % (struct.__name__, C.sizeof(struct), fn()))

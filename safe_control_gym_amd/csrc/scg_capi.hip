@@ -23,6 +23,9 @@ struct scg_handle {
     int max_lds_bytes;
     ConTable* d_con;       // device
     KTables* d_tb;         // device
+    DistTable* d_dist;     // device, null without passive disturbances
+    bool dist_needs_episode;   // some entry draws its step_offset per episode
+    bool dist_obs;             // observation-mode entries exist
     PhysT<double> phd;
     float* d_ref;          // device, [rows][nx]
     int ref_rows;
@@ -196,6 +199,7 @@ const char* scg_last_error(void) { return g_err; }
 int scg_sizeof_config(void) { return (int)sizeof(scg_config); }
 int scg_sizeof_step_io(void) { return (int)sizeof(scg_step_io); }
 int scg_sizeof_constraint_row(void) { return (int)sizeof(scg_constraint_row); }
+int scg_sizeof_disturbance(void) { return (int)sizeof(scg_disturbance); }
 
 int scg_create(const scg_config* cfg, scg_handle** out) {
     if (!cfg || !out) return fail(SCG_ERR_INVALID, "scg_create: null argument");
@@ -277,7 +281,73 @@ int scg_destroy(scg_handle* h) {
     if (h->d_con) (void)hipFree(h->d_con);
     if (h->d_tb) (void)hipFree(h->d_tb);
     if (h->d_ref) (void)hipFree(h->d_ref);
+    if (h->d_dist) (void)hipFree(h->d_dist);
     delete h;
+    return SCG_OK;
+}
+
+int scg_set_disturbances(scg_handle* h, const scg_disturbance* entries, int32_t n) {
+    if (!h) return fail(SCG_ERR_INVALID, "scg_set_disturbances: null handle");
+    if (n < 0 || (n > 0 && !entries)) return fail(SCG_ERR_INVALID, "scg_set_disturbances: bad entry list");
+    DistTable t;
+    std::memset(&t, 0, sizeof(t));
+    bool needs_episode = false;
+    const int dyn_dim = h->system == SCG_QUAD_3D ? 3 : (h->system == SCG_QUAD_2D ? 2 : 1);
+    const int dims[3] = {h->nu, dyn_dim, h->nx};
+    for (int32_t k = 0; k < n; ++k) {
+        const scg_disturbance& s = entries[k];
+        if (s.mode < 0 || s.mode > 2) return fail(SCG_ERR_INVALID, "scg_set_disturbances: entry %d: mode %d", k, s.mode);
+        if (s.kind < SCG_DIST_IMPULSE || s.kind > SCG_DIST_PERIODIC)
+            return fail(SCG_ERR_INVALID, "scg_set_disturbances: entry %d: kind %d", k, s.kind);
+        if (t.n[s.mode] >= SCG_MAX_DISTURBANCES)
+            return fail(SCG_ERR_INVALID, "scg_set_disturbances: more than %d entries for mode %d", SCG_MAX_DISTURBANCES, s.mode);
+        DistEntry& d = t.e[s.mode][t.n[s.mode]++];
+        d.kind = s.kind;
+        const int dim = dims[s.mode];
+        for (int j = 0; j < SCG_MAX_NX; ++j) d.mask[j] = (j < dim) ? (s.has_mask ? (float)s.mask[j] : 1.0f) : 0.0f;
+        if (s.kind == SCG_DIST_IMPULSE || s.kind == SCG_DIST_STEP) {
+            if (s.step_offset < 0 && s.max_step < 1)
+                return fail(SCG_ERR_INVALID, "scg_set_disturbances: entry %d: random step_offset needs max_step >= 1", k);
+            d.step_offset = s.step_offset < 0 ? -1 : s.step_offset;
+            d.max_step = s.max_step;
+            d.magnitude = (float)s.magnitude;
+            if (s.step_offset < 0) needs_episode = true;
+            if (s.kind == SCG_DIST_IMPULSE) {
+                // disturbances.py:119-120: duration >= 1, 0 < decay_rate <= 1
+                if (s.duration < 1 || !(s.decay_rate > 0.0 && s.decay_rate <= 1.0))
+                    return fail(SCG_ERR_INVALID, "scg_set_disturbances: entry %d: impulse needs duration >= 1 and 0 < decay_rate <= 1", k);
+                d.duration = s.duration;
+                d.half_duration = (float)(s.duration / 2.0);
+                d.log2_decay = (float)std::log2(s.decay_rate);
+            }
+        } else if (s.kind == SCG_DIST_UNIFORM) {
+            for (int j = 0; j < dim; ++j) { d.a[j] = (float)s.low[j]; d.b[j] = (float)(s.high[j] - s.low[j]); }
+        } else if (s.kind == SCG_DIST_WHITE_NOISE) {
+            for (int j = 0; j < dim; ++j) d.a[j] = (float)s.low[j];
+        } else {
+            d.scale = (float)s.scale;
+            d.omega_dt = (float)(2.0 * M_PI * s.frequency * h->cfg.dt);
+        }
+    }
+    if (h->d_dist) { (void)hipFree(h->d_dist); h->d_dist = nullptr; }
+    h->kp.dist = nullptr;
+    h->dist_needs_episode = false;
+    h->dist_obs = false;
+    if (n == 0) return SCG_OK;
+    HIP_TRY(hipMalloc(&h->d_dist, sizeof(DistTable)));
+    HIP_TRY(hipMemcpy(h->d_dist, &t, sizeof(DistTable), hipMemcpyHostToDevice));
+    h->kp.dist = h->d_dist;
+    h->dist_needs_episode = needs_episode;
+    h->dist_obs = t.n[SCG_DIST_OBSERVATION] > 0;
+    return SCG_OK;
+}
+
+// buffers the attached disturbances need (shared by scg_step / scg_rollout / scg_rollout_fused)
+static int check_dist_io(const scg_handle* h, const scg_step_io* io, const char* who) {
+    if (h->dist_obs && !io->obs)
+        return fail(SCG_ERR_INVALID, "%s: an observation disturbance needs an obs buffer (obs must not alias state)", who);
+    if (h->dist_needs_episode && !io->episode_id)
+        return fail(SCG_ERR_INVALID, "%s: a per-episode step_offset needs the episode_id plane", who);
     return SCG_OK;
 }
 
@@ -388,15 +458,17 @@ int scg_set_constraints(scg_handle* h, const scg_constraint_row* rows, int32_t n
 
 int scg_reset(scg_handle* h, float* state, float* state_lo, int32_t* step_count, float* ep_return,
               int32_t* ep_length, float* obs, const uint8_t* mask, const float* reset_state, float* inertial,
-              uint32_t reset_serial, int64_t ld, int64_t n, void* stream) {
+              uint32_t* episode_id, uint32_t reset_serial, int64_t ld, int64_t n, void* stream) {
     if (!h || !state || !step_count) return fail(SCG_ERR_INVALID, "scg_reset: null argument");
     if (n < 0 || ld < n) return fail(SCG_ERR_INVALID, "scg_reset: need 0 <= n <= ld (n=%lld ld=%lld)", (long long)n, (long long)ld);
     if (n == 0) return SCG_OK;
     if (n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_reset: n > 2^30 envs per device (32-bit lane offsets)");
     if ((h->kp.flags & F_TRACKING) && h->kp.obs_goal_horizon > 0 && obs && !h->d_ref)
         return fail(SCG_ERR_INVALID, "scg_reset: traj_tracking needs scg_set_reference() first");
+    if (h->dist_needs_episode && !episode_id)
+        return fail(SCG_ERR_INVALID, "scg_reset: a per-episode step_offset needs the episode_id plane");
     HIP_TRY(launch_reset(h->system, h->kp, h->d_tb, state, state_lo, step_count, ep_return, ep_length, obs, mask,
-                         reset_state, inertial, h->d_ref, reset_serial, ld, n, (hipStream_t)stream));
+                         reset_state, inertial, episode_id, h->d_ref, reset_serial, ld, n, (hipStream_t)stream));
     return SCG_OK;
 }
 
@@ -413,6 +485,7 @@ int scg_step(scg_handle* h, const scg_step_io* io, int64_t n, void* stream) {
         return fail(SCG_ERR_INVALID, "scg_step: obs_goal_horizon > 0 needs an obs buffer (obs does not alias state)");
     if (io->obs_noise && !io->obs)
         return fail(SCG_ERR_INVALID, "scg_step: obs_noise needs an obs buffer");
+    if (int rc = check_dist_io(h, io, "scg_step")) return rc;
     if (n == 0) return SCG_OK;
     if (n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_step: n > 2^30 envs per device (32-bit lane offsets)");
     HIP_TRY(launch_step(h->system, h->kp, *io, h->d_tb, h->d_con, h->d_ref, n, h->num_cus, (hipStream_t)stream));

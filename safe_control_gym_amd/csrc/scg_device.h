@@ -46,6 +46,8 @@ struct PhysT {
     T cp_l, cp_m, cp_inv_Mm, cp_ml, cp_g;
 };
 
+struct DistTable;
+
 // Scalars: travel in the kernarg block (SGPRs).
 struct KParams {
     uint32_t flags;
@@ -62,6 +64,7 @@ struct KParams {
     float goal_tol2;
     float constraint_penalty;
     float cost_scale;           // -1 (rl_reward: rew = -dist) or -0.5 (quadratic: rew = -l/2 ... see w_state)
+    const DistTable* dist;   // device; null when the env has no passive disturbances
 };
 
 // Per-dimension constant vectors: live in device memory, read through a wave-uniform pointer with
@@ -115,6 +118,19 @@ struct ConTable {
     QuadRow quad[SCG_MAX_QUADRATIC];
 };
 
+// Compiled DisturbanceList entries (scg_set_disturbances), grouped by mode.
+struct DistEntry {
+    int32_t kind, step_offset, max_step, duration;
+    float magnitude, log2_decay, half_duration;
+    float scale, omega_dt;                      // periodic: 2 pi frequency * CTRL_TIMESTEP
+    float a[SCG_MAX_NX], b[SCG_MAX_NX];         // uniform: low, high - low; white_noise: std, -
+    float mask[SCG_MAX_NX];                     // 1 when the entry has no mask
+};
+struct DistTable {
+    int32_t n[3];
+    DistEntry e[3][SCG_MAX_DISTURBANCES];
+};
+
 struct LaunchGeom {
     int32_t block, grid, lds_bytes;
 };
@@ -132,8 +148,8 @@ hipError_t launch_rollout_fused(int system, const KParams& p, const scg_step_io&
                                 int32_t period, int num_cus, hipStream_t s);
 hipError_t launch_reset(int system, const KParams& p, const KTables* tb, float* state, float* state_lo,
                         int32_t* step_count, float* ep_return, int32_t* ep_length, float* obs, const uint8_t* mask,
-                        const float* reset_state, float* inertial, const float* ref, uint32_t reset_serial, int64_t ld,
-                        int64_t n, hipStream_t s);
+                        const float* reset_state, float* inertial, uint32_t* episode_id, const float* ref,
+                        uint32_t reset_serial, int64_t ld, int64_t n, hipStream_t s);
 hipError_t launch_gae(const float* rew, const float* val, const float* mask, const float* term_val,
                       const float* last_val, float* ret, float* adv, float* rew_out, double* stats, int T, int64_t n,
                       int64_t ld, float gamma, float lam, int use_gae, hipStream_t s);

@@ -58,6 +58,83 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// ---- passive disturbances (envs/disturbances.py:89-288), evaluated in registers --------------------------------
+// One Philox stream per (stream, mode, entry): counter = (env index lo, hi, step serial, word3) with
+// word3 = 16 + ((stream * 3 + mode) * SCG_MAX_DISTURBANCES + entry) * 4 + block (the reset draws use words 0..2
+// and 15).  stream 0: draws of step(); stream 1: the observation returned by a reset.  A per-episode step_offset
+// (np_random.randint(max_step), :128-131,168-171) is word 0 of counter (env, episode id, 128 + mode * MAX + entry)
+// scaled to [0, max_step).  `t` is ctrl_step_counter BEFORE its increment, as in the reference (the counters move in
+// after_step, benchmark_env.py:427-428).  Shared with oracle/ref_disturbances.py.
+constexpr uint32_t kDistCtrBase = 16u, kDistEpisodeCtr = 128u;
+
+template <int DIM>
+__device__ __forceinline__ void apply_disturbances(const KParams& p, const DistTable* __restrict__ dt, int mode,
+                                                   int stream, uint32_t i, uint32_t serial, uint32_t episode, int t,
+                                                   float (&v)[DIM]) {
+    constexpr int NB = (DIM + 3) / 4;
+    const int cnt = dt->n[mode];
+    const uint64_t g = (uint64_t)(p.env_base + (int64_t)i);
+    for (int e = 0; e < cnt; ++e) {
+        const DistEntry& d = dt->e[mode][e];
+        const int kind = d.kind;
+        float noise[DIM];
+        if (kind == SCG_DIST_IMPULSE || kind == SCG_DIST_STEP) {
+            int off = d.step_offset;
+            if (off < 0) {
+                uint32_t w[4];
+                philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), episode,
+                              kDistEpisodeCtr + (uint32_t)(mode * SCG_MAX_DISTURBANCES + e), p.seed_lo, p.seed_hi, w);
+                off = (int)__umulhi(w[0], (uint32_t)d.max_step);
+            }
+            float val = 0.f;
+            if (t >= off) {
+                if (kind == SCG_DIST_STEP) {
+                    val = d.magnitude;                                         // :177-178
+                } else {
+                    const int peak = (int)((float)off + d.half_duration);      // int(offset + duration / 2)  (:132)
+                    const float po = fabsf((float)(t - peak));
+                    val = po < d.half_duration ? d.magnitude * exp2f(po * d.log2_decay) : 0.f;   // :134-139
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) noise[j] = val;
+        } else {
+            float u[NB * 4];
+            const uint32_t c3 = kDistCtrBase + (uint32_t)(((stream * 3 + mode) * SCG_MAX_DISTURBANCES + e) * 4);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                uint32_t w[4];
+                philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), serial, c3 + (uint32_t)b, p.seed_lo, p.seed_hi, w);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) u[4 * b + q] = (float)(w[q] >> 8) * 5.9604644775390625e-8f;
+            }
+            if (kind == SCG_DIST_UNIFORM) {                                     // :207-208
+#pragma unroll
+                for (int j = 0; j < DIM; ++j) noise[j] = fmaf(d.b[j], u[j], d.a[j]);
+            } else if (kind == SCG_DIST_PERIODIC) {                             // :282-284
+#pragma unroll
+                for (int j = 0; j < DIM; ++j) {
+                    const float phase = fmaf(u[j], 6.283185307179586f, -3.141592653589793f);
+                    float sn, cs;
+                    sincos_f(fmaf(d.omega_dt, (float)t, phase), sn, cs);
+                    noise[j] = d.scale * sn;
+                }
+            } else {                                                            // white noise (:241): Box-Muller pairs
+#pragma unroll
+                for (int k = 0; k < (DIM + 1) / 2; ++k) {
+                    const float r = sqrt_f(-2.0f * logf(u[2 * k] + 5.9604644775390625e-8f));     // u1 in (0, 1]
+                    float sn, cs;
+                    sincos_f(6.283185307179586f * u[2 * k + 1], sn, cs);
+                    noise[2 * k] = r * cs * d.a[2 * k];
+                    if (2 * k + 1 < DIM) noise[2 * k + 1] = r * sn * d.a[2 * k + 1];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) v[j] = fmaf(noise[j], d.mask[j], v[j]);
+    }
+}
+
 // nominal (+ uniform Philox offsets) reset state of env i -- quadrotor.py:478-493 with
 // benchmark_env.py:297-307 restricted to 'uniform' draws.
 template <int NX>
@@ -562,7 +639,27 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         }
         const int t = cur.t;
         float epr = cur.epr; int epl = cur.epl;
-        const float fx = cur.fx, fy = cur.fy, fz = cur.fz;
+        float fx = cur.fx, fy = cur.fy, fz = cur.fz;
+        // passive disturbances (quadrotor.py:526-548,835-836,879-880): action, dynamics and observation noise
+        float act_noise[NU], obs_noise[NX];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) act_noise[j] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) obs_noise[j] = 0.f;
+        if (EXTRA && p.dist) {
+            const uint32_t episode = io.episode_id ? ldp(io.episode_id, i4) : 0u;
+            apply_disturbances<NU>(p, p.dist, SCG_DIST_ACTION, 0, i, serial, episode, t, act_noise);
+            constexpr int ND = SYS == SCG_QUAD_3D ? 3 : (SYS == SCG_QUAD_2D ? 2 : 1);
+            float dn[ND];
+#pragma unroll
+            for (int j = 0; j < ND; ++j) dn[j] = 0.f;
+            apply_disturbances<ND>(p, p.dist, SCG_DIST_DYNAMICS, 0, i, serial, episode, t, dn);
+            if constexpr (SYS == SCG_QUAD_3D) { fx += dn[0]; fy += dn[1]; fz += dn[2]; }
+            else if constexpr (SYS == SCG_QUAD_2D) { fx += dn[0]; fz += dn[1]; }        // x-z plane (:543-545)
+            else if constexpr (SYS == SCG_QUAD_1D) { fz += dn[0]; }                     // z only (:540-542)
+            else { fx += dn[0]; }                                                       // cart force
+            apply_disturbances<NX>(p, p.dist, SCG_DIST_OBSERVATION, 0, i, serial, episode, t, obs_noise);
+        }
 
         // ---- before_step / _preprocess_control (benchmark_env.py:394-404, quadrotor.py:815-842) and the state
         //      advance: _advance_simulation replaced by fixed-step integration of the prior model.
@@ -593,6 +690,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                     th = (RT)fmin(fmax(ad, tb->act_low_d[j]), tb->act_high_d[j]);
                 }
                 if (EXTRA && io.action_disturbance) th += (RT)ldp(PL(io.action_disturbance, j), i4);   // :835-838
+                if (EXTRA) th += (RT)act_noise[j];
                 if (SYS != SCG_CARTPOLE && (p.flags & F_MOTOR_MAP)) {
                     // cmd2pwm / pwm2rpm / KF rpm^2  (quadrotor_utils.py:38-50,66; base_aviary.py:420)
                     RT pwm;
@@ -753,7 +851,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                     // state (+ observation noise) + the goal extension of extend_obs(obs, t + 1)
 #pragma unroll
                     for (int j = 0; j < NX; ++j) {
-                        float o = x[j];
+                        float o = x[j] + obs_noise[j];
                         if (io.obs_noise) o += ldp(PL(io.obs_noise, j), i4);
                         stp(PLS(io.terminal_obs, j), i4, o);
                     }
@@ -788,6 +886,13 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                 }
                 t_out = 0;
                 epr = 0.f; epl = 0;
+                if (EXTRA && io.episode_id) stp(io.episode_id, i4, serial);
+                if (EXTRA && p.dist) {
+                    // the observation handed back is the one reset() computes: counter 0, its own draws (:497)
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) obs_noise[j] = 0.f;
+                    apply_disturbances<NX>(p, p.dist, SCG_DIST_OBSERVATION, 1, i, serial, serial, 0, obs_noise);
+                }
                 if (EXTRA && io.inertial && (p.flags & F_RAND_INERTIAL)) {
                     float prop[4];
                     draw_inertial(p, tb, i, serial, prop);
@@ -818,7 +923,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         if (EXTRA && io.obs) {
 #pragma unroll
             for (int j = 0; j < NX; ++j) {
-                float o = x[j];
+                float o = x[j] + obs_noise[j];
                 if (io.obs_noise) o += ldp(PL(io.obs_noise, j), i4);
                 stp(PL(io.obs, j), i4, o);
             }
@@ -1312,6 +1417,7 @@ __global__ __launch_bounds__(kBlock) void scg_reset_kernel(const KParams p, cons
                                                            const uint8_t* __restrict__ mask,
                                                            const float* __restrict__ reset_state,
                                                            float* __restrict__ inertial,
+                                                           uint32_t* __restrict__ episode_id,
                                                            const float* __restrict__ ref, uint32_t serial,
                                                            int64_t ld, uint32_t n) {
     constexpr int NX = Dim<SYS>::NX;
@@ -1335,7 +1441,9 @@ __global__ __launch_bounds__(kBlock) void scg_reset_kernel(const KParams p, cons
         stp(step_count, i4, 0);
         if (ep_return) stp(ep_return, i4, 0.f);
         if (ep_length) stp(ep_length, i4, 0);
+        if (episode_id) stp(episode_id, i4, serial);
         if (obs) {
+            if (p.dist) apply_disturbances<NX>(p, p.dist, SCG_DIST_OBSERVATION, 1, i, serial, serial, 0, x);   // obs only
 #pragma unroll
             for (int j = 0; j < NX; ++j) stp(PL(obs, j), i4, x[j]);
             if (p.obs_goal_horizon > 0) {
@@ -1416,7 +1524,7 @@ LaunchGeom step_geometry(const KParams& p, int system, int64_t n, int num_cus) {
 static uint32_t features_needed(const KParams& p, const scg_step_io& io) {
     const bool extra = io.inertial || io.action_disturbance || io.dynamics_force || io.obs_noise || io.obs || io.truncated ||
                        io.goal_reached || io.mse || io.terminal_obs || io.last_ep_return || io.last_ep_length ||
-                       io.stats || (p.flags & F_NORMALIZED) || !(p.flags & F_Q_DIAG);
+                       io.stats || io.episode_id || p.dist || (p.flags & F_NORMALIZED) || !(p.flags & F_Q_DIAG);
     if (extra) return FT_TRACK | FT_CON | FT_EXTRA;
     uint32_t ft = 0;
     if (p.flags & F_TRACKING) ft |= FT_TRACK;
@@ -1545,8 +1653,8 @@ hipError_t launch_step(int system, const KParams& p, const scg_step_io& io, cons
 
 hipError_t launch_reset(int system, const KParams& p, const KTables* tb, float* state, float* state_lo,
                         int32_t* step_count, float* ep_return, int32_t* ep_length, float* obs,
-                        const uint8_t* mask, const float* reset_state, float* inertial, const float* ref,
-                        uint32_t serial, int64_t ld, int64_t n64, hipStream_t s) {
+                        const uint8_t* mask, const float* reset_state, float* inertial, uint32_t* episode_id,
+                        const float* ref, uint32_t serial, int64_t ld, int64_t n64, hipStream_t s) {
     const uint32_t n = (uint32_t)n64;
     int64_t blocks = (n64 + kBlock - 1) / kBlock;
     if (blocks < 1) blocks = 1;
@@ -1554,16 +1662,16 @@ hipError_t launch_reset(int system, const KParams& p, const KTables* tb, float* 
     dim3 grid((unsigned)blocks), block(kBlock);
     switch (system) {
         case SCG_QUAD_1D:
-            hipLaunchKernelGGL(scg_reset_kernel<SCG_QUAD_1D>, grid, block, 0, s, p, tb, state, state_lo, step_count, ep_return, ep_length, obs, mask, reset_state, inertial, ref, serial, ld, n);
+            hipLaunchKernelGGL(scg_reset_kernel<SCG_QUAD_1D>, grid, block, 0, s, p, tb, state, state_lo, step_count, ep_return, ep_length, obs, mask, reset_state, inertial, episode_id, ref, serial, ld, n);
             break;
         case SCG_QUAD_2D:
-            hipLaunchKernelGGL(scg_reset_kernel<SCG_QUAD_2D>, grid, block, 0, s, p, tb, state, state_lo, step_count, ep_return, ep_length, obs, mask, reset_state, inertial, ref, serial, ld, n);
+            hipLaunchKernelGGL(scg_reset_kernel<SCG_QUAD_2D>, grid, block, 0, s, p, tb, state, state_lo, step_count, ep_return, ep_length, obs, mask, reset_state, inertial, episode_id, ref, serial, ld, n);
             break;
         case SCG_QUAD_3D:
-            hipLaunchKernelGGL(scg_reset_kernel<SCG_QUAD_3D>, grid, block, 0, s, p, tb, state, state_lo, step_count, ep_return, ep_length, obs, mask, reset_state, inertial, ref, serial, ld, n);
+            hipLaunchKernelGGL(scg_reset_kernel<SCG_QUAD_3D>, grid, block, 0, s, p, tb, state, state_lo, step_count, ep_return, ep_length, obs, mask, reset_state, inertial, episode_id, ref, serial, ld, n);
             break;
         case SCG_CARTPOLE:
-            hipLaunchKernelGGL(scg_reset_kernel<SCG_CARTPOLE>, grid, block, 0, s, p, tb, state, state_lo, step_count, ep_return, ep_length, obs, mask, reset_state, inertial, ref, serial, ld, n);
+            hipLaunchKernelGGL(scg_reset_kernel<SCG_CARTPOLE>, grid, block, 0, s, p, tb, state, state_lo, step_count, ep_return, ep_length, obs, mask, reset_state, inertial, episode_id, ref, serial, ld, n);
             break;
         default:
             return hipErrorInvalidValue;

@@ -330,7 +330,8 @@ class BenchmarkEnv:
         cfg.seed = self._seed & 0xFFFFFFFFFFFFFFFF
         cfg.env_index_base = self.ENV_INDEX_BASE
         self._fill_system_config(cfg)
-        return Engine(cfg, x_goal_table=self._x_goal_table(), constraint_list=constraint_list, device=self.device)
+        return Engine(cfg, x_goal_table=self._x_goal_table(), constraint_list=constraint_list, device=self.device,
+                      disturbances=[e for mode, dl in self.disturbances.items() for e in dl.compile(mode)])
 
     def _ensure_engine(self):
         if self._engine is None or self._engine_dirty:
@@ -360,6 +361,8 @@ class BenchmarkEnv:
         b['step_count'] = torch.zeros(ld, dtype=torch.int32, device=dev)
         b['reward'] = torch.zeros(ld, dtype=f32, device=dev)
         b['done'] = torch.zeros(ld, dtype=torch.bool, device=dev)          # the kernel writes 0 / 1 bytes
+        if any(dl.needs_episode_id for dl in self.disturbances.values()):
+            b['episode_id'] = torch.zeros(ld, dtype=torch.int32, device=dev)     # uint32 on the device side
         if self.COMPENSATED_STATE:
             b['state_lo'] = torch.zeros((nx, ld), dtype=f32, device=dev)
         if self.RANDOMIZED_INERTIAL_PROP:
@@ -527,10 +530,11 @@ class BenchmarkEnv:
 
         ``actions``: contiguous float32 device tensor [T, nu, ld] (``ld = env.plane_stride``), used
         cyclically.  Outputs (``env.state``, reward, done, ... buffers) hold the last step's values;
-        episode statistics accumulate.  Disturbance planes are not refreshed between the steps."""
+        episode statistics accumulate.  Passive disturbances are drawn in the kernel at every step; an adversary
+        needs ``step()`` (its action changes per step)."""
         self._check_initial_reset()
-        if self.disturbances or self.adversary_disturbance is not None:
-            raise RuntimeError('[ERROR] rollout() does not regenerate disturbance planes per step; use step().')
+        if self.adversary_disturbance is not None:
+            raise RuntimeError('[ERROR] rollout() cannot take per-step adversary actions; use step().')
         if not (isinstance(actions, torch.Tensor) and actions.dtype == torch.float32 and actions.is_contiguous()
                 and actions.ndim == 3 and actions.shape[1:] == (self.action_dim, self._ld)):
             raise ValueError('[ERROR] rollout() needs a contiguous float32 [T, %d, %d] device tensor.'
@@ -633,17 +637,13 @@ class BenchmarkEnv:
         act = self._load_action(action)
         self._raw_action = act
         b = self._bufs
-        if self.disturbances or self.adversary_disturbance is not None:
-            # disturbances (quadrotor.py:526-548,835-838,879-880): noise planes generated on device
+        if self.adversary_disturbance is not None:
+            # adversary inputs (benchmark_env.py:256-266, quadrotor.py:529-536,837-838) arrive as planes; the passive
+            # disturbances are generated inside the kernel (scg_set_disturbances)
             io = dict(b)
             io['action'] = act
             io['reset_state'] = self._reset_state_buf
-            if 'action' in self.disturbances or self.adversary_disturbance == 'action':
-                io['action_disturbance'] = self._disturbance_plane('action', self.action_dim)
-            if 'dynamics' in self.disturbances or self.adversary_disturbance == 'dynamics':
-                io['dynamics_force'] = self._dynamics_force_plane()
-            if 'observation' in self.disturbances:
-                io['obs_noise'] = self._disturbance_plane('observation', self.state_dim)
+            self._adversary_planes(io)
             self._engine.step(io, self.num_envs, self._ld, self._serial)
             self._bound = False
         else:
@@ -662,33 +662,25 @@ class BenchmarkEnv:
             info['n'] = LazyInfoList(info, done)
         return obs, rew, done, info
 
-    def _disturbance_plane(self, mode, dim):
-        out = torch.zeros((dim, self._ld), dtype=torch.float32, device=self.device)
-        view = out[:, :self.num_envs].T              # [N, dim]
-        if mode in self.disturbances:
-            view.copy_(self.disturbances[mode].apply(torch.zeros_like(view), self))
-        if mode == 'action' and self.adversary_disturbance == 'action' and self.adv_action is not None:
-            view += self.adv_action
-        return out
-
-    def _dynamics_force_plane(self):
-        """World-frame force [3][ld] from the mode-dimensional disturbance (quadrotor.py:539-548)."""
-        dim = self.DISTURBANCE_MODES['dynamics']['dim']
-        f = torch.zeros((self.num_envs, dim), dtype=torch.float32, device=self.device)
-        if 'dynamics' in self.disturbances:
-            f = self.disturbances['dynamics'].apply(f, self)
-        if self.adversary_disturbance == 'dynamics' and self.adv_action is not None:
-            f = f + self.adv_action
-            self.adv_action = None
-        out = torch.zeros((3, self._ld), dtype=torch.float32, device=self.device)
+    def _adversary_planes(self, io):
         n = self.num_envs
-        if dim == 1:
-            out[2, :n] = f[:, 0]
-        elif dim == 2:
-            out[0, :n], out[2, :n] = f[:, 0], f[:, 1]
-        else:
-            out[:, :n] = f.T
-        return out
+        if self.adversary_disturbance == 'action' and self.adv_action is not None:
+            out = torch.zeros((self.action_dim, self._ld), dtype=torch.float32, device=self.device)
+            out[:, :n] = self.adv_action.T
+            io['action_disturbance'] = out
+        elif self.adversary_disturbance == 'dynamics' and self.adv_action is not None:
+            # world-frame force [3][ld] from the mode-dimensional adversary action (quadrotor.py:529-548)
+            f = self.adv_action
+            self.adv_action = None                         # cleared after use (:534-536)
+            dim = self.DISTURBANCE_MODES['dynamics']['dim']
+            out = torch.zeros((3, self._ld), dtype=torch.float32, device=self.device)
+            if dim == 1:
+                out[0 if self.NAME == 'cartpole' else 2, :n] = f[:, 0]
+            elif dim == 2:
+                out[0, :n], out[2, :n] = f[:, 0], f[:, 1]
+            else:
+                out[:, :n] = f.T
+            io['dynamics_force'] = out
 
     def close(self):
         if self._engine is not None:

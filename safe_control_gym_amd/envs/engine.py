@@ -12,7 +12,7 @@ from safe_control_gym_amd import _capi
 
 
 class Engine:
-    def __init__(self, cfg, x_goal_table=None, constraint_list=None, device=None):
+    def __init__(self, cfg, x_goal_table=None, constraint_list=None, device=None, disturbances=None):
         """cfg: a filled ``_capi.ScgConfig``; x_goal_table: (T, nx) float64 or None."""
         self.lib = _capi.load()
         self.device = torch.device(device)
@@ -38,6 +38,9 @@ class Engine:
                 rows, n_rows, pmats, n_p = constraint_list.compile_rows()
                 _capi.check(self.lib.scg_set_constraints(handle, rows, n_rows, pmats, n_p), 'scg_set_constraints')
                 self.num_device_rows = n_rows
+            if disturbances:
+                arr = (_capi.ScgDisturbance * len(disturbances))(*disturbances)
+                _capi.check(self.lib.scg_set_disturbances(handle, arr, len(disturbances)), 'scg_set_disturbances')
         self.obs_dim = self.lib.scg_obs_dim(handle)
         self._io = _capi.ScgStepIO()
         self._io.struct_size = C.sizeof(_capi.ScgStepIO)
@@ -62,11 +65,12 @@ class Engine:
             _capi.check(self.lib.scg_reset(self.handle, p(bufs['state']), p(bufs.get('state_lo')),
                                            p(bufs['step_count']), p(bufs.get('ep_return')),
                                            p(bufs.get('ep_length')), p(bufs.get('obs')), p(mask),
-                                           p(reset_state), p(bufs.get('inertial')), serial & 0xffffffff, ld, n, self._stream()),
+                                           p(reset_state), p(bufs.get('inertial')), p(bufs.get('episode_id')),
+                                           serial & 0xffffffff, ld, n, self._stream()),
                         'scg_reset')
 
     _IO_FIELDS = ('action', 'action_disturbance', 'dynamics_force', 'obs_noise', 'reset_state', 'inertial', 'state',
-                  'state_lo', 'step_count', 'ep_return', 'ep_length', 'obs', 'reward', 'done',
+                  'state_lo', 'step_count', 'ep_return', 'ep_length', 'episode_id', 'obs', 'reward', 'done',
                   'constraint_values', 'constraint_violation', 'truncated', 'goal_reached', 'mse',
                   'terminal_obs', 'last_ep_return', 'last_ep_length', 'stats')
 

@@ -55,7 +55,7 @@ def make_pair(system, n, seed=1337, device='cuda', engine_kwargs=None, init_stat
     else:
         env = scg.make('quadrotor', quad_type=system, num_envs=n, device=device, seed=seed, **ek)
     sampler = PhiloxSampler(seed, system, kw.get('init_state_randomization_info'))
-    okw = {k: v for k, v in kw.items() if k not in ('physics',)}
+    okw = {k: v for k, v in kw.items() if k not in ('physics', 'disturbances')}
     if 'physics' in kw:
         okw['integrator'] = {'rk4': 'rk4', 'euler': 'euler', 'pyb': 'rk4', 'dyn': 'euler'}[kw['physics']]
     for k_engine, k_oracle in (('integration_substeps', 'substeps'),):
@@ -67,13 +67,25 @@ def make_pair(system, n, seed=1337, device='cuda', engine_kwargs=None, init_stat
         if init_states is not None:
             o['init_state'] = np.asarray(init_states[i], dtype=np.float64)
         refs.append(RefEnv(system=system, env_index=i, reset_sampler=sampler, **o))
+    dist = (engine_kwargs or {}).get('disturbances') or kw.get('disturbances')
+    if dist:
+        from oracle.ref_disturbances import RefDisturbanceModel
+        for i, r in enumerate(refs):
+            r.disturbance_model = RefDisturbanceModel(dist, system, seed, i, r.EPISODE_LEN_SEC, r.CTRL_TIMESTEP)
     if init_states is not None:
         env.set_init_states(np.asarray(init_states, dtype=np.float32))
     return env, RefVecEnv(refs), sampler
 
 
-def sync_reset(env, ref, sampler):
+def _sync_serial(env, ref, sampler):
     sampler.serial = env._serial
+    for r in ref.envs:
+        if r.disturbance_model is not None:
+            r.disturbance_model.serial = env._serial
+
+
+def sync_reset(env, ref, sampler):
+    _sync_serial(env, ref, sampler)
     obs_e = env.reset()
     if isinstance(obs_e, tuple):
         obs_e = obs_e[0]
@@ -83,7 +95,7 @@ def sync_reset(env, ref, sampler):
 
 def sync_step(env, ref, sampler, actions):
     """Step both with the same (N, nu) float32 actions."""
-    sampler.serial = env._serial
+    _sync_serial(env, ref, sampler)
     a32 = np.asarray(actions, dtype=np.float32)
     out_e = env.step(a32)
     out_r = ref.step(a32.astype(np.float64))

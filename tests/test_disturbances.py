@@ -1,0 +1,253 @@
+"""disturbances generated inside the step kernel.
+
+CPU: oracle/ref_disturbances.py replayed against vectors recorded from the LIVE reference classes
+(tests/golden/disturbances.json, made by tests/golden/make_golden_disturbances.py), plus the statistics of the
+Philox -> uniform / Box-Muller transforms and the host-side compile().
+GPU: the HIP kernel against the oracle, teacher-forced, for every disturbance kind and mode; batch statistics,
+determinism and shard invariance at scale.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ref_disturbances as rd
+from helpers import RTOL, compare_step, force_state, make_pair, rel_err, sync_reset, sync_step
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOAL3 = {'stabilization_goal': [0.0, 0.0, 1.0], 'stabilization_goal_tolerance': 0.05}
+
+
+def test_oracle_matches_reference_recordings():
+    with open(os.path.join(HERE, 'golden', 'disturbances.json')) as f:
+        cases = json.load(f)['cases']
+    assert len(cases) == 12
+    for c in cases:
+        for s in c['steps']:
+            noise = rd.entry_noise(c['spec'], c['dim'], s['t'], c['spec'].get('step_offset', None)
+                                   if c['spec'].get('step_offset', None) is not None else c['episode_offset'],
+                                   np.asarray(s['u']), c['ctrl_timestep'])
+            out = np.asarray(s['target']) + noise
+            assert np.allclose(out, s['out'], rtol=1e-13, atol=1e-15), (c['spec'], s['t'])
+
+
+def test_philox_transforms_statistics():
+    u = np.concatenate([rd._uniforms(1337, i, 5, rd.CTR_BASE, 12) for i in range(4000)])
+    assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.01 and abs(u.var() - 1 / 12) < 0.003
+    z = rd.standard_normals(u)
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02 and abs(np.mean(z ** 3)) < 0.06
+    assert abs(np.mean(z ** 4) - 3.0) < 0.15 and np.isfinite(z).all()
+    offs = np.array([rd.episode_step_offset(7, i, 3, 0, 1, 300) for i in range(3000)])
+    assert offs.min() >= 0 and offs.max() < 300 and abs(offs.mean() - 149.5) < 8
+    # streams of different entries / modes / serials do not coincide
+    a = rd._uniforms(1, 0, 0, rd.CTR_BASE, 4)
+    assert not np.array_equal(a, rd._uniforms(1, 0, 0, rd.CTR_BASE + 4, 4))
+    assert not np.array_equal(a, rd._uniforms(1, 0, 1, rd.CTR_BASE, 4))
+    assert not np.array_equal(a, rd._uniforms(1, 1, 0, rd.CTR_BASE, 4))
+
+
+def test_host_compile_and_validation():
+    from safe_control_gym_amd import _capi
+    from safe_control_gym_amd.envs import disturbances as D
+
+    class E:
+        EPISODE_LEN_SEC, CTRL_TIMESTEP = 5, 1 / 60
+    dl = D.create_disturbance_list([dict(disturbance_func='impulse', magnitude=2, step_offset=None, duration=4, decay_rate=0.5),
+                                    dict(disturbance_func='white_noise', std=[0.1, 0.2], mask=[1, 0])],
+                                   {'dim': 2}, E())
+    e = dl.compile('action')
+    assert dl.needs_episode_id and len(e) == 2
+    assert (e[0].mode, e[0].kind, e[0].step_offset, e[0].max_step, e[0].duration) == (0, _capi.SCG_DIST_IMPULSE, -1, 300, 4)
+    assert e[0].decay_rate == 0.5 and e[0].has_mask == 0
+    assert e[1].kind == _capi.SCG_DIST_WHITE_NOISE and list(e[1].low)[:2] == [0.1, 0.2] and e[1].has_mask == 1
+    with pytest.raises(AssertionError):
+        D.ImpulseDisturbance(E(), 2, duration=0)
+    with pytest.raises(AssertionError):
+        D.ImpulseDisturbance(E(), 2, decay_rate=1.5)
+    with pytest.raises(ValueError):
+        D.UniformNoise(E(), 2, low=1)                                    # int is neither float nor list (:198-203)
+    with pytest.raises(AssertionError):
+        D.WhiteNoise(E(), 3, std=[0.1])
+    with pytest.raises(AssertionError):
+        D.create_disturbance_list([{'magnitude': 1}], {'dim': 1}, E())
+
+
+# ------------------------------------------------------------------------------------------------------
+# GPU parity
+# ------------------------------------------------------------------------------------------------------
+def _actions(env, rng, n, spread=0.3):
+    lo, hi = env.action_space.low.astype(np.float64), env.action_space.high.astype(np.float64)
+    mid = 0.5 * (lo + hi)
+    return mid + spread * (hi - lo) * rng.uniform(-0.5, 0.5, size=(n, len(lo)))
+
+
+CASES = [
+    ('q3_noise_everywhere', 3, dict(task='stabilization', task_info=GOAL3, cost='rl_reward', ctrl_freq=60, pyb_freq=240),
+     {'action': [{'disturbance_func': 'white_noise', 'std': 0.002}],
+      'dynamics': [{'disturbance_func': 'uniform', 'low': [-0.05, -0.05, -0.05], 'high': [0.05, 0.05, 0.05]}],
+      'observation': [{'disturbance_func': 'white_noise', 'std': 0.01}]}),
+    ('q2_impulse_step_periodic', 2, dict(task='traj_tracking', cost='quadratic', ctrl_freq=50, pyb_freq=50, episode_len_sec=1),
+     {'action': [{'disturbance_func': 'impulse', 'magnitude': 0.05, 'step_offset': None, 'duration': 5, 'decay_rate': 0.6},
+                 {'disturbance_func': 'uniform', 'low': [-0.01, 0.0], 'high': [0.01, 0.02], 'mask': [1, 0]}],
+      'dynamics': [{'disturbance_func': 'step', 'magnitude': 0.08, 'step_offset': None, 'mask': [1, 0]},
+                   {'disturbance_func': 'periodic', 'scale': 0.03, 'frequency': 3.0}],
+      'observation': [{'disturbance_func': 'periodic', 'scale': 0.02, 'frequency': 1.5},
+                      {'disturbance_func': 'impulse', 'magnitude': 0.1, 'step_offset': 3, 'duration': 2, 'decay_rate': 1}]}),
+    ('q1_white_force', 1, dict(task='stabilization', cost='rl_reward', ctrl_freq=60, pyb_freq=60, episode_len_sec=0.5),
+     {'dynamics': [{'disturbance_func': 'white_noise', 'std': 0.05}],
+      'action': [{'disturbance_func': 'step', 'magnitude': 0.02, 'step_offset': 5}]}),
+    ('cartpole_mix', 'cartpole', dict(task='stabilization', cost='quadratic', ctrl_freq=50, pyb_freq=50, episode_len_sec=1),
+     {'action': [{'disturbance_func': 'white_noise', 'std': 0.5}],
+      'dynamics': [{'disturbance_func': 'impulse', 'magnitude': 3.0, 'step_offset': None, 'duration': 3, 'decay_rate': 0.8}],
+      'observation': [{'disturbance_func': 'uniform', 'low': -0.01, 'high': 0.01, 'mask': [1, 0, 1, 0]}]}),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,system,kw,dist', CASES, ids=[c[0] for c in CASES])
+def test_in_kernel_disturbances_match_oracle(gpu, name, system, kw, dist):
+    """Every kind x mode, teacher-forced for 60 steps (episodes of 50-60 steps: the time limit, out-of-bound dones
+    and the auto-reset observation with its own noise draw are all crossed)."""
+    n = 96
+    env, ref, sampler = make_pair(system, n, randomized_init=True, disturbances=dist, **kw)
+    obs_e, obs_r = sync_reset(env, ref, sampler)
+    assert rel_err(obs_e.cpu().numpy(), obs_r) <= RTOL
+    if 'observation' in dist:
+        assert np.abs(obs_r - np.stack([r.state for r in ref.envs])).max() > 0          # reset obs carries noise
+    rng = np.random.default_rng(23)
+    worst, dones = 0.0, 0
+    for k in range(60):
+        force_state(env, ref)
+        out = sync_step(env, ref, sampler, _actions(env, rng, n))
+        worst = max(worst, compare_step(*out, ref))
+        dones += int(out[1][2].sum())
+    assert dones >= n // 2                 # episode ends (time limit / out of bounds) and auto-resets were crossed
+    print('%s worst rel err %.3e, %d episode ends' % (name, worst, dones))
+    env.close()
+
+
+@pytest.mark.gpu
+def test_disturbed_rollout_equals_step_loop(gpu):
+    """scg_rollout with in-kernel disturbances == the same steps issued one by one (same serials -> same draws)."""
+    import torch
+    import safe_control_gym_amd as scg
+    dist = {'dynamics': [{'disturbance_func': 'white_noise', 'std': 0.02}],
+            'observation': [{'disturbance_func': 'white_noise', 'std': 0.01}]}
+    mk = lambda: scg.make('quadrotor', quad_type=2, num_envs=500, device='cuda', seed=3, randomized_init=True,
+                          disturbances=dist, task='traj_tracking', cost='quadratic')
+    a, b = mk(), mk()
+    a.reset(), b.reset()
+    g = torch.Generator(device='cuda'); g.manual_seed(0)
+    lo, hi = float(a.action_space.low[0]), float(a.action_space.high[0])
+    acts = lo + (hi - lo) * torch.rand((7, 2, a.plane_stride), generator=g, device='cuda')
+    a.rollout(acts, steps=20)
+    for k in range(20):
+        b.step(acts[k % 7])
+    assert torch.equal(a.state, b.state) and torch.equal(a._bufs['obs'], b._bufs['obs'])
+    assert torch.equal(a._bufs['reward'], b._bufs['reward'])
+    assert not torch.equal(a._bufs['obs'][:, :500], a._bufs['state'][:, :500])
+    a.close(), b.close()
+
+
+@pytest.mark.gpu
+def test_disturbance_statistics_determinism_and_sharding(gpu):
+    """2^17 envs: white observation noise has the configured std, uniform force noise its range (seen through
+    the 1-D acceleration), draws differ between steps, the same seed reproduces them bit for bit, and a shard
+    (env_index_base) sees exactly the draws of those envs in the full batch."""
+    import torch
+    import safe_control_gym_amd as scg
+    n = 1 << 17
+    dist = {'observation': [{'disturbance_func': 'white_noise', 'std': [0.05, 0.2]}],
+            'dynamics': [{'disturbance_func': 'uniform', 'low': -0.02, 'high': 0.06}]}
+    mk = lambda num, base=0: scg.make('quadrotor', quad_type=1, num_envs=num, device='cuda', seed=11, disturbances=dist,
+                                      env_index_base=base, task='stabilization', cost='rl_reward')
+    env = mk(n)
+    obs0 = env.reset().clone()                 # step() reuses the buffer behind the returned view
+    noise0 = (obs0 - env.state).double()
+    assert abs(float(noise0[:, 0].std()) - 0.05) < 1e-3 and abs(float(noise0[:, 1].std()) - 0.2) < 4e-3
+    assert abs(float(noise0.mean())) < 2e-3
+    hover = torch.full((n, 1), float(env.U_GOAL[0]), device='cuda')
+    v0 = env.state[:, 1].clone()
+    obs1, _, done1, _ = env.step(hover)
+    obs1, live = obs1.clone(), ~done1.clone()                 # lanes that fell out of the box were re-initialised
+    assert int(live.sum()) > n // 4
+    noise1 = (obs1 - env.state).double()
+    assert abs(float(noise1[:, 0].std()) - 0.05) < 1e-3
+    corr = float((noise0[:, 0] * noise1[:, 0]).mean() / (0.05 * 0.05))
+    assert abs(corr) < 0.02                                   # reset-obs and step-obs draws are independent streams
+    # hover thrust cancels gravity: dv = F / m * dt with F ~ U(-0.02, 0.06)
+    force = ((env.state[:, 1] - v0).double() * env.MASS / env.CTRL_TIMESTEP)[live]
+    assert float(force.min()) >= -0.02 - 1e-4 and float(force.max()) <= 0.06 + 1e-4
+    assert abs(float(force.mean()) - 0.02) < 5e-4 and abs(float(force.std()) - 0.08 / np.sqrt(12)) < 5e-4
+    # determinism
+    env2 = mk(n)
+    assert torch.equal(env2.reset(), obs0)
+    assert torch.equal(env2.step(hover)[0], obs1)
+    # shard invariance
+    lo, cnt = 70001, 5000
+    shard = mk(cnt, base=lo)
+    assert torch.equal(shard.reset(), obs0[lo:lo + cnt])
+    assert torch.equal(shard.step(hover[:cnt])[0], obs1[lo:lo + cnt])
+    env.close(), env2.close(), shard.close()
+
+
+@pytest.mark.gpu
+def test_adversary_planes_still_enter_where_the_reference_adds_them(gpu):
+    """set_adversary_control (benchmark_env.py:256-266): scaled action added as a dynamics force (quadrotor.py:529-536)
+    next to a passive in-kernel disturbance."""
+    n = 64
+    kw = dict(task='stabilization', cost='rl_reward', ctrl_freq=60, pyb_freq=60)
+    dist = {'dynamics': [{'disturbance_func': 'step', 'magnitude': 0.01, 'step_offset': 0}]}
+    env, ref, sampler = make_pair(2, n, randomized_init=True, disturbances=dist,
+                                  engine_kwargs=dict(adversary_disturbance='dynamics', adversary_disturbance_scale=0.05), **kw)
+    sync_reset(env, ref, sampler)
+    rng = np.random.default_rng(2)
+    for k in range(10):
+        force_state(env, ref)
+        adv = rng.uniform(-1.5, 1.5, size=(n, 2)).astype(np.float32)
+        env.set_adversary_control(adv)
+        scaled = np.clip(adv.astype(np.float64), -1, 1) * 0.05
+        a = _actions(env, rng, n)
+        # oracle: passive model fills dynamics_force in on_step; add the adversary on top through a wrapper
+        for i, r in enumerate(ref.envs):
+            m = r.disturbance_model
+            if not hasattr(m, '_orig_on_step'):
+                m._orig_on_step = m.on_step
+            def on_step(env_r, m=m, extra=np.array([scaled[i, 0], 0.0, scaled[i, 1]])):
+                m._orig_on_step(env_r)
+                env_r.dynamics_force = env_r.dynamics_force + extra
+            m.on_step = on_step
+        compare_step(*sync_step(env, ref, sampler, a), ref)
+    env.close()
+
+
+@pytest.mark.gpu
+def test_disturbance_c_abi_validation(gpu):
+    import ctypes as C
+    import safe_control_gym_amd as scg
+    from safe_control_gym_amd import _capi
+    env = scg.make('quadrotor', quad_type=2, num_envs=4, device='cuda')
+    env.reset()
+    lib, h = _capi.load(), env._engine.handle
+    d = _capi.ScgDisturbance()
+    d.mode, d.kind = 7, 0
+    assert lib.scg_set_disturbances(h, C.byref(d), 1) < 0 and b'mode' in lib.scg_last_error()
+    d.mode, d.kind = 0, 9
+    assert lib.scg_set_disturbances(h, C.byref(d), 1) < 0
+    d.kind, d.duration, d.decay_rate = _capi.SCG_DIST_IMPULSE, 0, 1.0
+    assert lib.scg_set_disturbances(h, C.byref(d), 1) < 0                 # duration >= 1 (disturbances.py:119)
+    d.duration, d.decay_rate, d.step_offset, d.max_step = 1, 1.0, -1, 0
+    assert lib.scg_set_disturbances(h, C.byref(d), 1) < 0                 # random offset needs max_step
+    five = (_capi.ScgDisturbance * 5)()
+    for e in five:
+        e.mode, e.kind = 1, _capi.SCG_DIST_STEP
+    assert lib.scg_set_disturbances(h, five, 5) < 0                       # > SCG_MAX_DISTURBANCES per mode
+    # a per-episode offset without the episode_id plane is refused at step time
+    d.max_step = 100
+    assert lib.scg_set_disturbances(h, C.byref(d), 1) == 0
+    with pytest.raises(_capi.ScgError, match='episode_id'):
+        env.step(np.zeros((4, 2), dtype=np.float32))
+    assert lib.scg_set_disturbances(h, None, 0) == 0                      # cleared
+    env.step(np.zeros((4, 2), dtype=np.float32))
+    env.close()

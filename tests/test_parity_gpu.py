@@ -192,46 +192,6 @@ def test_full_q_matrix_parity(gpu):
         compare_step(*sync_step(env, ref, sampler, _actions(env, rng, n, 0.3)), ref)
 
 
-def test_disturbance_planes_parity(gpu):
-    """Action / dynamics / observation disturbances enter exactly where the reference adds them
-    (quadrotor.py:835-838, :526-548 + base_aviary.py:306-315, :879-880)."""
-    import torch
-    n = 64
-    kw = dict(task='stabilization', task_info=GOAL3, cost='rl_reward', ctrl_freq=60, pyb_freq=240)
-    dist = {'action': [{'disturbance_func': 'white_noise', 'std': 0.002}],
-            'dynamics': [{'disturbance_func': 'uniform', 'low': [-0.05, -0.05, -0.05], 'high': [0.05, 0.05, 0.05]}],
-            'observation': [{'disturbance_func': 'white_noise', 'std': 0.01}]}
-    env, ref, sampler = make_pair(3, n, randomized_init=True, engine_kwargs=dict(disturbances=dist), **kw)
-    sync_reset(env, ref, sampler)
-    rng = np.random.default_rng(4)
-    planes = {}
-    orig_plane, orig_force = env._disturbance_plane, env._dynamics_force_plane
-
-    def spy_plane(mode, dim):
-        planes[mode] = orig_plane(mode, dim)
-        return planes[mode]
-
-    def spy_force():
-        planes['dynamics'] = orig_force()
-        return planes['dynamics']
-    env._disturbance_plane, env._dynamics_force_plane = spy_plane, spy_force
-    for k in range(12):
-        force_state(env, ref)
-        a = _actions(env, rng, n, 0.3)
-        sampler.serial = env._serial
-        out_e = env.step(a)
-        torch.cuda.synchronize()
-        ad = planes['action'][:, :n].T.cpu().numpy().astype(np.float64)
-        fd = planes['dynamics'][:, :n].T.cpu().numpy().astype(np.float64)
-        on = planes['observation'][:, :n].T.cpu().numpy().astype(np.float64)
-        assert np.abs(ad).max() > 0 and np.abs(fd).max() > 0 and np.abs(on).max() > 0
-        for i, r in enumerate(ref.envs):
-            r.action_disturbance, r.dynamics_force, r.obs_noise = ad[i], fd[i], on[i]
-        out_r = ref.step(a.astype(np.float64))
-        # the oracle applies obs noise to the reset observation as well; the engine adds the same plane
-        compare_step(out_e, out_r, ref)
-
-
 def test_free_running_rollout_with_auto_reset(gpu):
     """No teacher forcing: 120 steps near hover (plus wide-action lanes that leave the box and reset through
     the Philox path).  State error stays within 1e-5 on these <= 300-step episodes."""
