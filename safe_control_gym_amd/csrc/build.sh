@@ -8,5 +8,5 @@ out="$here/../lib"
 mkdir -p "$out"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-slp-vectorize \
-    -o "$out/libscg_rollout.so" "$here/scg_kernels.hip" "$here/scg_gae.hip" "$here/scg_linearize.hip" "$here/scg_capi.hip" "$@"
+    -o "$out/libscg_rollout.so" "$here/scg_kernels.hip" "$here/scg_gae.hip" "$here/scg_linearize.hip" "$here/scg_normalize.hip" "$here/scg_capi.hip" "$@"
 echo "built $out/libscg_rollout.so"

@@ -581,6 +581,37 @@ int scg_quadratic_loss(scg_handle* h, const double* Q, const double* R, const fl
     return SCG_OK;
 }
 
+int scg_mean_std_normalize(const float* x, float* y, int32_t d, int64_t ld_x, int64_t ld_y, int64_t n,
+                           const double* state_in, double* state_out, double* moments, float clip, double epsilon,
+                           void* stream) {
+    if (!x || !y || !state_in) return fail(SCG_ERR_INVALID, "scg_mean_std_normalize: null argument");
+    if (state_out && !moments) return fail(SCG_ERR_INVALID, "scg_mean_std_normalize: an updating call needs the moments scratch");
+    if (state_out == state_in) return fail(SCG_ERR_INVALID, "scg_mean_std_normalize: state_out must not alias state_in");
+    if (d < 1 || d > 65535) return fail(SCG_ERR_INVALID, "scg_mean_std_normalize: need 1 <= d <= 65535");
+    if (n < 0 || ld_x < n || ld_y < n) return fail(SCG_ERR_INVALID, "scg_mean_std_normalize: need 0 <= n <= ld_x, ld_y");
+    if (n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_mean_std_normalize: n > 2^30");
+    if (!(clip >= 0.f) || !(epsilon >= 0.0)) return fail(SCG_ERR_INVALID, "scg_mean_std_normalize: clip and epsilon must be >= 0");
+    if (n == 0) return SCG_OK;                     // np.mean of an empty batch is NaN in the reference; refuse to poison the tracker
+    HIP_TRY(launch_mean_std_normalize(x, y, d, ld_x, ld_y, n, state_in, state_out, moments, clip, epsilon,
+                                      (hipStream_t)stream));
+    return SCG_OK;
+}
+
+int scg_reward_normalize(const float* rew, const uint8_t* done, float* ret, float* out, int64_t n,
+                         const double* state_in, double* state_out, double* moments, float gamma, float clip,
+                         double epsilon, int32_t legacy_index_reset, void* stream) {
+    if (!rew || !out || !state_in) return fail(SCG_ERR_INVALID, "scg_reward_normalize: null argument");
+    if (state_out && (!moments || !done || !ret))
+        return fail(SCG_ERR_INVALID, "scg_reward_normalize: an updating call needs done, ret and the moments scratch");
+    if (state_out == state_in) return fail(SCG_ERR_INVALID, "scg_reward_normalize: state_out must not alias state_in");
+    if (n < 0 || n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_reward_normalize: need 0 <= n <= 2^30");
+    if (!(clip >= 0.f) || !(epsilon >= 0.0)) return fail(SCG_ERR_INVALID, "scg_reward_normalize: clip and epsilon must be >= 0");
+    if (n == 0) return SCG_OK;
+    HIP_TRY(launch_reward_normalize(rew, done, ret, out, n, state_in, state_out, moments, gamma, clip, epsilon,
+                                    legacy_index_reset, (hipStream_t)stream));
+    return SCG_OK;
+}
+
 int scg_num_constraints(const scg_handle* h) { return h ? h->n_con_rows : 0; }
 
 int scg_obs_dim(const scg_handle* h) { return h ? h->obs_dim : 0; }

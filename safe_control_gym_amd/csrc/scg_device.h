@@ -160,6 +160,12 @@ hipError_t launch_linearize(int system, const PhysT<float>& ph, const float* sta
 hipError_t launch_loss(int system, const double* Q, const double* R, const float* state, const float* input,
                        const float* xr, int64_t xr_ld, const float* ur, int64_t ur_ld, float* l, float* l_x, float* l_u,
                        int64_t ld, int64_t n, hipStream_t s);
+hipError_t launch_mean_std_normalize(const float* x, float* y, int d, int64_t ld_x, int64_t ld_y, int64_t n,
+                                     const double* state_in, double* state_out, double* moments, float clip,
+                                     double epsilon, hipStream_t s);
+hipError_t launch_reward_normalize(const float* rew, const uint8_t* done, float* ret, float* out, int64_t n,
+                                   const double* state_in, double* state_out, double* moments, float gamma,
+                                   float clip, double epsilon, int legacy, hipStream_t s);
 hipError_t launch_eval_constraints(int system, const ConTable* ct, const float* state, const float* action,
                                    float* c_val, uint8_t* violation, int64_t ld, int64_t n, hipStream_t s);
 }  // namespace scg

@@ -1,0 +1,273 @@
+// Running mean / std normalisers on the device.
+//
+// Replaces math_and_models/normalization.py: RunningMeanStd (:17-62), MeanStdNormalizer (:107-147) and
+// RewardStdNormalizer (:150-190), which PPO calls on every rollout step on host copies of the observations
+// and rewards (controllers/ppo/ppo.py:260-261).  Here the batch stays where the step kernel left it.
+//
+// One call = two launches:
+//   1. moments: per feature j, sum (x - c_j) and sum (x - c_j)^2 over the batch in double, c_j = the current
+//      running mean (a shift that removes the cancellation of the one-pass variance).  Each of the <= 64
+//      workgroups of a feature reduces through wave shuffles + LDS and writes ONE partial pair -- no atomics:
+//      f64 atomics on one address serialise at ~40 ns each on this part (measured: 2048 of them = 86 us), and the
+//      fixed summation order makes the tracker bit-reproducible.  Planes are SoA ([d][ld]), so every load is a
+//      coalesced wave transaction (float4 per lane when the planes are 16-byte aligned).
+//   2. normalise: every wave sums the feature's partials (one per lane), recomputes the tiny update_from_moments
+//      (:41-62) from the CURRENT state (the state is double-buffered: workgroup (0, j) writes the NEXT state,
+//      nobody reads it in this launch), then streams y = clip((x - mean) / sqrt(var + eps)).
+// The second pass re-reads x out of the 256 MB Infinity Cache for the batch sizes of interest (48 MB at 2^20 x 12).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "scg_device.h"
+#include "scg_math.h"
+
+namespace scg {
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// state record (doubles): mean[d], var[d], count
+__device__ __forceinline__ const double* st_mean(const double* s) { return s; }
+__device__ __forceinline__ const double* st_var(const double* s, int d) { return s + d; }
+
+// ---- pass 1 ---------------------------------------------------------------------------------------
+constexpr int kMaxPartials = 64;          // workgroups per feature (= lanes of the wave that sums them in pass 2)
+typedef float nf4 __attribute__((ext_vector_type(4)));
+
+// block-wide sum of up to 3 doubles; result valid in thread 0
+template <int K>
+__device__ __forceinline__ void block_sum(double (&v)[K], double* lds) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = wsum(v[k]);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) lds[wave * K + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = lds[k] + lds[K + k] + lds[2 * K + k] + lds[3 * K + k];
+    }
+}
+
+// partials: [d][kMaxPartials][2]
+template <bool VEC>
+__global__ __launch_bounds__(256) void scg_moments_kernel(const float* __restrict__ x, int64_t ld, uint32_t n,
+                                                          const double* __restrict__ state, int d,
+                                                          double* __restrict__ partials) {
+    __shared__ double lds[8];
+    const int j = blockIdx.y;
+    const float* plane = uptr(x + (int64_t)j * ld);
+    const double c = state[j];
+    double acc[2] = {0.0, 0.0};
+    if constexpr (VEC) {
+        const uint32_t n4 = n >> 2;
+        for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < n4; q += gridDim.x * 256u) {
+            const nf4 v4 = __builtin_nontemporal_load(reinterpret_cast<const nf4*>(plane) + q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double v = (double)v4[k] - c;
+                acc[0] += v;
+                acc[1] = fma(v, v, acc[1]);
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3u)) {                // ragged tail: at most 3 elements
+            const double v = (double)plane[(n & ~3u) + threadIdx.x] - c;
+            acc[0] += v;
+            acc[1] = fma(v, v, acc[1]);
+        }
+    } else {
+        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+            const double v = (double)ldp(plane, i * 4u) - c;
+            acc[0] += v;
+            acc[1] = fma(v, v, acc[1]);
+        }
+    }
+    block_sum<2>(acc, lds);
+    if (threadIdx.x == 0) {
+        double* out = partials + ((int64_t)j * kMaxPartials + blockIdx.x) * 2;
+        out[0] = acc[0];
+        out[1] = acc[1];
+    }
+}
+
+// RewardStdNormalizer.__call__ (:172-189), first half: ret = ret * gamma + rew; moments of ret; then the
+// "information leak" reset.  legacy == 0: ret[i] = 0 where done[i] (what the comment at :187 intends).
+// legacy != 0 reproduces the reference statement literally -- `self.ret[dones.astype(np.long)] = 0` indexes with
+// the 0 / 1 VALUES of dones, i.e. clears ret[0] when some env is not done and ret[1] when some env is done --
+// which the normalise pass applies once the done count is known.  partials: [kMaxPartials][3].
+__global__ __launch_bounds__(256) void scg_reward_moments_kernel(const float* __restrict__ rew,
+                                                                 const uint8_t* __restrict__ done,
+                                                                 float* __restrict__ ret, uint32_t n, float gamma,
+                                                                 const double* __restrict__ state, int legacy,
+                                                                 double* __restrict__ partials) {
+    __shared__ double lds[12];
+    const double c = state[0];
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const float r = fmaf(ret[i], gamma, rew[i]);
+        const double v = (double)r - c;
+        acc[0] += v;
+        acc[1] = fma(v, v, acc[1]);
+        const bool dn = done[i] != 0;
+        acc[2] += dn ? 1.0 : 0.0;
+        ret[i] = (!legacy && dn) ? 0.f : r;
+    }
+    block_sum<3>(acc, lds);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x * 3 + 0] = acc[0];
+        partials[blockIdx.x * 3 + 1] = acc[1];
+        partials[blockIdx.x * 3 + 2] = acc[2];
+    }
+}
+
+// every lane of the calling wave gets the sum over the feature's `count` partials (count <= 64)
+template <int K>
+__device__ __forceinline__ void sum_partials(const double* __restrict__ p, int count, double (&tot)[K]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < K; ++k) tot[k] = wsum(lane < count ? p[lane * K + k] : 0.0);
+}
+
+// ---- RunningMeanStd.update_from_moments (:41-62) for one feature --------------------------------------
+struct Updated { double mean, var, count; };
+__device__ __forceinline__ Updated update_from_moments(double mean, double var, double count, double c, double s1,
+                                                       double s2, double n) {
+    const double m1 = s1 / n;
+    const double batch_mean = c + m1;
+    const double batch_var = fmax(s2 / n - m1 * m1, 0.0);      // np.var (population variance, :36)
+    const double delta = batch_mean - mean;
+    const double tot = count + n;
+    Updated u;
+    u.mean = mean + delta * n / tot;
+    const double m2 = var * count + batch_var * n + delta * delta * count * n / tot;
+    u.var = m2 / tot;
+    u.count = tot;
+    return u;
+}
+
+// ---- pass 2 ---------------------------------------------------------------------------------------
+// state_out may be null (read-only normaliser: no update, partials unused).
+template <bool VEC>
+__global__ __launch_bounds__(256) void scg_mean_std_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                 int64_t ld_x, int64_t ld_y, uint32_t n, int d,
+                                                                 const double* __restrict__ state_in,
+                                                                 double* __restrict__ state_out,
+                                                                 const double* __restrict__ partials, int n_partials,
+                                                                 float clip, double epsilon) {
+    const int j = blockIdx.y;
+    double mean = state_in[j], var = state_in[d + j];
+    if (state_out) {
+        double tot[2];
+        sum_partials<2>(partials + (int64_t)j * kMaxPartials * 2, n_partials, tot);
+        const Updated u = update_from_moments(mean, var, state_in[2 * d], mean, tot[0], tot[1], (double)n);
+        mean = u.mean; var = u.var;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            state_out[j] = u.mean;
+            state_out[d + j] = u.var;
+            if (j == 0) state_out[2 * d] = u.count;
+        }
+    }
+    const double inv = 1.0 / sqrt(var + epsilon);               // :131-133
+    const float* src = uptr(x + (int64_t)j * ld_x);
+    float* dst = uptr(y + (int64_t)j * ld_y);
+    const double lo = -(double)clip, hi = (double)clip;
+    if constexpr (VEC) {
+        const uint32_t n4 = n >> 2;
+        for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < n4; q += gridDim.x * 256u) {
+            const nf4 v4 = reinterpret_cast<const nf4*>(src)[q];      // plain load: this pass should hit the cache
+            nf4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (float)fmin(fmax(((double)v4[k] - mean) * inv, lo), hi);
+            __builtin_nontemporal_store(o, reinterpret_cast<nf4*>(dst) + q);
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3u)) {
+            const uint32_t i = (n & ~3u) + threadIdx.x;
+            dst[i] = (float)fmin(fmax(((double)src[i] - mean) * inv, lo), hi);
+        }
+    } else {
+        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+            const double v = ((double)src[i] - mean) * inv;
+            stp(dst, i * 4u, (float)fmin(fmax(v, lo), hi));
+        }
+    }
+}
+
+// RewardStdNormalizer, second half (:189): out = clip(rew / sqrt(var + eps)) -- scaling only.
+__global__ __launch_bounds__(256) void scg_reward_apply_kernel(const float* __restrict__ rew, float* __restrict__ out,
+                                                               float* __restrict__ ret, uint32_t n,
+                                                               const double* __restrict__ state_in,
+                                                               double* __restrict__ state_out,
+                                                               const double* __restrict__ partials, int n_partials,
+                                                               int legacy, float clip, double epsilon) {
+    double var = state_in[1];
+    if (state_out) {
+        double tot[3];
+        sum_partials<3>(partials, n_partials, tot);
+        const Updated u = update_from_moments(state_in[0], var, state_in[2], state_in[0], tot[0], tot[1], (double)n);
+        var = u.var;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            state_out[0] = u.mean; state_out[1] = u.var; state_out[2] = u.count;
+            if (legacy) {
+                const double nd = tot[2];
+                if (nd < (double)n) ret[0] = 0.f;               // some dones == 0 -> index 0
+                if (nd > 0.0 && n > 1) ret[1] = 0.f;            // some dones == 1 -> index 1
+            }
+        }
+    }
+    const double inv = 1.0 / sqrt(var + epsilon);
+    const double lo = -(double)clip, hi = (double)clip;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
+        out[i] = (float)fmin(fmax((double)rew[i] * inv, lo), hi);
+}
+
+// ---- launchers ------------------------------------------------------------------------------------
+static unsigned partial_blocks(int64_t n) {
+    int64_t b = (n + 4095) / 4096;                              // >= 16 elements per thread
+    if (b > kMaxPartials) b = kMaxPartials;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+static unsigned apply_blocks(int64_t n, int d) {
+    int64_t b = (n + 4095) / 4096;
+    const int64_t cap = d >= 8 ? 256 : 1024;
+    if (b > cap) b = cap;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
+// scratch: d * kMaxPartials * 2 doubles (mean / std normaliser), kMaxPartials * 3 doubles (reward normaliser)
+hipError_t launch_mean_std_normalize(const float* x, float* y, int d, int64_t ld_x, int64_t ld_y, int64_t n,
+                                     const double* state_in, double* state_out, double* partials, float clip,
+                                     double epsilon, hipStream_t s) {
+    const unsigned pb = partial_blocks(n);
+    if (state_out) {
+        const dim3 grid(pb, (unsigned)d), block(256);
+        const bool vec = ((reinterpret_cast<uintptr_t>(x) | (uintptr_t)(ld_x * 4)) & 15u) == 0;
+        if (vec) hipLaunchKernelGGL(scg_moments_kernel<true>, grid, block, 0, s, x, ld_x, (uint32_t)n, state_in, d, partials);
+        else hipLaunchKernelGGL(scg_moments_kernel<false>, grid, block, 0, s, x, ld_x, (uint32_t)n, state_in, d, partials);
+    }
+    const dim3 grid(apply_blocks(n, d), (unsigned)d), block(256);
+    const bool vec2 = ((reinterpret_cast<uintptr_t>(x) | (uintptr_t)(ld_x * 4) | reinterpret_cast<uintptr_t>(y) |
+                        (uintptr_t)(ld_y * 4)) & 15u) == 0;
+    if (vec2) hipLaunchKernelGGL(scg_mean_std_apply_kernel<true>, grid, block, 0, s, x, y, ld_x, ld_y, (uint32_t)n, d,
+                                 state_in, state_out, partials, (int)pb, clip, epsilon);
+    else hipLaunchKernelGGL(scg_mean_std_apply_kernel<false>, grid, block, 0, s, x, y, ld_x, ld_y, (uint32_t)n, d,
+                            state_in, state_out, partials, (int)pb, clip, epsilon);
+    return hipGetLastError();
+}
+
+hipError_t launch_reward_normalize(const float* rew, const uint8_t* done, float* ret, float* out, int64_t n,
+                                   const double* state_in, double* state_out, double* partials, float gamma,
+                                   float clip, double epsilon, int legacy, hipStream_t s) {
+    const unsigned pb = partial_blocks(n);
+    if (state_out)
+        hipLaunchKernelGGL(scg_reward_moments_kernel, dim3(pb), dim3(256), 0, s, rew, done, ret, (uint32_t)n, gamma,
+                           state_in, legacy, partials);
+    hipLaunchKernelGGL(scg_reward_apply_kernel, dim3(apply_blocks(n, 1)), dim3(256), 0, s, rew, out, ret, (uint32_t)n,
+                       state_in, state_out, partials, (int)pb, legacy, clip, epsilon);
+    return hipGetLastError();
+}
+
+}  // namespace scg

@@ -1,0 +1,223 @@
+"""Normalisers for observations and rewards -- device mirror of the reference's ``math_and_models/normalization.py``.
+
+Same classes and call protocol as /root/reference/safe_control_gym/math_and_models/normalization.py
+(``RunningMeanStd`` :17-62, ``BaseNormalizer`` :65-104, ``MeanStdNormalizer`` :107-147, ``RewardStdNormalizer``
+:150-190, ``RescaleNormalizer`` :193-214, ``ActionUnnormalizer`` :226-248, ``normalize_angle`` :10-14), but the
+batch is a device tensor straight out of the step kernel and the tracking + normalisation run in two HIP
+kernels behind ``scg_mean_std_normalize`` / ``scg_reward_normalize`` (csrc/scg_normalize.hip).  The running
+statistics live in float64 device records (mean[d], var[d], count), double-buffered so that an update never
+needs a host round trip; ``state_dict()`` / ``load_state_dict()`` exchange the reference's ``{'mean', 'var'}``
+NumPy arrays.
+
+Observations are taken zero-copy when they are the engine's own ``[N, d]`` view of SoA planes
+(``env.step()``'s obs: stride (1, ld)); any other tensor is transposed into planes first.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from safe_control_gym_amd import _capi
+
+
+def normalize_angle(x):
+    """Wraps input angle to [-pi, pi] (normalization.py:10-14)."""
+    return ((x + math.pi) % (2 * math.pi)) - math.pi
+
+
+class RunningMeanStd:
+    """Device-resident running mean / variance / count (normalization.py:17-62).  ``update`` is fused into the
+    normalisers' kernels; this object owns the two float64 state records and exposes the current one."""
+
+    def __init__(self, epsilon=1e-4, shape=(), device='cuda'):
+        self.shape = tuple(shape) if not isinstance(shape, int) else (shape,)
+        self.d = int(np.prod(self.shape)) if self.shape else 1
+        self.device = torch.device(device)
+        self._state = torch.zeros((2, 2 * self.d + 1), dtype=torch.float64, device=self.device)
+        self._state[:, self.d:2 * self.d] = 1.0
+        self._state[:, 2 * self.d] = epsilon
+        self._cur = 0
+        self._moments = torch.zeros(max(128 * self.d, 192), dtype=torch.float64, device=self.device)   # kernel scratch
+
+    # the reference's attributes, as views of the current record
+    @property
+    def mean(self):
+        return self._state[self._cur, :self.d].reshape(self.shape)
+
+    @property
+    def var(self):
+        return self._state[self._cur, self.d:2 * self.d].reshape(self.shape)
+
+    @property
+    def count(self):
+        return self._state[self._cur, 2 * self.d]
+
+    def _records(self, update):
+        """(state_in, state_out or None); flips the current record when updating."""
+        cur = self._state[self._cur]
+        if not update:
+            return cur, None
+        nxt = self._state[1 - self._cur]
+        self._cur = 1 - self._cur
+        return cur, nxt
+
+    def set(self, mean=None, var=None, count=None):
+        rec = self._state[self._cur]
+        if mean is not None:
+            rec[:self.d] = torch.as_tensor(np.asarray(mean, dtype=np.float64).reshape(-1), device=self.device)
+        if var is not None:
+            rec[self.d:2 * self.d] = torch.as_tensor(np.asarray(var, dtype=np.float64).reshape(-1), device=self.device)
+        if count is not None:
+            rec[2 * self.d] = float(count)
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class BaseNormalizer:
+    """Template / default normaliser: identity (normalization.py:65-104)."""
+
+    def __init__(self, read_only=False):
+        self.read_only = read_only
+
+    def set_read_only(self):
+        self.read_only = True
+
+    def unset_read_only(self):
+        self.read_only = False
+
+    def __call__(self, x, *args, **kwargs):
+        return x
+
+    def state_dict(self):
+        return {}
+
+    def load_state_dict(self, _):
+        pass
+
+
+class MeanStdNormalizer(BaseNormalizer):
+    """Normalise by the running average (normalization.py:107-147)."""
+
+    def __init__(self, shape=(), read_only=False, clip=10.0, epsilon=1e-8, device='cuda'):
+        super().__init__(read_only)
+        self.lib = _capi.load()
+        self.rms = RunningMeanStd(shape=shape, device=device)
+        self.clip = clip
+        self.epsilon = epsilon
+        self.device = self.rms.device
+        self._out = None
+
+    def _planes(self, x):
+        """(planes pointer tensor, ld, n): zero copy for an [N, d] view of SoA planes, else one transposing copy."""
+        d = self.rms.d
+        x = torch.as_tensor(x, device=self.device)
+        if x.dtype != torch.float32:
+            x = x.to(torch.float32)
+        if x.ndim == 1:
+            x = x.reshape(-1, 1) if d == 1 else x.reshape(1, d)
+        if x.ndim != 2 or x.shape[1] != d:
+            raise ValueError('[ERROR] expected a (batch, %d) input, got %s' % (d, tuple(x.shape)))
+        n = x.shape[0]
+        if n > 0 and x.stride(0) == 1 and (d == 1 or x.stride(1) >= n):
+            return x, (x.stride(1) if d > 1 else n), n
+        t = x.T.contiguous()
+        return t.T, n, n
+
+    def __call__(self, x):
+        """Update the tracker with the batch (unless read_only), return the normalised, clipped batch [N, d]."""
+        xv, ld_x, n = self._planes(x)
+        d = self.rms.d
+        if n == 0:
+            return xv
+        ld_y = (n + 63) // 64 * 64
+        if self._out is None or self._out.shape[1] != ld_y:
+            self._out = torch.empty((d, ld_y), dtype=torch.float32, device=self.device)
+        state_in, state_out = self.rms._records(not self.read_only)
+        with torch.cuda.device(self.device):
+            _capi.check(self.lib.scg_mean_std_normalize(xv.data_ptr(), self._out.data_ptr(), d, ld_x, ld_y, n,
+                                                        state_in.data_ptr(), _capi.ptr(state_out),
+                                                        self.rms._moments.data_ptr(), float(self.clip),
+                                                        float(self.epsilon), _stream(self.device)),
+                        'scg_mean_std_normalize')
+        return self._out[:, :n].T
+
+    def state_dict(self):
+        return {'mean': self.rms.mean.cpu().numpy(), 'var': self.rms.var.cpu().numpy()}
+
+    def load_state_dict(self, saved):
+        self.rms.set(mean=saved['mean'], var=saved['var'])
+
+
+class RewardStdNormalizer(MeanStdNormalizer):
+    """Reward normalisation by the running std of the discounted returns (normalization.py:150-190).
+
+    ``legacy_index_reset=True`` reproduces the reference's ``self.ret[dones.astype(np.long)] = 0`` literally (it
+    clears ret[0] / ret[1] according to the VALUES in dones); the default clears the returns of the finished envs,
+    which is what the comment above that line says it is for."""
+
+    def __init__(self, gamma=0.99, read_only=False, clip=10.0, epsilon=1e-8, device='cuda', legacy_index_reset=False):
+        super().__init__((), read_only, clip, epsilon, device=device)
+        self.gamma = gamma
+        self.ret = None
+        self.legacy_index_reset = legacy_index_reset
+
+    def __call__(self, x, dones):
+        x = torch.as_tensor(x, dtype=torch.float32, device=self.device).reshape(-1).contiguous()
+        n = x.shape[0]
+        if n == 0:
+            return x
+        dones = torch.as_tensor(dones, device=self.device).reshape(-1)
+        if dones.dtype not in (torch.bool, torch.uint8):
+            dones = dones != 0
+        dones = dones.contiguous()
+        if not self.read_only and self.ret is None:
+            self.ret = torch.zeros(n, dtype=torch.float32, device=self.device)
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        state_in, state_out = self.rms._records(not self.read_only)
+        with torch.cuda.device(self.device):
+            _capi.check(self.lib.scg_reward_normalize(x.data_ptr(), dones.data_ptr(), _capi.ptr(self.ret), out.data_ptr(),
+                                                      n, state_in.data_ptr(), _capi.ptr(state_out),
+                                                      self.rms._moments.data_ptr(), float(self.gamma), float(self.clip),
+                                                      float(self.epsilon), int(self.legacy_index_reset),
+                                                      _stream(self.device)), 'scg_reward_normalize')
+        return out
+
+
+class RescaleNormalizer(BaseNormalizer):
+    """Apply constant scaling (normalization.py:193-214)."""
+
+    def __init__(self, coef=1.0):
+        super().__init__()
+        self.coef = coef
+
+    def __call__(self, x):
+        if not isinstance(x, torch.Tensor):
+            x = np.asarray(x)
+        return self.coef * x
+
+
+class ImageNormalizer(RescaleNormalizer):
+    """Scale image pixels from [0, 255] to [0, 1] (normalization.py:217-223)."""
+
+    def __init__(self):
+        super().__init__(1.0 / 255)
+
+
+class ActionUnnormalizer(BaseNormalizer):
+    """Assumes the policy's action is in [-1, 1]; maps it to the env's bounds (normalization.py:226-248)."""
+
+    def __init__(self, action_space):
+        super().__init__()
+        assert hasattr(action_space, 'low') and hasattr(action_space, 'high'), 'action space must be a Box'
+        low, high = np.asarray(action_space.low), np.asarray(action_space.high)
+        self.mean = (low + high) / 2.0
+        self.std = (high - low) / 2.0
+
+    def __call__(self, action):
+        if isinstance(action, torch.Tensor):
+            f = dict(dtype=action.dtype, device=action.device)
+            return torch.as_tensor(self.mean, **f) + action * torch.as_tensor(self.std, **f)
+        return self.mean + np.asarray(action) * self.std

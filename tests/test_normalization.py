@@ -1,0 +1,155 @@
+"""running mean / std normalisers (math_and_models/normalization.py) on the device.
+
+The reference module cannot be imported here (gym is absent) and its tests hold no vectors for it, so the oracle
+(oracle/ref_normalization.py, a statement-by-statement restatement) is pinned analytically: Chan's pairwise update
+must reproduce np.mean / np.var of the concatenated stream.
+"""
+import numpy as np
+import pytest
+
+from oracle import ref_normalization as rn
+
+RTOL = 1e-5
+
+
+def test_oracle_running_stats_equal_stream_statistics():
+    rng = np.random.default_rng(0)
+    batches = [rng.normal(3.0, 2.0, size=(k, 5)) for k in (7, 1, 64, 300)]
+    rms = rn.RunningMeanStd(epsilon=1e-4, shape=(5,))
+    for b in batches:
+        rms.update(b)
+    # the prior is `epsilon` pseudo-samples of mean 0, var 1: fold it in exactly
+    allx = np.concatenate(batches)
+    n, eps = len(allx), 1e-4
+    mean = allx.sum(0) / (n + eps)
+    second = ((allx ** 2).sum(0) + eps * 1.0) / (n + eps)
+    assert np.allclose(rms.mean, mean, rtol=1e-12) and np.allclose(rms.var, second - mean ** 2, rtol=1e-10)
+    assert rms.count == pytest.approx(n + eps)
+
+
+def test_oracle_normaliser_known_answers():
+    norm = rn.MeanStdNormalizer(shape=(2,), clip=1.5, epsilon=0.0)
+    x = np.array([[0.0, 10.0], [2.0, 10.0], [4.0, 40.0]])
+    y = norm(x)
+    m, v = norm.rms.mean, norm.rms.var
+    assert np.allclose(m, x.sum(0) / (3 + 1e-4), rtol=1e-12)
+    assert np.allclose(y, np.clip((x - m) / np.sqrt(v), -1.5, 1.5)) and y.max() <= 1.5
+    frozen = rn.MeanStdNormalizer(shape=(2,), read_only=True)
+    assert np.allclose(frozen(x), np.clip(x / np.sqrt(1 + 1e-8), -10, 10))          # mean 0, var 1, no update
+    # reward normaliser: scaling only, by the std of the discounted return stream
+    r = rn.RewardStdNormalizer(gamma=0.5, clip=100.0, epsilon=0.0)
+    out = r(np.array([1.0, 3.0]), np.array([False, True]))
+    assert np.allclose(r.ret, [1.0, 0.0])                                           # finished env cleared
+    assert np.allclose(out, np.array([1.0, 3.0]) / np.sqrt(r.rms.var))
+    out = r(np.array([1.0, 1.0]), np.array([False, False]))
+    assert np.allclose(r.ret, [1.5, 1.0])
+    # the reference statement as written indexes with the VALUES of dones
+    q = rn.RewardStdNormalizer(gamma=0.5, legacy=True)
+    q(np.array([1.0, 3.0, 5.0]), np.array([False, False, True]))
+    assert np.allclose(q.ret, [0.0, 0.0, 5.0])                                      # ret[0] and ret[1] cleared, not ret[2]
+
+
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('d', [1, 4, 12, 36])
+def test_mean_std_normalizer_matches_oracle(gpu, d):
+    import torch
+    from safe_control_gym_amd.math_and_models.normalization import MeanStdNormalizer
+    rng = np.random.default_rng(d)
+    dev, ref = MeanStdNormalizer(shape=(d,), clip=5.0), rn.MeanStdNormalizer(shape=(d,), clip=5.0)
+    scale, shift = rng.uniform(0.01, 30.0, size=d), rng.normal(0, 50.0, size=d)      # |mean| >> std in some features
+    for n in (1, 63, 65, 1000, 4097, 7):
+        x = (rng.normal(size=(n, d)) * scale + shift).astype(np.float32)
+        y = dev(torch.as_tensor(x, device='cuda'))
+        y_ref = ref(x.astype(np.float64))
+        assert y.shape == (n, d)
+        assert np.abs(y.cpu().numpy() - y_ref).max() <= RTOL * 5.0, (n, d)
+        assert np.allclose(dev.rms.mean.cpu().numpy(), ref.rms.mean, rtol=1e-12, atol=1e-12)
+        assert np.allclose(dev.rms.var.cpu().numpy(), ref.rms.var, rtol=1e-10)
+        assert float(dev.rms.count) == pytest.approx(ref.rms.count, rel=1e-14)
+    # read_only: statistics frozen, same normalisation
+    dev.set_read_only(); ref.read_only = True
+    before = dev.state_dict()
+    x = (rng.normal(size=(300, d)) * scale + shift).astype(np.float32)
+    assert np.abs(dev(torch.as_tensor(x, device='cuda')).cpu().numpy() - ref(x.astype(np.float64))).max() <= RTOL * 5.0
+    after = dev.state_dict()
+    assert np.array_equal(before['mean'], after['mean']) and np.array_equal(before['var'], after['var'])
+    # state_dict round trip into a fresh normaliser (ppo.py:125,147)
+    fresh = MeanStdNormalizer(shape=(d,), clip=5.0, read_only=True)
+    fresh.load_state_dict(after)
+    assert torch.equal(fresh(torch.as_tensor(x, device='cuda')), dev(torch.as_tensor(x, device='cuda')))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('legacy', [False, True])
+def test_reward_std_normalizer_matches_oracle(gpu, legacy):
+    import torch
+    from safe_control_gym_amd.math_and_models.normalization import RewardStdNormalizer
+    rng = np.random.default_rng(3)
+    n = 777
+    dev = RewardStdNormalizer(gamma=0.97, clip=4.0, legacy_index_reset=legacy)
+    ref = rn.RewardStdNormalizer(gamma=0.97, clip=4.0, legacy=legacy)
+    for k in range(25):
+        rew = rng.normal(-1.0, 2.0, size=n).astype(np.float32)
+        done = rng.uniform(size=n) < (0.0 if k == 3 else 0.05)
+        out = dev(torch.as_tensor(rew, device='cuda'), torch.as_tensor(done, device='cuda'))
+        out_ref = ref(rew.astype(np.float64), done)
+        assert np.abs(out.cpu().numpy() - out_ref).max() <= RTOL * 4.0
+        assert np.abs(dev.ret.cpu().numpy() - ref.ret).max() <= 2e-5 * max(1.0, np.abs(ref.ret).max())
+        assert float(dev.rms.var) == pytest.approx(float(ref.rms.var), rel=1e-5)     # ret is kept in fp32 on the device
+    dev.set_read_only(); ref.read_only = True
+    ret_before = dev.ret.clone()
+    rew = rng.normal(size=n).astype(np.float32)
+    out = dev(torch.as_tensor(rew, device='cuda'), torch.zeros(n, dtype=torch.bool, device='cuda'))
+    assert np.abs(out.cpu().numpy() - ref(rew.astype(np.float64), np.zeros(n, bool))).max() <= RTOL * 4.0
+    assert torch.equal(dev.ret, ret_before)
+
+
+@pytest.mark.gpu
+def test_normalizers_on_the_env_buffers_zero_copy_and_at_scale(gpu):
+    """2^20 x 12 observations straight from the step kernel (no copy: the [N, d] view of the SoA planes), the
+    PPO rollout order of ppo.py:256-261, then the batch statistics of the output."""
+    import torch
+    import safe_control_gym_amd as scg
+    from safe_control_gym_amd.math_and_models.normalization import MeanStdNormalizer, RewardStdNormalizer
+    n = 1 << 20
+    env = scg.make('quadrotor', quad_type=3, num_envs=n, device='cuda', seed=5, randomized_init=True,
+                   task='traj_tracking', cost='quadratic')
+    obs_norm, rew_norm = MeanStdNormalizer(shape=(12,)), RewardStdNormalizer(gamma=0.99)
+    obs = env.reset()
+    assert obs.stride(0) == 1                                     # SoA view: taken without a copy
+    xv, ld, cnt = obs_norm._planes(obs)
+    assert xv.data_ptr() == obs.data_ptr() and ld == env.plane_stride and cnt == n
+    y = obs_norm(obs)
+    # first update: the running stats are the batch stats (up to the 1e-4 prior) -> output is standardised
+    live = obs.std(0) > 1e-6
+    assert torch.allclose(y.mean(0)[live], torch.zeros(12, device='cuda')[live], atol=2e-3)
+    assert torch.allclose(y.std(0)[live], torch.ones(12, device='cuda')[live], atol=2e-3)
+    a = torch.full((n, 4), float(env.U_GOAL[0]), device='cuda')
+    for _ in range(3):
+        obs, rew, done, _ = env.step(a)
+        y = obs_norm(obs)
+        r = rew_norm(rew, done)
+    assert torch.isfinite(y).all() and torch.isfinite(r).all() and float(y.abs().max()) <= 10.0
+    assert float(obs_norm.rms.count) == pytest.approx(4 * n + 1e-4)
+    ref_mean = obs.double().mean(0)
+    assert torch.isfinite(obs_norm.rms.mean).all() and obs_norm.rms.mean.shape == (12,)
+    env.close()
+
+
+@pytest.mark.gpu
+def test_normalizer_c_abi_validation(gpu):
+    import torch
+    from safe_control_gym_amd import _capi
+    lib = _capi.load()
+    x = torch.zeros((4, 64), device="cuda"); st = torch.zeros((2, 9), dtype=torch.float64, device="cuda")
+    mom = torch.zeros(512, dtype=torch.float64, device="cuda")
+    p = lambda t: t.data_ptr()
+    assert lib.scg_mean_std_normalize(None, p(x), 4, 64, 64, 10, p(st[0]), p(st[1]), p(mom), 10.0, 1e-8, None) < 0
+    assert lib.scg_mean_std_normalize(p(x), p(x), 4, 8, 64, 10, p(st[0]), p(st[1]), p(mom), 10.0, 1e-8, None) < 0     # ld < n
+    assert lib.scg_mean_std_normalize(p(x), p(x), 4, 64, 64, 10, p(st[0]), p(st[0]), p(mom), 10.0, 1e-8, None) < 0    # aliasing
+    assert lib.scg_mean_std_normalize(p(x), p(x), 4, 64, 64, 10, p(st[0]), p(st[1]), None, 10.0, 1e-8, None) < 0      # no scratch
+    assert lib.scg_mean_std_normalize(p(x), p(x), 0, 64, 64, 10, p(st[0]), p(st[1]), p(mom), 10.0, 1e-8, None) < 0
+    assert lib.scg_mean_std_normalize(p(x), p(x), 4, 64, 64, 0, p(st[0]), p(st[1]), p(mom), 10.0, 1e-8, None) == 0    # empty batch
+    assert lib.scg_reward_normalize(p(x), None, None, p(x), 10, p(st[0]), p(st[1]), p(mom), 0.99, 10.0, 1e-8, 0, None) < 0
+    assert lib.scg_reward_normalize(p(x), None, None, p(x), 10, p(st[0]), None, None, 0.99, 10.0, 1e-8, 0, None) == 0   # read-only

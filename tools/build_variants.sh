@@ -7,7 +7,7 @@ out="$root/safe_control_gym_amd/lib/variants"
 mkdir -p "$out"
 build() { # name, extra flags...
   local name="$1"; shift
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared "$@" -o "$out/$name.so" "$src/scg_kernels.hip" "$src/scg_gae.hip" "$src/scg_linearize.hip" "$src/scg_capi.hip" &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared "$@" -o "$out/$name.so" "$src/scg_kernels.hip" "$src/scg_gae.hip" "$src/scg_linearize.hip" "$src/scg_normalize.hip" "$src/scg_capi.hip" &
 }
 build base -fno-slp-vectorize
 build nt2 -fno-slp-vectorize -DSCG_NT=2
