@@ -35,6 +35,7 @@ extern "C" {
 #define SCG_MAX_QUADRATIC 4
 #define SCG_MAX_GOAL_HORIZON 8
 #define SCG_MAX_DISTURBANCES 4       /* per disturbance mode */
+#define SCG_STATS_STRIPES 64         /* rows of scg_step_io.stats */
 
 typedef enum scg_status {
     SCG_OK = 0,
@@ -158,7 +159,9 @@ typedef struct scg_step_io {
     float* terminal_obs;             /* nullable [nx][ld], written for done lanes only */
     float* last_ep_return;           /* nullable [n], written for done lanes only (info['episode']['r']) */
     int32_t* last_ep_length;         /* nullable [n] */
-    double* stats;                   /* nullable [8] batch sums, atomically accumulated:
+    double* stats;                   /* nullable [SCG_STATS_STRIPES][8] batch sums, accumulated with one f64 atomic per
+                                        wave and statistic; the waves spread over the stripes (same-address f64 atomics
+                                        serialise at ~40 ns each), the caller adds the stripes up.  Columns:
                                         0 sum reward, 1 #done, 2 #violation, 3 sum finished returns,
                                         4 sum finished lengths, 5 #truncated, 6-7 reserved */
     uint32_t reset_serial;           /* Philox counter word for resets happening in this call */

@@ -60,11 +60,15 @@ __global__ __launch_bounds__(256) void scg_gae_kernel(const float* __restrict__ 
         }
     }
     if (stats) {
+        // workgroup reduction first: same-address f64 atomics serialise, so one pair per workgroup, not per wave
+        __shared__ double red[8];
         s1 = wave_sum_d(s1);
         s2 = wave_sum_d(s2);
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&stats[0], s1);
-            atomicAdd(&stats[1], s2);
+        if ((threadIdx.x & 63) == 0) { red[(threadIdx.x >> 6) * 2] = s1; red[(threadIdx.x >> 6) * 2 + 1] = s2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(&stats[0], (red[0] + red[2]) + (red[4] + red[6]));
+            atomicAdd(&stats[1], (red[1] + red[3]) + (red[5] + red[7]));
         }
     }
 }

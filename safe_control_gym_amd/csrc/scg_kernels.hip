@@ -959,12 +959,14 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         st_rew = wave_sum(st_rew); st_done = wave_sum(st_done); st_viol = wave_sum(st_viol);
         st_fret = wave_sum(st_fret); st_flen = wave_sum(st_flen); st_trunc = wave_sum(st_trunc);
         if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&io.stats[0], (double)st_rew);
-            atomicAdd(&io.stats[1], (double)st_done);
-            atomicAdd(&io.stats[2], (double)st_viol);
-            atomicAdd(&io.stats[3], (double)st_fret);
-            atomicAdd(&io.stats[4], (double)st_flen);
-            atomicAdd(&io.stats[5], (double)st_trunc);
+            // one stripe per wave slot: 2^20 envs = 16384 waves -> 256 atomics per address instead of 16384
+            double* row = io.stats + 8 * ((blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) & (SCG_STATS_STRIPES - 1));
+            atomicAdd(&row[0], (double)st_rew);
+            atomicAdd(&row[1], (double)st_done);
+            atomicAdd(&row[2], (double)st_viol);
+            atomicAdd(&row[3], (double)st_fret);
+            atomicAdd(&row[4], (double)st_flen);
+            atomicAdd(&row[5], (double)st_trunc);
         }
     }
 }

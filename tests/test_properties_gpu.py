@@ -97,8 +97,8 @@ def test_rollout_equals_step_loop_and_stats(gpu):
     hi = torch.as_tensor(a_env.action_space.high, device='cuda')[None, :, None]
     acts = torch.rand((7, 4, ld), generator=g, device='cuda') * (hi - lo) + lo
     K = 20
-    stats = torch.zeros(8, dtype=torch.float64, device='cuda')
-    b_env._bufs['stats'] = stats
+    stripes = torch.zeros((64, 8), dtype=torch.float64, device='cuda')      # SCG_STATS_STRIPES rows, summed by the caller
+    b_env._bufs['stats'] = stripes
     rew_sum, done_sum, ret_sum, len_sum = 0.0, 0, 0.0, 0
     for k in range(K):
         obs, rew, done, info = a_env.step(acts[k % 7])
@@ -106,6 +106,7 @@ def test_rollout_equals_step_loop_and_stats(gpu):
         rew_sum += float(rew.double().sum()); done_sum += int(done.sum())
         ret_sum += float(info['episode']['r'][done].double().sum()); len_sum += int(info['episode']['l'][done].sum())
     assert torch.equal(a_env.state, b_env.state)
+    stats = stripes.sum(0)
     assert abs(float(stats[0]) - rew_sum) <= 1e-5 * abs(rew_sum) and int(stats[1]) == done_sum
     assert abs(float(stats[3]) - ret_sum) <= 1e-5 * abs(ret_sum) and int(stats[4]) == len_sum
     c_env = scg.make('quadrotor', num_envs=n, **kw)
