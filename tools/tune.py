@@ -38,9 +38,6 @@ def main():
     for f in sorted(os.listdir(vdir)):
         if f.endswith('.so'):
             arms.append((f[:-3], os.path.join(vdir, f), {}))
-    for v in ('base', 'nt2', 'nt3', 'b128'):
-        arms.append((v + '_', os.path.join(vdir, v + '.so'), {'SCG_LD_PAD': '17'}))
-    arms = [x for x in arms if x[2] != {}]
     if a.arms:
         keep = set(a.arms.split(','))
         arms = [x for x in arms if x[0] in keep]
