@@ -531,10 +531,12 @@ __device__ __forceinline__ PhysT<T> phys_of_env(const PhysT<T>& shared, const KT
 enum Feat : uint32_t {
     FT_TRACK = 1u,   // Task.TRAJ_TRACKING: LDS-staged X_GOAL table (else the constant stabilisation goal)
     FT_CON = 2u,     // a ConstraintList is attached
-    FT_EXTRA = 4u,   // everything else: disturbance planes, separate obs buffer (+noise, +goal horizon),
-                     // mse / goal_reached / truncated / terminal_obs / last_ep_* / stats outputs,
-                     // non-diagonal Q or R, normalised action space.  In this tier FT_TRACK / FT_CON
-                     // are run-time decisions again.
+    FT_EXTRA = 4u,   // everything else: disturbances, separate obs buffer (+noise, +goal horizon), per-env inertial
+                     // properties, stats sums, non-diagonal Q or R, normalised action space.  In this tier
+                     // FT_TRACK / FT_CON are run-time decisions again.
+    FT_INFO = 8u,    // the per-step info outputs of the default API (info_level='full'): mse / goal_reached /
+                     // truncated / terminal_obs (= the state: obs aliases it in this tier) / last_ep_*.  A tier of its
+                     // own because it is what make() gives by default: 43 us in the EXTRA tier at 2^20 envs.
 };
 
 // STRIDED: the grid is smaller than the batch and every lane walks several envs (LDS-staged table, tuning
@@ -558,6 +560,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                                                           const RolloutArgs ro) {
     constexpr int NX = Dim<SYS>::NX, NU = Dim<SYS>::NU, NV = NX + NU;
     constexpr bool EXTRA = (FT & FT_EXTRA) != 0;
+    constexpr bool INFO = (FT & (FT_EXTRA | FT_INFO)) != 0;
     constexpr bool STRIDED = MODE == MODE_STRIDED, FUSED = MODE == MODE_FUSED;
     extern __shared__ __align__(16) float s_ref[];
 
@@ -750,7 +753,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         }
 
         // ---- _get_info: mse (quadrotor.py:1015-1025)
-        if (EXTRA && io.mse) {
+        if (INFO && io.mse) {
             float m = 0.f;
 #pragma unroll
             for (int j = 0; j < NX; ++j) { const float w = e[j] * tb->mse_w[j]; m = fmaf(w, w, m); }
@@ -772,7 +775,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
             for (int j = 0; j < NX; ++j) inb &= (x[j] >= tb->oob_low[j]) & (x[j] <= tb->oob_high[j]);
             done |= !inb;
         }
-        if (EXTRA && io.goal_reached) stp(io.goal_reached, i, (uint8_t)(goal_reached ? 1 : 0));
+        if (INFO && io.goal_reached) stp(io.goal_reached, i, (uint8_t)(goal_reached ? 1 : 0));
 
         // ---- _get_reward (quadrotor.py:886-930)
         float rew;
@@ -825,7 +828,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         }
         bool truncated = false;
         if (t1 >= p.ctrl_steps) { truncated = !done; done = true; }         // :460-462
-        if (EXTRA && io.truncated) stp(io.truncated, i, (uint8_t)(truncated ? 1 : 0));
+        if (INFO && io.truncated) stp(io.truncated, i, (uint8_t)(truncated ? 1 : 0));
 
         // ---- VecRecordEpisodeStatistics (record_episode_statistics.py:144-160)
         epr += rew;
@@ -845,17 +848,18 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         // ---- auto-reset (dummy_vec_env.py:41-47): returned obs is the reset obs; the terminal one is stashed
         int t_out = t1;
         if (done) {
-            if (EXTRA) {
+            if (INFO) {
                 if (io.terminal_obs) {
                     // the observation step() would have returned without the auto-reset (dummy_vec_env.py:43):
                     // state (+ observation noise) + the goal extension of extend_obs(obs, t + 1)
 #pragma unroll
                     for (int j = 0; j < NX; ++j) {
-                        float o = x[j] + obs_noise[j];
-                        if (io.obs_noise) o += ldp(PL(io.obs_noise, j), i4);
+                        float o = x[j];
+                        if (EXTRA) o += obs_noise[j];
+                        if (EXTRA && io.obs_noise) o += ldp(PL(io.obs_noise, j), i4);
                         stp(PLS(io.terminal_obs, j), i4, o);
                     }
-                    if (p.obs_goal_horizon > 0) {
+                    if (EXTRA && p.obs_goal_horizon > 0) {
                         if (tracking) {
                             for (int k = 0; k < p.obs_goal_horizon; ++k) {
                                 float g[NX];
@@ -1524,11 +1528,11 @@ LaunchGeom step_geometry(const KParams& p, int system, int64_t n, int num_cus) {
 
 // Which instantiation covers this call.
 static uint32_t features_needed(const KParams& p, const scg_step_io& io) {
-    const bool extra = io.inertial || io.action_disturbance || io.dynamics_force || io.obs_noise || io.obs || io.truncated ||
-                       io.goal_reached || io.mse || io.terminal_obs || io.last_ep_return || io.last_ep_length ||
-                       io.stats || io.episode_id || p.dist || (p.flags & F_NORMALIZED) || !(p.flags & F_Q_DIAG);
+    const bool extra = io.inertial || io.action_disturbance || io.dynamics_force || io.obs_noise || io.obs || io.stats ||
+                       io.episode_id || p.dist || (p.flags & F_NORMALIZED) || !(p.flags & F_Q_DIAG);
     if (extra) return FT_TRACK | FT_CON | FT_EXTRA;
     uint32_t ft = 0;
+    if (io.truncated || io.goal_reached || io.mse || io.terminal_obs || io.last_ep_return || io.last_ep_length) ft |= FT_INFO;
     if (p.flags & F_TRACKING) ft |= FT_TRACK;
     if (p.n_con_rows > 0) ft |= FT_CON;
     return ft;
@@ -1552,6 +1556,10 @@ static void launch_step_ft(uint32_t ft, const LaunchGeom& g, const KParams& p, c
         case FT_TRACK: SCG_LAUNCH(FT_TRACK); break;
         case FT_CON: SCG_LAUNCH(FT_CON); break;
         case FT_TRACK | FT_CON: SCG_LAUNCH(FT_TRACK | FT_CON); break;
+        case FT_INFO: SCG_LAUNCH(FT_INFO); break;
+        case FT_INFO | FT_TRACK: SCG_LAUNCH(FT_INFO | FT_TRACK); break;
+        case FT_INFO | FT_CON: SCG_LAUNCH(FT_INFO | FT_CON); break;
+        case FT_INFO | FT_TRACK | FT_CON: SCG_LAUNCH(FT_INFO | FT_TRACK | FT_CON); break;
         default: SCG_LAUNCH(FT_TRACK | FT_CON | FT_EXTRA); break;
     }
 #undef SCG_LAUNCH
@@ -1563,7 +1571,7 @@ static bool packed_ok(const KParams& p, const scg_step_io& io, uint32_t ft) {
     // 155 VGPRs (3 waves/SIMD) and 8-byte streams lose more to exposed latency than that saves
     // (31.4 us vs 29.9 us at 2^20 envs).
     static const bool disabled = [] { const char* e = getenv("SCG_PACKED"); return !(e && e[0] == '1'); }();
-    if (disabled || (ft & FT_EXTRA) || io.state_lo || (p.flags & F_REF_IN_LDS) || (io.ld & 1)) return false;
+    if (disabled || (ft & (FT_EXTRA | FT_INFO)) || io.state_lo || (p.flags & F_REF_IN_LDS) || (io.ld & 1)) return false;
     auto al = [](const void* q, uintptr_t a) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) % a) == 0; };
     return al(io.state, 8) && al(io.action, 8) && al(io.step_count, 8) && al(io.reward, 8) && al(io.done, 2) &&
            al(io.ep_return, 8) && al(io.ep_length, 8) && al(io.reset_state, 4);
@@ -1606,7 +1614,7 @@ static void launch_step_sys(LaunchGeom g, const KParams& p, const scg_step_io& i
 
 // Fused multi-step rollout: lean tiers, float state, table gathered from global memory, exact-cover grid.
 bool fused_rollout_ok(const KParams& p, const scg_step_io& io) {
-    return !(features_needed(p, io) & FT_EXTRA) && !io.state_lo && !(p.flags & F_REF_IN_LDS);
+    return !(features_needed(p, io) & (FT_EXTRA | FT_INFO)) && !io.state_lo && !(p.flags & F_REF_IN_LDS);
 }
 
 template <int SYS>
