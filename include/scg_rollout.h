@@ -156,9 +156,15 @@ typedef struct scg_step_io {
     uint8_t* truncated;              /* nullable [n] info["TimeLimit.truncated"] */
     uint8_t* goal_reached;           /* nullable [n] */
     float* mse;                      /* nullable [n] */
-    float* terminal_obs;             /* nullable [nx][ld], written for done lanes only */
-    float* last_ep_return;           /* nullable [n], written for done lanes only (info['episode']['r']) */
-    int32_t* last_ep_length;         /* nullable [n] */
+    float* terminal_record;          /* nullable [n][terminal_stride] row-major, written for done lanes only -- one dense
+                                        record per env instead of obs_dim + 2 scattered 4-byte stores (each of those is a
+                                        read-modify-write of a whole DRAM burst):
+                                        [0, obs_dim)  the observation step() would have returned without the auto-reset
+                                                      (info['terminal_observation'], dummy_vec_env.py:43);
+                                        [obs_dim]     the finished episode's return (float), [obs_dim + 1] its length
+                                                      (int32 bits) -- info['episode']['r' / 'l']
+                                                      (record_episode_statistics.py:155-158); 0 without ep_return */
+    int64_t terminal_stride;         /* floats per record: a multiple of 4, >= obs_dim + 2 */
     double* stats;                   /* nullable [SCG_STATS_STRIPES][8] batch sums, accumulated with one f64 atomic per
                                         wave and statistic; the waves spread over the stripes (same-address f64 atomics
                                         serialise at ~40 ns each), the caller adds the stripes up.  Columns:

@@ -485,6 +485,9 @@ int scg_step(scg_handle* h, const scg_step_io* io, int64_t n, void* stream) {
         return fail(SCG_ERR_INVALID, "scg_step: obs_goal_horizon > 0 needs an obs buffer (obs does not alias state)");
     if (io->obs_noise && !io->obs)
         return fail(SCG_ERR_INVALID, "scg_step: obs_noise needs an obs buffer");
+    if (io->terminal_record && (io->terminal_stride < h->obs_dim + 2 || (io->terminal_stride & 3)))
+        return fail(SCG_ERR_INVALID, "scg_step: terminal_stride must be a multiple of 4 and >= obs_dim + 2 = %d (got %lld)",
+                    h->obs_dim + 2, (long long)io->terminal_stride);
     if (int rc = check_dist_io(h, io, "scg_step")) return rc;
     if (n == 0) return SCG_OK;
     if (n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_step: n > 2^30 envs per device (32-bit lane offsets)");

@@ -535,7 +535,7 @@ enum Feat : uint32_t {
                      // properties, stats sums, non-diagonal Q or R, normalised action space.  In this tier
                      // FT_TRACK / FT_CON are run-time decisions again.
     FT_INFO = 8u,    // the per-step info outputs of the default API (info_level='full'): mse / goal_reached /
-                     // truncated / terminal_obs (= the state: obs aliases it in this tier) / last_ep_*.  A tier of its
+                     // truncated / terminal_record (terminal obs = the state: obs aliases it in this tier).  A tier of its
                      // own because it is what make() gives by default: 43 us in the EXTRA tier at 2^20 envs.
 };
 
@@ -849,15 +849,18 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         int t_out = t1;
         if (done) {
             if (INFO) {
-                if (io.terminal_obs) {
-                    // the observation step() would have returned without the auto-reset (dummy_vec_env.py:43):
-                    // state (+ observation noise) + the goal extension of extend_obs(obs, t + 1)
+                if (io.terminal_record) {
+                    // one dense record per finished env: the observation step() would have returned without the
+                    // auto-reset (dummy_vec_env.py:43: state (+ observation noise) + the goal extension of
+                    // extend_obs(obs, t + 1)), then the finished episode's return and length
+                    float* rec = io.terminal_record + (int64_t)i * io.terminal_stride;
+                    int od = NX;
 #pragma unroll
                     for (int j = 0; j < NX; ++j) {
                         float o = x[j];
                         if (EXTRA) o += obs_noise[j];
                         if (EXTRA && io.obs_noise) o += ldp(PL(io.obs_noise, j), i4);
-                        stp(PLS(io.terminal_obs, j), i4, o);
+                        rec[j] = o;
                     }
                     if (EXTRA && p.obs_goal_horizon > 0) {
                         if (tracking) {
@@ -865,16 +868,18 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                                 float g[NX];
                                 load_goal<NX>(p, ref, t + 1 + k, g);
 #pragma unroll
-                                for (int j = 0; j < NX; ++j) stp(PLS(io.terminal_obs, NX * (1 + k) + j), i4, g[j]);
+                                for (int j = 0; j < NX; ++j) rec[NX * (1 + k) + j] = g[j];
                             }
+                            od = NX * (1 + p.obs_goal_horizon);
                         } else {
 #pragma unroll
-                            for (int j = 0; j < NX; ++j) stp(PLS(io.terminal_obs, NX + j), i4, tb->x_goal[j]);
+                            for (int j = 0; j < NX; ++j) rec[NX + j] = tb->x_goal[j];
+                            od = 2 * NX;
                         }
                     }
+                    rec[od] = epr;
+                    rec[od + 1] = __int_as_float(epl);
                 }
-                if (io.last_ep_return) stp(io.last_ep_return, i4, epr);
-                if (io.last_ep_length) stp(io.last_ep_length, i4, epl);
             }
         }
         const bool need_reset = done && (p.flags & F_AUTO_RESET);
@@ -1532,7 +1537,7 @@ static uint32_t features_needed(const KParams& p, const scg_step_io& io) {
                        io.episode_id || p.dist || (p.flags & F_NORMALIZED) || !(p.flags & F_Q_DIAG);
     if (extra) return FT_TRACK | FT_CON | FT_EXTRA;
     uint32_t ft = 0;
-    if (io.truncated || io.goal_reached || io.mse || io.terminal_obs || io.last_ep_return || io.last_ep_length) ft |= FT_INFO;
+    if (io.truncated || io.goal_reached || io.mse || io.terminal_record) ft |= FT_INFO;
     if (p.flags & F_TRACKING) ft |= FT_TRACK;
     if (p.n_con_rows > 0) ft |= FT_CON;
     return ft;

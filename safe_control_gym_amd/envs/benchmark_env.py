@@ -378,12 +378,11 @@ class BenchmarkEnv:
         if self.INFO_LEVEL == 'full':
             b['mse'] = torch.zeros(ld, dtype=f32, device=dev)
             b['truncated'] = torch.zeros(ld, dtype=torch.bool, device=dev)
-            b['terminal_obs'] = torch.zeros((self.obs_dim, ld), dtype=f32, device=dev)
+            # one dense row per env: terminal observation | finished-episode return | length (int32 bits), written by
+            # the lanes that finish an episode (a multiple of 8 floats: whole 32-byte DRAM sectors)
+            b['terminal_record'] = torch.zeros((ld, (self.obs_dim + 2 + 7) // 8 * 8), dtype=f32, device=dev)
             if self.TASK == Task.STABILIZATION and self.COST == Cost.QUADRATIC:
                 b['goal_reached'] = torch.zeros(ld, dtype=torch.bool, device=dev)
-            if self.TRACK_EPISODE_STATS:
-                b['last_ep_return'] = torch.zeros(ld, dtype=f32, device=dev)
-                b['last_ep_length'] = torch.zeros(ld, dtype=torch.int32, device=dev)
         self._bufs = b
         self._reset_state_buf = None
         self._bound = False
@@ -399,10 +398,11 @@ class BenchmarkEnv:
             info['constraint_violation'] = b['constraint_violation'][:n]
         if 'truncated' in b:
             info['TimeLimit.truncated'] = b['truncated'][:n]
-        if 'terminal_obs' in b:
-            info['terminal_observation'] = b['terminal_obs'][:, :n].T
-        if 'last_ep_return' in b:
-            info['episode'] = {'r': b['last_ep_return'][:n], 'l': b['last_ep_length'][:n]}
+        if 'terminal_record' in b:
+            rec, od = b['terminal_record'], self.obs_dim
+            info['terminal_observation'] = rec[:n, :od]
+            if self.TRACK_EPISODE_STATS:
+                info['episode'] = {'r': rec[:n, od], 'l': rec.view(torch.int32)[:n, od + 1]}
         self._info_views = info
         self._out_views = ((b['obs'] if 'obs' in b else b['state'])[:, :n].T, b['reward'][:n], b['done'][:n])
 

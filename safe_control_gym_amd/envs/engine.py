@@ -72,11 +72,13 @@ class Engine:
     _IO_FIELDS = ('action', 'action_disturbance', 'dynamics_force', 'obs_noise', 'reset_state', 'inertial', 'state',
                   'state_lo', 'step_count', 'ep_return', 'ep_length', 'episode_id', 'obs', 'reward', 'done',
                   'constraint_values', 'constraint_violation', 'truncated', 'goal_reached', 'mse',
-                  'terminal_obs', 'last_ep_return', 'last_ep_length', 'stats')
+                  'terminal_record', 'stats')
 
     def _bind(self, bufs, ld):
         io = self._io
         io.ld = ld
+        rec = bufs.get('terminal_record')
+        io.terminal_stride = rec.shape[1] if rec is not None else 0
         for name in self._IO_FIELDS:
             t = bufs.get(name)
             setattr(io, name, None if t is None else t.data_ptr())
