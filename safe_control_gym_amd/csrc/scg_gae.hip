@@ -18,6 +18,11 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+#ifndef SCG_GAE_DEPTH
+#define SCG_GAE_DEPTH 4        // time steps whose loads are in flight together
+#endif
+constexpr int kGaeDepth = SCG_GAE_DEPTH;
+
 __global__ __launch_bounds__(256) void scg_gae_kernel(const float* __restrict__ rew, const float* __restrict__ val,
                                                       const float* __restrict__ mask, const float* __restrict__ term_val,
                                                       const float* __restrict__ last_val, float* __restrict__ ret_out,
@@ -29,34 +34,60 @@ __global__ __launch_bounds__(256) void scg_gae_kernel(const float* __restrict__ 
         float ret = last_val[i];                     // ppo_utils.py:440: ret, adv = last_val, 0
         float v_next = ret;                          // vals[T] = last_val (:441)
         float adv = 0.f;
-        // software pipeline: the four loads of step t-1 are issued before the arithmetic of step t
+        // The scan over t is sequential per lane, so bandwidth comes from bytes in flight: the loads of kGaeDepth steps
+        // are issued together (4 steps x 3-4 planes x 256 B per wave) before the dependent arithmetic of those steps.
+        // Measured at T = 128 x 2^20: depth 1 / 2 / 4 / 8 = 0.568 / 0.563 / 0.515-0.564 / 0.532 ms -- within the box-to-box
+        // noise of each other (~5 TB/s either way); 4 is kept.
+        constexpr int D = kGaeDepth;
         int t = T - 1;
-        float r = rew[(int64_t)t * ld + i], v = val[(int64_t)t * ld + i], m = mask[(int64_t)t * ld + i];
-        float tv = term_val ? term_val[(int64_t)t * ld + i] : 0.f;
-        for (; t >= 0; --t) {
-            float rn = 0.f, vn = 0.f, mn = 0.f, tvn = 0.f;
-            if (t > 0) {
-                const int64_t o = (int64_t)(t - 1) * ld + i;
-                rn = rew[o]; vn = val[o]; mn = mask[o];
-                tvn = term_val ? term_val[o] : 0.f;
+        for (; t >= D - 1; t -= D) {
+            float r[D], v[D], m[D], tv[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const int64_t o = (int64_t)(t - k) * ld + i;
+                r[k] = __builtin_nontemporal_load(rew + o);
+                v[k] = __builtin_nontemporal_load(val + o);
+                m[k] = __builtin_nontemporal_load(mask + o);
+                tv[k] = term_val ? __builtin_nontemporal_load(term_val + o) : 0.f;
             }
-            const float rr = fmaf(gamma, tv, r);                              // :443 rews += gamma * terminal_vals
-            const float gm = gamma * m;
-            ret = fmaf(gm, ret, rr);                                          // :446
-            if (use_gae) {
-                const float td = fmaf(gm, v_next, rr) - v;                    // :450
-                adv = fmaf(adv * lam, gm, td);                                // :451
-            } else {
-                adv = ret - v;                                                // :448
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const float rr = fmaf(gamma, tv[k], r[k]);                    // :443 rews += gamma * terminal_vals
+                const float gm = gamma * m[k];
+                ret = fmaf(gm, ret, rr);                                      // :446
+                if (use_gae) {
+                    const float td = fmaf(gm, v_next, rr) - v[k];             // :450
+                    adv = fmaf(adv * lam, gm, td);                            // :451
+                } else {
+                    adv = ret - v[k];                                         // :448
+                }
+                const int64_t o = (int64_t)(t - k) * ld + i;
+                __builtin_nontemporal_store(ret, ret_out + o);
+                __builtin_nontemporal_store(adv, adv_out + o);
+                if (rew_out) __builtin_nontemporal_store(rr, rew_out + o);
+                s1 += (double)adv;
+                s2 += (double)adv * (double)adv;
+                v_next = v[k];
             }
+        }
+        for (; t >= 0; --t) {                                                 // the T mod D oldest steps
             const int64_t o = (int64_t)t * ld + i;
+            const float r = rew[o], v = val[o], m = mask[o], tv = term_val ? term_val[o] : 0.f;
+            const float rr = fmaf(gamma, tv, r);
+            const float gm = gamma * m;
+            ret = fmaf(gm, ret, rr);
+            if (use_gae) {
+                const float td = fmaf(gm, v_next, rr) - v;
+                adv = fmaf(adv * lam, gm, td);
+            } else {
+                adv = ret - v;
+            }
             ret_out[o] = ret;
             adv_out[o] = adv;
             if (rew_out) rew_out[o] = rr;
             s1 += (double)adv;
             s2 += (double)adv * (double)adv;
             v_next = v;
-            r = rn; v = vn; m = mn; tv = tvn;
         }
     }
     if (stats) {

@@ -13,6 +13,6 @@ build base -fno-slp-vectorize
 build nt2 -fno-slp-vectorize -DSCG_NT=2
 build b128 -fno-slp-vectorize -DSCG_BLOCK=128
 build lin_ep8 -fno-slp-vectorize -DSCG_LIN_EP3=8
-build lin_ep64 -fno-slp-vectorize -DSCG_LIN_EP3=64 -DSCG_LIN_BLOCK=64
+build gae1 -fno-slp-vectorize -DSCG_GAE_DEPTH=1
 wait
 ls -la "$out"
