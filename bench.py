@@ -5,12 +5,15 @@ Contract (see the build prompt): ``python bench.py --gpus N --steps K --warmup W
 ONE JSON line.  A "step" is one pass of the hot path (one ``scg_step`` kernel launch) over one batch
 of synthetic input: every env of the batch advances by one control step.
 
-Workloads (BASELINE.json ``configs``):
-  * N = 1  -> C4: Quadrotor-3D trajectory tracking, 2^20 envs, quadratic cost, RK4, auto-reset;
-              algorithmic bytes B = 8 nx + 4 nu + 13 = 125 per env-step.
-  * N > 1  -> C5: the same per GPU (weak scaling, envs sharded by contiguous global index) with
-              per-env episode-return tracking (B = 141) and one RCCL all-gather of the episode
-              returns every 300 steps (= one episode) inside the timed region.
+Workload (BASELINE.json ``configs``) -- the SAME per-GPU work at every N, so that the
+per-N values measure scaling and nothing else:
+  * C4 = Quadrotor-3D trajectory tracking, 2^20 envs per GPU, quadratic cost, RK4, auto-reset, with the per-env
+    episode-return tracking every vectorised caller of the reference has (VecRecordEpisodeStatistics):
+    algorithmic bytes B = 8 nx + 4 nu + 13 + 16 = 141 per env-step.
+  * N > 1 -> C5: that shard on every GPU (weak scaling, envs sharded by contiguous global index) plus one RCCL
+    all-gather of the episode returns every 300 steps (= one episode) inside the timed region.
+  * At N = 1 the line also carries ``c4_without_episode_stats``: the bare 125-byte step (``--no-episode-stats``
+    makes it the primary measurement).
 Actions are i.i.d. U(a_low, a_high) float32, pre-generated on the device ([300, nu, N]) and reused
 cyclically; initial / reset states are nominal + the reference's uniform offsets (Philox on device).
 Inputs are resident in HBM when the timed region starts.
@@ -31,7 +34,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MI
 def build_env(args, rank, world):
     import safe_control_gym_amd as scg
     n = args.envs_per_gpu
-    track = world > 1 or args.episode_stats
+    track = not args.no_episode_stats
     common = dict(num_envs=n, device='cuda', seed=1337, env_index_base=rank * n, randomized_init=True,
                   info_level='minimal', track_episode_stats=track, ctrl_freq=60, pyb_freq=240, episode_len_sec=5)
     import yaml
@@ -117,12 +120,14 @@ def main():
     ap.add_argument('--steps', type=int, default=3000)
     ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--envs-per-gpu', type=int, default=1 << 20)
-    ap.add_argument('--workload', default=None, help='c4 (default at 1 GPU), c5 (default at >1), c3, c2')
-    ap.add_argument('--episode-stats', action='store_true', help='track episode returns at 1 GPU too (B += 16)')
+    ap.add_argument('--workload', default=None, help='c4 (default; called c5 when sharded over > 1 GPU), c3, c2')
+    ap.add_argument('--episode-stats', action='store_true', help='(default now) track episode returns (B += 16)')
+    ap.add_argument('--no-episode-stats', action='store_true', help='bare step without episode-return tracking (1 GPU only)')
     ap.add_argument('--action-period', type=int, default=300)
     ap.add_argument('--python-loop', action='store_true', help='also time env.step() called from Python per step')
     ap.add_argument('--fused', action='store_true', help='also time the one-launch multi-step rollout (own byte count)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-bare', action='store_true', help='skip the secondary c4_without_episode_stats measurement')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--env-kw', action='append', default=[], help='extra make() kwargs key=value (yaml), for experiments')
     args = ap.parse_args()
@@ -137,7 +142,9 @@ def main():
             raise SystemExit('--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`'
                              % (args.gpus, args.gpus))
     if args.workload is None:
-        args.workload = 'c4' if world == 1 else 'c5'
+        args.workload = 'c4' if world == 1 else 'c5'        # same env; 'c5' = sharded + all-gather
+    if world > 1 and args.no_episode_stats:
+        raise SystemExit('--no-episode-stats is a single-GPU option (the sharded run gathers the episode returns)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
@@ -211,6 +218,25 @@ def main():
                  'note': 'scg_rollout_fused: ONE launch for all steps, envs stay in registers; not comparable with the '
                          'per-step roofline above (its algorithmic bytes are 4*nu per env-step); VALU-bound'}
 
+    bare = None
+    if world == 1 and not args.no_episode_stats and not args.no_bare and args.workload == 'c4' and not args.env_kw:
+        # the same step without episode-return tracking (B = 125): the bare C4 roofline number
+        args.no_episode_stats = True
+        env2, _, bytes2 = build_env(args, rank, world)
+        args.no_episode_stats = False
+        env2.reset()
+        env2.rollout(actions, steps=args.warmup)
+        torch.cuda.synchronize()
+        b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        b0.record()
+        env2.rollout(actions, steps=args.steps)
+        b1.record()
+        torch.cuda.synchronize()
+        bus = b0.elapsed_time(b1) * 1e3 / args.steps
+        bare = {'value': n / (bus * 1e-6), 'unit': 'env-steps/s', 'bytes_per_env_step': bytes2, 'kernel_us_per_launch': bus,
+                'achieved_GBs': bytes2 * n / (bus * 1e-6) / 1e9, 'frac': bytes2 * n / (bus * 1e-6) / 1e9 / HBM_PEAK_GBS}
+        env2.close()
+
     if rank == 0:
         kernel_us = dev_ms * 1e3 / args.steps            # HIP-event time over the timed region / launches
         achieved = bytes_per * n / (kernel_us * 1e-6) / 1e9
@@ -218,7 +244,7 @@ def main():
         tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
         if os.path.exists(tpath):
             with open(tpath) as f:
-                rec = json.load(f).get(args.workload if (world == 1 and not args.episode_stats) else 'c5', {})
+                rec = json.load(f).get(args.workload if args.no_episode_stats else 'c5', {}) if args.workload in ('c4', 'c5') else {}
             if rec.get('envs', 1 << 20) == n and not args.env_kw:       # counters were collected at this size only
                 traffic = rec.get('bytes_per_launch')
         out = {
@@ -226,7 +252,9 @@ def main():
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': '%s: %s' % (args.workload.upper(), wname), 'envs_per_gpu': n,
+            'config': {'workload': '%s: %s%s' % (args.workload.upper(), wname,
+                                                  '' if args.no_episode_stats else ' + per-env episode-return tracking'),
+                       'envs_per_gpu': n,
                        'total_envs': n * world, 'bytes_per_env_step': bytes_per,
                        'launch': 'one fused scg_step kernel per step (scg_rollout issues the launches)',
                        'sharding': 'envs block-sharded by global index; all-gather of episode returns every '
@@ -235,6 +263,8 @@ def main():
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'kernel_us_per_launch': kernel_us, 'algorithmic_bytes_per_launch': bytes_per * n},
         }
+        if bare is not None:
+            out['c4_without_episode_stats'] = bare
         if py_value is not None:
             out['python_step_api_value'] = py_value
         if fused is not None:
