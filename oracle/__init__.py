@@ -13,6 +13,11 @@ reference's step path, function for function, each citing the reference
 "vector env" here is a Python ``for`` over single-env objects, exactly like the
 reference's ``DummyVecEnv``.
 
+Modules: ``ref_model`` / ``ref_env`` / ``ref_constraints`` / ``ref_trajectory`` / ``ref_vec`` (the step path),
+``philox`` (the reset / noise generator), ``ref_disturbances`` (envs/disturbances.py), ``ref_ppo`` (returns / GAE),
+``ref_linearize`` (df_func Jacobians, discretisation, quadratic loss), ``ref_normalization`` (running mean / std
+normalisers), ``independent`` (sympy / DOP853 cross-check), ``c/`` + ``c_port`` (plain-C port = CPU baseline).
+
 Pinning status
 --------------
 * The reference cannot be imported in the build container (``casadi``,
@@ -25,7 +30,13 @@ Pinning status
   (b) an independent re-derivation of the dynamics with sympy and a
   high-accuracy ``scipy.integrate.solve_ivp`` integration
   (``oracle/independent.py``), and (c) the one importable reference module,
-  ``safe_control_gym.envs.disturbances`` (used when generating fixtures).
+  ``safe_control_gym.envs.disturbances``, RUN in the build container with a stub ``np_random`` to record
+  ``tests/golden/disturbances.json`` (``tests/golden/make_golden_disturbances.py``); ``ref_disturbances``
+  reproduces those recordings to 1e-13.
+* ``ref_linearize`` differentiates the reference's matrix-form dynamics symbolically (the sympy analogue of the
+  reference's ``cs.jacobian``) and is cross-checked by central differences; ``ref_normalization`` restates
+  ``math_and_models/normalization.py`` (not importable: it imports gym) and is pinned by the identity "Chan's
+  update == statistics of the concatenated stream".
 * PyBullet and CVODES numerics: **parity unpinned** (third-party native code,
   absent here, no reference fixture covers them).  CartPole: **parity
   unpinned** (no CartPole environment exists in this fork of the reference).
