@@ -271,6 +271,12 @@ int scg_normalize_advantages(float* adv, const double* stats, int32_t T, int64_t
  * (pole_length, pole_mass, cart_mass, -); NULL uses the handle's nominal constants.  Outputs are row-major
  * batches dfdx [n][nx][nx], dfdu [n][nx][nu].  disc_dt > 0 applies discretize_linear_system(exact=False)
  * (controllers/mpc/mpc_utils.py:51-54, controllers/lqr/lqr_utils.py:39-60): Ad = I + A dt, Bd = B dt. */
+/* SymbolicModel.fc_func (symbolic_systems.py:68) and fd_func (:70-73) for n explicit (x, u) pairs: xdot = f(x, u) and/or
+ * xnext = one control step of the handle's integrator (RK4 / Euler, its sub-steps) with zero-order-hold input -- the
+ * engine's discretisation, where the reference's fd_func integrates with CVODES.  Same plane conventions as scg_linearize
+ * (`input` is the model input; inertial nullable).  xdot and xnext are [nx][ld] planes, each nullable, not both. */
+int scg_model_eval(scg_handle* h, const float* state, const float* input, const float* inertial, float* xdot,
+                   float* xnext, int64_t ld, int64_t n, void* stream);
 int scg_linearize(scg_handle* h, const float* state, const float* input, const float* inertial, float* dfdx,
                   float* dfdu, double disc_dt, int64_t ld, int64_t n, void* stream);
 /* Quadratic stage cost and gradients (quadrotor.py:678-682, symbolic_systems.py:94-123):

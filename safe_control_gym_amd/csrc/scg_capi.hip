@@ -559,6 +559,17 @@ int scg_normalize_advantages(float* adv, const double* stats, int32_t T, int64_t
     return SCG_OK;
 }
 
+int scg_model_eval(scg_handle* h, const float* state, const float* input, const float* inertial, float* xdot,
+                   float* xnext, int64_t ld, int64_t n, void* stream) {
+    if (!h) return fail(SCG_ERR_INVALID, "scg_model_eval: null handle");
+    if (!state || !input || (!xdot && !xnext)) return fail(SCG_ERR_INVALID, "scg_model_eval: null argument");
+    if (n < 0 || ld < n) return fail(SCG_ERR_INVALID, "scg_model_eval: need 0 <= n <= ld");
+    if (n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_model_eval: n > 2^30");
+    if (n == 0) return SCG_OK;
+    HIP_TRY(launch_model_eval(h->system, h->kp, h->d_tb, state, input, inertial, xdot, xnext, ld, n, (hipStream_t)stream));
+    return SCG_OK;
+}
+
 int scg_linearize(scg_handle* h, const float* state, const float* input, const float* inertial, float* dfdx,
                   float* dfdu, double disc_dt, int64_t ld, int64_t n, void* stream) {
     if (!h) return fail(SCG_ERR_INVALID, "scg_linearize: null handle");

@@ -1475,6 +1475,55 @@ __global__ __launch_bounds__(kBlock) void scg_reset_kernel(const KParams p, cons
 }
 
 // ------------------------------------------------------------------------------------------
+// stand-alone prior-model evaluation: SymbolicModel.fc_func (symbolic_systems.py:68) and fd_func (:70-73, here the
+// engine's own fixed-step integrator instead of CVODES) for n explicit (x, u) pairs -- what model-based callers
+// (controllers/mpc/mpc.py:136-139 rollouts of the prior) ask of env.symbolic.  `input` is the MODEL input u
+// (thrusts / cart force): no clipping, no motor map, no disturbance.
+// ------------------------------------------------------------------------------------------
+template <int SYS>
+__global__ __launch_bounds__(kBlock) void scg_model_kernel(const KParams p, const KTables* __restrict__ tb,
+                                                           const float* __restrict__ state,
+                                                           const float* __restrict__ input,
+                                                           const float* __restrict__ inertial,
+                                                           float* __restrict__ xdot, float* __restrict__ xnext,
+                                                           int64_t ld, uint32_t n) {
+    constexpr int NX = Dim<SYS>::NX, NU = Dim<SYS>::NU;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const uint32_t i4 = i * 4u;
+        float x[NX], u[NU];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) x[j] = ldp(PL(state, j), i4);
+#pragma unroll
+        for (int j = 0; j < NU; ++j) u[j] = ldp(PL(input, j), i4);
+        PhysT<float> ph = p.ph;
+        if (inertial) {
+            float prop[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) prop[q] = ldp(PL(inertial, q), i4);
+            ph = phys_of_env<SYS, float>(p.ph, tb, prop);
+        }
+        Inputs<SYS, float> in;
+        make_inputs<SYS, float>(ph, u, 0.f, 0.f, 0.f, in);
+        if (xdot) {
+            float d[NX];
+            f_eval<SYS, float>(ph, in, x, d);
+#pragma unroll
+            for (int j = 0; j < NX; ++j) stp(PL(xdot, j), i4, d[j]);
+        }
+        if (xnext) {
+            for (int s = 0; s < p.substeps; ++s) {
+                float inc[NX];
+                integrate<SYS, float>(ph, p.flags, in, x, inc);
+#pragma unroll
+                for (int j = 0; j < NX; ++j) x[j] += inc[j];
+            }
+#pragma unroll
+            for (int j = 0; j < NX; ++j) stp(PL(xnext, j), i4, x[j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // stand-alone ConstraintList.get_values (constraints.py:503-520)
 // ------------------------------------------------------------------------------------------
 template <int SYS>
@@ -1717,6 +1766,23 @@ hipError_t launch_eval_constraints(int system, const ConTable* ct, const float* 
             break;
         default:
             return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_model_eval(int system, const KParams& p, const KTables* tb, const float* state, const float* input,
+                             const float* inertial, float* xdot, float* xnext, int64_t ld, int64_t n64, hipStream_t s) {
+    const uint32_t n = (uint32_t)n64;
+    int64_t blocks = (n64 + kBlock - 1) / kBlock;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 65536) blocks = 65536;
+    dim3 grid((unsigned)blocks), block(kBlock);
+    switch (system) {
+        case SCG_QUAD_1D: hipLaunchKernelGGL(scg_model_kernel<SCG_QUAD_1D>, grid, block, 0, s, p, tb, state, input, inertial, xdot, xnext, ld, n); break;
+        case SCG_QUAD_2D: hipLaunchKernelGGL(scg_model_kernel<SCG_QUAD_2D>, grid, block, 0, s, p, tb, state, input, inertial, xdot, xnext, ld, n); break;
+        case SCG_QUAD_3D: hipLaunchKernelGGL(scg_model_kernel<SCG_QUAD_3D>, grid, block, 0, s, p, tb, state, input, inertial, xdot, xnext, ld, n); break;
+        case SCG_CARTPOLE: hipLaunchKernelGGL(scg_model_kernel<SCG_CARTPOLE>, grid, block, 0, s, p, tb, state, input, inertial, xdot, xnext, ld, n); break;
+        default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }

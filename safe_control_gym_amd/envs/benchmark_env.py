@@ -471,6 +471,31 @@ class BenchmarkEnv:
         buf[:, :n] = a.T
         return buf, self._ld
 
+    def _model_planes(self, state, input):
+        xs, ldx = self._planes(state, self.state_dim, default=self._bufs['state'])
+        us, ldu = self._planes(input, self.action_dim, default=np.asarray(self.U_EQ, dtype=np.float64))
+        if ldx != ldu:                                     # bring both to the env's own plane stride
+            xs = self._planes(xs[:, :self.num_envs].T, self.state_dim)[0] if ldx != self._ld else xs
+            us = self._planes(us[:, :self.num_envs].T, self.action_dim)[0] if ldu != self._ld else us
+            ldx = self._ld
+        inertial = self._bufs.get('inertial') if ldx == self._ld else None
+        return xs, us, inertial, ldx
+
+    def model_dynamics(self, state=None, input=None):
+        """Batched ``symbolic.fc_func`` (symbolic_systems.py:68): ``x_dot = f(x, u)`` [N, nx] for each env's (state, input)
+        (defaults as in ``linearize``)."""
+        self._ensure_engine()
+        xs, us, inertial, ld = self._model_planes(state, input)
+        return self._engine.model_eval(xs, us, inertial, self.num_envs, ld, True, False)[0][:, :self.num_envs].T
+
+    def model_step(self, state=None, input=None):
+        """Batched ``symbolic.fd_func`` (symbolic_systems.py:70-73): the state after one control step of the prior model
+        under zero-order-hold input, [N, nx], WITHOUT touching the envs -- the engine's own RK4 / Euler discretisation
+        (the reference integrates with CVODES)."""
+        self._ensure_engine()
+        xs, us, inertial, ld = self._model_planes(state, input)
+        return self._engine.model_eval(xs, us, inertial, self.num_envs, ld, False, True)[1][:, :self.num_envs].T
+
     def linearize(self, state=None, input=None, discrete=False):
         """Batched ``symbolic.df_func`` (symbolic_systems.py:77-92) on the device: Jacobians of the continuous
         dynamics about each env's (state, input) -> ``(dfdx [N, nx, nx], dfdu [N, nx, nu])`` float32 tensors.
@@ -480,13 +505,7 @@ class BenchmarkEnv:
         (mpc_utils.py:51-54): ``Ad = I + A dt``, ``Bd = B dt`` with ``dt = CTRL_TIMESTEP``.  Per-env inertial
         properties are used when ``randomized_inertial_prop`` is on."""
         self._ensure_engine()
-        xs, ldx = self._planes(state, self.state_dim, default=self._bufs['state'])
-        us, ldu = self._planes(input, self.action_dim, default=np.asarray(self.U_EQ, dtype=np.float64))
-        if ldx != ldu:                                     # bring both to the env's own plane stride
-            xs = self._planes(xs[:, :self.num_envs].T, self.state_dim)[0] if ldx != self._ld else xs
-            us = self._planes(us[:, :self.num_envs].T, self.action_dim)[0] if ldu != self._ld else us
-            ldx = self._ld
-        inertial = self._bufs.get('inertial') if ldx == self._ld else None
+        xs, us, inertial, ldx = self._model_planes(state, input)
         return self._engine.linearize(xs, us, inertial, self.num_envs, ldx,
                                       self.CTRL_TIMESTEP if discrete else 0.0)
 

@@ -129,6 +129,16 @@ class Engine:
                                                       self._stream()), 'scg_eval_constraints')
         return out[:self.num_device_rows, :n].T
 
+    def model_eval(self, state_soa, input_soa, inertial_soa, n, ld, want_xdot, want_xnext):
+        """Batched fc_func / fd_func (symbolic_systems.py:68-73): ([nx, ld] xdot or None, [nx, ld] xnext or None)."""
+        mk = lambda: torch.empty((self.nx, ld), dtype=torch.float32, device=self.device)
+        xdot, xnext = (mk() if want_xdot else None), (mk() if want_xnext else None)
+        with torch.cuda.device(self.device):
+            _capi.check(self.lib.scg_model_eval(self.handle, _capi.ptr(state_soa), _capi.ptr(input_soa),
+                                                _capi.ptr(inertial_soa), _capi.ptr(xdot), _capi.ptr(xnext), ld, n,
+                                                self._stream()), 'scg_model_eval')
+        return xdot, xnext
+
     def linearize(self, state_soa, input_soa, inertial_soa, n, ld, disc_dt=0.0):
         """Batched df_func (symbolic_systems.py:77-92): ([n, nx, nx], [n, nx, nu]) for SoA planes [.][ld]."""
         A = torch.empty((n, self.nx, self.nx), dtype=torch.float32, device=self.device)

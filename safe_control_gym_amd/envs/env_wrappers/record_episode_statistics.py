@@ -1,7 +1,8 @@
 """Episode statistics for the batched env (reference: env_wrappers/record_episode_statistics.py:92-169).
 
 The per-env accumulators (``episode_return[i] += r``, ``episode_length[i] += 1``, flush on done,
-:144-160) are fused into the step kernel (``ep_return`` / ``ep_length`` planes, ``last_ep_*`` on done);
+:144-160) are fused into the step kernel (``ep_return`` / ``ep_length`` planes; the finished episode lands in the
+env's ``terminal_record`` row);
 this wrapper exposes them under the reference's names and keeps the ``return_queue`` /
 ``length_queue`` deques by copying ONLY the finished episodes to the host when asked.
 """

@@ -98,10 +98,14 @@ class AnalyticModel:
         return np.stack([np.broadcast_to(np.asarray(v, dtype=np.float64), shape) for v in comps], -1)
 
     def fc_func(self, x, u):
+        if _is_device_tensor(x):
+            return {'f': self._backend().model_dynamics(x, u)}
         return {'f': self._f(x, u)}
 
     def fd_func(self, x0, p):
-        """One RK4 step of length dt with zero-order-hold input p."""
+        """One RK4 step of length dt with zero-order-hold input p (device tensors: the env's own integrator)."""
+        if _is_device_tensor(x0):
+            return {'xf': self._backend().model_step(x0, p)}
         x0 = np.asarray(x0, dtype=np.float64)
         dt = self.dt
         k1 = self._f(x0, p)

@@ -270,3 +270,44 @@ def test_linearize_c_abi_rejects_bad_arguments(gpu):
     assert lib.scg_linearize(eng.handle, p(st), p(ac), None, p(A), p(B), 0.0, env._ld, 0, None) == 0   # empty batch
     assert b'ld' in lib.scg_last_error() or lib.scg_last_error() is not None
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('system', SYSTEMS)
+def test_model_eval_matches_oracle(gpu, system):
+    """env.symbolic.fc_func / fd_func on device tensors: x_dot = f(x, u) and one zero-order-hold step of the env's
+    integrator for explicit (x, u) pairs, without touching the envs (symbolic_systems.py:68-73)."""
+    import torch
+    n = 333
+    env = _make(system, n, ctrl_freq=50, pyb_freq=50)
+    env.reset()
+    before = env.state.clone()
+    rng = np.random.default_rng(21)
+    xs, us = sample(system, n, rng)
+    xt = torch.as_tensor(xs, dtype=torch.float32, device='cuda')
+    ut = torch.as_tensor(us, dtype=torch.float32, device='cuda')
+    f_dev = env.symbolic.fc_func(xt, ut)['f'].cpu().numpy().astype(np.float64)
+    x_dev = env.symbolic.fd_func(xt, ut)['xf'].cpu().numpy().astype(np.float64)
+    assert torch.equal(env.state, before)                                  # the envs were not advanced
+    p = params_of(system)
+    x32, u32 = xs.astype(np.float32).astype(np.float64), us.astype(np.float32).astype(np.float64)
+    dt = env.CTRL_TIMESTEP
+    for k in range(n):
+        f_ref = np.asarray(F[system](list(x32[k]), list(u32[k]), p))
+        x_ref = np.asarray(ref_model.rk4_step(F[system], list(x32[k]), list(u32[k]), p, dt))
+        # f is a sum of terms that cancel (torque rows: 2005 N^-1 s^-2 times thrust differences; T/m against g):
+        # the 1e-5 bound is relative to the size of those terms, |A||x| + |B||u| (+ gravity), not to the cancelled sum
+        A, B = ref_linearize.df(system, x32[k], u32[k], p)
+        scale = 1.0 + np.abs(A) @ np.abs(x32[k]) + np.abs(B) @ np.abs(u32[k]) + p.g
+        assert np.max(np.abs(f_dev[k] - f_ref) / scale) <= RTOL, (k, f_dev[k], f_ref)
+        assert np.max(np.abs(x_dev[k] - x_ref) / np.maximum(np.abs(x_ref), 1.0 + dt * scale)) <= RTOL, (k, x_dev[k], x_ref)
+    # consistency with the env itself: stepping the envs from these states with the same (in-bounds) inputs
+    if system != 'cartpole':
+        env2 = _make(system, n, ctrl_freq=50, pyb_freq=50, done_on_out_of_bound=False, auto_reset=False)
+        env2.reset()
+        env2.state[:] = xt
+        env2.step(ut)
+        # same integrator; step() additionally sends the thrusts through the motor map round trip (quadrotor_utils.py:21-67)
+        assert torch.allclose(env2.state, env.model_step(xt, ut), rtol=1e-5, atol=2e-5)
+        env2.close()
+    env.close()
