@@ -189,3 +189,68 @@ def test_c_abi_edge_cases(gpu):
     stab = scg.make('quadrotor', quad_type=2, num_envs=4, device='cuda')
     stab.reset()
     assert lib.scg_set_reference(stab._engine.handle, tab, 10) == -1
+
+
+BASELINE_CASES = [
+    # BASELINE.json configs[1..3] at their full sizes (C2, C3, C4)
+    ('C2_cartpole_64k', 'cartpole', 1 << 16, dict(task='stabilization', cost='quadratic', ctrl_freq=50, pyb_freq=50)),
+    ('C3_quad2d_256k_bounded', 2, 1 << 18,
+     dict(task='stabilization', cost='rl_reward', ctrl_freq=60, pyb_freq=240,
+          constraints=[{'constraint_form': 'bounded_constraint', 'constrained_variable': 'state', 'active_dims': [0, 2, 4],
+                        'lower_bounds': [-2, 0, -0.5], 'upper_bounds': [2, 2, 0.5]}])),
+    ('C4_quad3d_1M_tracking', 3, 1 << 20, dict(task='traj_tracking', cost='quadratic', ctrl_freq=60, pyb_freq=240)),
+]
+
+
+@pytest.mark.parametrize('name,system,n,kw', BASELINE_CASES, ids=[c[0] for c in BASELINE_CASES])
+def test_sampled_oracle_parity_at_baseline_sizes(gpu, name, system, n, kw):
+    """The full-size batch free-runs with i.i.d. uniform actions (the benchmark's recipe); at every checked step 256
+    randomly chosen envs are handed to the float64 oracle -- their state and counter BEFORE the step, the same
+    action -- and next state / reward / done / constraint values / terminal observation must agree to 1e-5.
+    The sample is redrawn every step, so it also lands on envs that were reset through the Philox path."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import RTOL, rel_err
+    from oracle.ref_env import RefEnv
+    make = (lambda **k: scg.make('cartpole', **k)) if system == 'cartpole' else (lambda **k: scg.make('quadrotor', quad_type=system, **k))
+    env = make(num_envs=n, device='cuda', seed=1337, randomized_init=True, **kw)
+    env.reset()
+    okw = {k: v for k, v in kw.items()}
+    ref = RefEnv(system=system, randomized_init=False, **okw)           # its state is overwritten before every step
+    ref.reset()
+    rng = np.random.default_rng(7)
+    g = torch.Generator(device='cuda'); g.manual_seed(3)
+    lo = torch.as_tensor(env.action_space.low, device='cuda')
+    hi = torch.as_tensor(env.action_space.high, device='cuda')
+    worst, dones_seen = 0.0, 0
+    for k in range(24):
+        act = torch.rand((n, env.action_dim), generator=g, device='cuda') * (hi - lo) + lo
+        idx = rng.choice(n, 256, replace=False)
+        it = torch.as_tensor(idx, device='cuda')
+        x0 = env.state[it].cpu().numpy().astype(np.float64)
+        t0 = env.ctrl_step_counter[it].cpu().numpy()
+        a = act[it].cpu().numpy().astype(np.float64)
+        obs, rew, done, info = env.step(act)
+        obs_s, rew_s, done_s = obs[it].cpu().numpy(), rew[it].cpu().numpy(), done[it].cpu().numpy()
+        term = info['terminal_observation'][it].cpu().numpy()
+        cv = info['constraint_values'][it].cpu().numpy() if 'constraint_values' in info else None
+        for j in range(256):
+            ref.state = x0[j].copy()
+            ref.ctrl_step_counter = int(t0[j])
+            o_r, r_r, d_r, inf_r = ref.step(a[j])
+            if system == 3 and abs(ref.state[7]) >= 1.5:           # crossed the Euler-angle singularity: done only
+                assert bool(done_s[j]) == bool(d_r)
+                continue
+            assert bool(done_s[j]) == bool(d_r), (name, k, j)
+            e = abs(float(rew_s[j]) - r_r) / max(abs(r_r), 1.0)
+            nxt = term[j][:len(o_r)] if d_r else obs_s[j]          # a finished env already shows its reset observation
+            e = max(e, rel_err(nxt, o_r))
+            if cv is not None:
+                e = max(e, rel_err(cv[j], inf_r['constraint_values']))
+            assert e <= RTOL, (name, k, j, e)
+            worst = max(worst, e)
+            dones_seen += int(d_r)
+    assert dones_seen > 0
+    print('%s: worst rel err %.3e over 24 x 256 sampled env-steps (%d episode ends)' % (name, worst, dones_seen))
+    env.close()
