@@ -59,7 +59,8 @@ def build_env(args, rank, world):
     nx, nu = env.state_dim, env.action_dim
     bytes_per = 8 * nx + 4 * nu + 13
     if track:
-        bytes_per += 16                                  # ep_return + ep_length read-modify-write
+        bytes_per += 16                                  # ep_return + ep_length read-modify-write (141 B for C5);
+        # the engine moves 8 of them: under auto-reset the episode length IS the step counter, so no ep_length plane exists
     if env.constraints is not None:
         bytes_per += 4 * env.constraints.num_device_rows + 1
     return env, name, bytes_per
@@ -256,6 +257,7 @@ def main():
                                                   '' if args.no_episode_stats else ' + per-env episode-return tracking'),
                        'envs_per_gpu': n,
                        'total_envs': n * world, 'bytes_per_env_step': bytes_per,
+                       'moved_bytes_per_env_step': bytes_per - (8 if not args.no_episode_stats else 0),
                        'launch': 'one fused scg_step kernel per step (scg_rollout issues the launches)',
                        'sharding': 'envs block-sharded by global index; all-gather of episode returns every '
                                    '%d steps' % gather_every if world > 1 else 'single GPU'},

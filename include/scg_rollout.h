@@ -144,7 +144,8 @@ typedef struct scg_step_io {
     float* state_lo;                 /* nullable [nx][ld] compensation residual (state = hi + lo) */
     int32_t* step_count;             /* [n] ctrl_step_counter */
     float* ep_return;                /* nullable [n] running episode return (record_episode_statistics.py:145) */
-    int32_t* ep_length;              /* nullable [n] */
+    int32_t* ep_length;              /* nullable [n]; NULL: the episode length is read off step_count (the two are equal
+                                        whenever finished envs are reset, i.e. with cfg.auto_reset) */
     uint32_t* episode_id;            /* nullable [n] serial of the reset that began the env's episode; needed only
                                         when a disturbance draws its step_offset per episode */
     /* out */

@@ -595,7 +595,9 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         }
         L.epr = 0.f; L.epl = 0;
         if (io.ep_return) L.epr = ldp(io.ep_return, b4);
-        if (io.ep_length) L.epl = ldp(io.ep_length, b4);
+        // without an ep_length plane the episode length is the step counter (identical under auto-reset: both count the
+        // steps since the last reset) -- 8 bytes of read-modify-write per env-step that need not exist
+        L.epl = io.ep_length ? ldp(io.ep_length, b4) : L.t;
         L.fx = L.fy = L.fz = 0.f;
         if (EXTRA && io.dynamics_force) {
             L.fx = ldp(PL(io.dynamics_force, 0), b4); L.fy = ldp(PL(io.dynamics_force, 1), b4);
@@ -1268,7 +1270,7 @@ __global__ __launch_bounds__(kBlock) void scg_step2_kernel(const KParams p, cons
         L.epr = (f2){0.f, 0.f};
         L.epl = (i2){0, 0};
         if (io.ep_return) L.epr = ldp2<f2>(io.ep_return, b4);
-        if (io.ep_length) L.epl = ldp2<i2>(io.ep_length, b4);
+        L.epl = io.ep_length ? ldp2<i2>(io.ep_length, b4) : L.t;
     };
     const uint32_t stride = gridDim.x * kBlock;
     uint32_t pr = blockIdx.x * kBlock + threadIdx.x;

@@ -369,7 +369,8 @@ class BenchmarkEnv:
             b['inertial'] = torch.zeros((4, ld), dtype=f32, device=dev)
         if self.TRACK_EPISODE_STATS:
             b['ep_return'] = torch.zeros(ld, dtype=f32, device=dev)
-            b['ep_length'] = torch.zeros(ld, dtype=torch.int32, device=dev)
+            if not self.AUTO_RESET:          # with auto-reset the episode length IS the step counter: no second plane
+                b['ep_length'] = torch.zeros(ld, dtype=torch.int32, device=dev)
         if self.constraints is not None:
             b['constraint_values'] = torch.zeros((self.constraints.num_device_rows, ld), dtype=f32, device=dev)
             b['constraint_violation'] = torch.zeros(ld, dtype=torch.uint8, device=dev)
@@ -440,7 +441,7 @@ class BenchmarkEnv:
 
     @property
     def episode_length(self):
-        return self._bufs['ep_length'][:self.num_envs]
+        return self._bufs.get('ep_length', self._bufs['step_count'])[:self.num_envs]
 
     @property
     def current_raw_input_action(self):
