@@ -73,6 +73,9 @@ class LazyInfoList:
         if 'TimeLimit.truncated' in info and bool(info['TimeLimit.truncated'][i]):
             out['TimeLimit.truncated'] = True       # benchmark_env.py:460-462 (key absent before the limit)
         if done:
+            # DummyVecEnv.step_wait stashes the finished step's info and observation (dummy_vec_env.py:41-47); callers
+            # read e.g. info['n'][i]['terminal_info']['TimeLimit.truncated'] (controllers/ppo/ppo.py:265-269)
+            out['terminal_info'] = dict(out)
             if 'terminal_observation' in info:
                 out['terminal_observation'] = info['terminal_observation'][i].cpu().numpy()
             if 'episode' in info:

@@ -150,6 +150,12 @@ def test_vec_env_protocol_and_episode_statistics(gpu):
     assert venv.get_attr('CTRL_FREQ')[0] == 60 and len(venv.get_attr('CTRL_FREQ')) == 512
     per_env = info['n'][0]
     assert 'constraint_values' in per_env and 'mse' in per_env
+    # the reference's per-env dict of a finished env (dummy_vec_env.py:41-47; read by ppo.py:265-269)
+    i_done = int(torch.nonzero(done)[0]) if bool(done.any()) else None
+    if i_done is not None:
+        fin = info['n'][i_done]
+        assert fin['terminal_observation'].shape == (6,) and 'mse' in fin['terminal_info'] and 'episode' in fin
+        assert fin['terminal_info'].get('TimeLimit.truncated', False) == bool(info['TimeLimit.truncated'][i_done])
     venv.close()
 
 
