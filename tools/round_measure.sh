@@ -13,7 +13,7 @@ echo "== bench c4"; python bench.py --python-loop --fused > "$out/bench_c4.json"
 echo "== bench c4 without episode-return tracking (bare 125-byte step)"; python bench.py --no-episode-stats --no-cpu-baseline > "$out/bench_c4_bare.json" 2>/dev/null; cat "$out/bench_c4_bare.json"
 echo "== bench c3"; python bench.py --workload c3 --envs-per-gpu 262144 --steps 5000 --fused > "$out/bench_c3.json" 2>/dev/null; cat "$out/bench_c3.json"
 echo "== bench c2"; python bench.py --workload c2 --envs-per-gpu 65536 --steps 10000 --fused > "$out/bench_c2.json" 2>/dev/null; cat "$out/bench_c2.json"
-echo "== N sweep"; for e in 10 12 14 16 18 20 22; do python bench.py --envs-per-gpu $((1<<e)) --steps 2000 --no-cpu-baseline --no-episode-stats 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read()); print('N=2^$e  %.3e env-steps/s  %.2f us/step  frac %.3f' % (j['value'], j['roofline']['kernel_us_per_launch'], j['roofline']['frac']))"; done | tee "$out/n_sweep.txt"
+echo "== N sweep"; for e in 10 12 14 16 18 20 22 23; do python bench.py --envs-per-gpu $((1<<e)) --steps 2000 --no-cpu-baseline --no-episode-stats 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read()); print('N=2^$e  %.3e env-steps/s  %.2f us/step  frac %.3f' % (j['value'], j['roofline']['kernel_us_per_launch'], j['roofline']['frac']))"; done | tee "$out/n_sweep.txt"
 echo "== precise mode"; python bench.py --no-cpu-baseline --no-episode-stats --steps 1500 --env-kw compensated_state=true > "$out/bench_c4_precise.json" 2>/dev/null; python -c "import json; j=json.load(open('$out/bench_c4_precise.json')); print('precise mode %.3e env-steps/s %.2f us' % (j['value'], j['roofline']['kernel_us_per_launch']))"
 echo "== disturbed step (white action + uniform force + white obs noise, drawn in the kernel)"; python bench.py --no-cpu-baseline --steps 1000 --env-kw 'disturbances={action: [{disturbance_func: white_noise, std: 0.002}], dynamics: [{disturbance_func: uniform, low: [-0.05, -0.05, -0.05], high: [0.05, 0.05, 0.05]}], observation: [{disturbance_func: white_noise, std: 0.01}]}' --env-kw info_level=full > "$out/bench_c4_disturbed.json" 2>/dev/null; python -c "import json; j=json.load(open('$out/bench_c4_disturbed.json')); print('disturbed %.3e env-steps/s %.2f us' % (j['value'], j['roofline']['kernel_us_per_launch']))"
 echo "== linearize"; python tools/bench_linearize.py 3 2>/dev/null | tail -1 | tee "$out/bench_linearize.json"; python tools/bench_linearize.py 2 2>/dev/null | tail -1 | tee -a "$out/bench_linearize.json"
