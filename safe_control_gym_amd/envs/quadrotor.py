@@ -238,6 +238,15 @@ class Quadrotor(BenchmarkEnv):
                                       self.CTRL_TIMESTEP)
         self.symbolic.device_backend = weakref.proxy(self)
 
+    def _get_reset_info(self):
+        """quadrotor.py:1134-1200 (the keys that exist without gates / obstacles / PyBullet)."""
+        info = super()._get_reset_info()
+        info['nominal_physical_parameters'] = {'quadrotor_mass': self.MASS, 'quadrotor_ixx_inertia': self.J[0, 0],
+                                               'quadrotor_iyy_inertia': self.J[1, 1], 'quadrotor_izz_inertia': self.J[2, 2]}
+        info['quadrotor_kf'] = self.KF
+        info['quadrotor_km'] = self.KM
+        return info
+
     def _inertial_nominal(self):
         return [self.MASS, self.J[0, 0], self.J[1, 1], self.J[2, 2]]
 
