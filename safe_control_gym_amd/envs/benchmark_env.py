@@ -208,6 +208,35 @@ class BenchmarkEnv:
         self._engine_dirty = True
         return [seed]
 
+    # -- checkpoint / resume of the simulation state (the reference checkpoints only the policy side and the envs' RNG
+    #    states, controllers/ppo/ppo.py:115-155 + dummy_vec_env.py:88-100; here the env state is a handful of tensors) ----
+    _CHECKPOINT_PLANES = ('state', 'state_lo', 'step_count', 'ep_return', 'ep_length', 'inertial', 'episode_id')
+
+    def state_dict(self):
+        """Everything a resumed run needs to continue bit for bit: the device planes that persist across steps, the
+        position of the Philox streams (seed, step serial) and the per-env nominal reset states.  ``torch.save``-able."""
+        self._ensure_engine()
+        return {'num_envs': self.num_envs, 'plane_stride': self._ld, 'seed': self._seed, 'serial': self._serial,
+                'initial_reset': self.initial_reset,
+                'planes': {k: self._bufs[k].clone() for k in self._CHECKPOINT_PLANES if k in self._bufs},
+                'reset_state': None if self._reset_state_buf is None else self._reset_state_buf.clone()}
+
+    def load_state_dict(self, sd):
+        if sd['num_envs'] != self.num_envs:
+            raise ValueError('[ERROR] checkpoint holds %d envs, this env has %d.' % (sd['num_envs'], self.num_envs))
+        if sd['seed'] != self._seed:
+            self.seed(sd['seed'])
+        self._ensure_engine()
+        if sd['plane_stride'] != self._ld or set(sd['planes']) != {k for k in self._CHECKPOINT_PLANES if k in self._bufs}:
+            raise ValueError('[ERROR] checkpoint was taken from a differently configured env.')
+        for k, v in sd['planes'].items():
+            self._bufs[k].copy_(v)
+        self._reset_state_buf = None if sd['reset_state'] is None else sd['reset_state'].to(self.device).clone()
+        self._serial = int(sd['serial'])
+        self.initial_reset = bool(sd['initial_reset'])
+        self._bound = False
+        self._raw_action = None
+
     def set_cost_function_param(self, Q, R):
         """benchmark_env.py:237-254."""
         if not self.initial_reset:

@@ -260,3 +260,35 @@ def test_sampled_oracle_parity_at_baseline_sizes(gpu, name, system, n, kw):
     assert dones_seen > 0
     print('%s: worst rel err %.3e over 24 x 256 sampled env-steps (%d episode ends)' % (name, worst, dones_seen))
     env.close()
+
+
+def test_checkpoint_resume_is_bit_exact(gpu):
+    """state_dict() / load_state_dict(): a fresh env restored from a mid-rollout snapshot continues bit for bit --
+    states, rewards, dones, the Philox reset draws and the in-kernel disturbance draws (the
+    reference checkpoints only the policy side and the envs' RNG states, ppo.py:115-155)."""
+    import io
+    n = 5000
+    kw = dict(quad_type=2, num_envs=n, device='cuda', seed=9, randomized_init=True, randomized_inertial_prop=True,
+              task='traj_tracking', cost='quadratic', episode_len_sec=0.5,
+              disturbances={'dynamics': [{'disturbance_func': 'white_noise', 'std': 0.02}],
+                            'action': [{'disturbance_func': 'impulse', 'magnitude': 0.05, 'step_offset': None, 'duration': 3}]})
+    a = scg.make('quadrotor', **kw)
+    a.reset()
+    g = torch.Generator(device='cuda'); g.manual_seed(5)
+    lo, hi = float(a.action_space.low[0]), float(a.action_space.high[0])
+    acts = [torch.rand((n, 2), generator=g, device='cuda') * (hi - lo) + lo for _ in range(50)]
+    for k in range(20):
+        a.step(acts[k])
+    buf = io.BytesIO()
+    torch.save(a.state_dict(), buf)                       # through a real serialisation round trip
+    outs_a = [tuple(t.clone() for t in a.step(acts[k])[:3]) for k in range(20, 50)]
+    b = scg.make('quadrotor', **dict(kw, seed=1))         # different seed: load_state_dict must bring the right one
+    buf.seek(0)
+    b.load_state_dict(torch.load(buf, weights_only=True))
+    for k in range(20, 50):
+        ob, rb, db = b.step(acts[k])[:3]
+        oa, ra, da = outs_a[k - 20]
+        assert torch.equal(ob, oa) and torch.equal(rb, ra) and torch.equal(db, da), k
+    assert torch.equal(a.state, b.state) and torch.equal(a.episode_return, b.episode_return)
+    assert int(sum(int(o[2].sum()) for o in outs_a)) > n          # episodes ended and were re-drawn after the snapshot
+    a.close(), b.close()
