@@ -10,7 +10,10 @@ build() { # name, extra flags...
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared "$@" -o "$out/$name.so" "$src/scg_kernels.hip" "$src/scg_gae.hip" "$src/scg_linearize.hip" "$src/scg_normalize.hip" "$src/scg_capi.hip" &
 }
 build base -fno-slp-vectorize
+build nt2 -fno-slp-vectorize -DSCG_NT=2
+build b128 -fno-slp-vectorize -DSCG_BLOCK=128
 build w5 -fno-slp-vectorize -DSCG_MIN_WAVES=5
-build w6 -fno-slp-vectorize -DSCG_MIN_WAVES=6
+build lin_ep8 -fno-slp-vectorize -DSCG_LIN_EP3=8
+build gae1 -fno-slp-vectorize -DSCG_GAE_DEPTH=1
 wait
 ls -la "$out"
