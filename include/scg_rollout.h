@@ -106,6 +106,15 @@ typedef struct scg_config {
     int32_t randomized_inertial;
     int32_t reserved2;
     double inertial_rand_low[4], inertial_rand_high[4];
+    /* Physics.PYB_GND / PYB_DRAG (base_aviary.py:35-45,437-500) as zero-order-hold terms of the analytic model
+     * (quadrotor only): ground effect -- every propeller's thrust scaled by 1 + gnd_eff_coeff (prop_radius / (4 h_i))^2,
+     * h_i = max(height of propeller i, gnd_eff_h_clip), while |roll|, |pitch| < pi/2 (:459-463), re-evaluated at every
+     * integration sub-step; drag -- the reference's R (R (k * v)) force with k = -drag_coeff * sum_i 2 pi rpm_i / 60
+     * (:487-490; applied in the link frame, hence the second rotation), held over the control step.  Downwash
+     * (:498-520) acts between drones of one env and does not exist for a single drone. */
+    int32_t ground_effect, drag;
+    double gnd_eff_coeff, prop_radius, gnd_eff_h_clip;
+    double drag_coeff_xy, drag_coeff_z;
     uint64_t seed;                   /* Philox key */
     int64_t env_index_base;          /* global index of this shard's env 0 (seed + rank analogue,
                                         env_wrappers/vectorized_env/__init__.py:29) */

@@ -85,7 +85,7 @@ class RefEnv:
                  norm_act_scale=0.1, obs_goal_horizon=0, rew_state_weight=1.0, rew_act_weight=0.0001,
                  rew_exponential=True, done_on_out_of_bound=True, info_mse_metric_state_weight=None,
                  # analytic-engine args
-                 integrator='rk4', substeps=1, motor_map=True,
+                 integrator='rk4', substeps=1, motor_map=True, ground_effect=False, drag=False,
                  # oracle-only plumbing
                  reset_sampler=None, env_index=0, inertial_sampler=None):
         self.system = system
@@ -115,6 +115,7 @@ class RefEnv:
         self.rew_exponential = rew_exponential
         self.done_on_out_of_bound = done_on_out_of_bound
         self.integrator, self.substeps, self.use_motor_map = integrator, int(substeps), motor_map
+        self.ground_effect, self.drag = bool(ground_effect), bool(drag)     # Physics.PYB_GND / PYB_DRAG analogues
         self.reset_sampler, self.env_index = reset_sampler, env_index
         self.inertial_sampler = inertial_sampler      # (env_index, episode) -> offsets added to (M, Ixx, Iyy, Izz)
         self.episode_index = -1
@@ -324,13 +325,19 @@ class RefEnv:
         return list(thrust)
 
     def _advance_simulation(self, u, fext):
-        """Replaces base_aviary.py:266-322: ``substeps`` fixed steps of dt/substeps, ZOH input."""
+        """Replaces base_aviary.py:266-322: ``substeps`` fixed steps of dt/substeps, ZOH input.  With ``aero`` the drag
+        force (held from the start of the control step) joins the external force and the ground effect rescales the
+        thrusts at the start of every sub-step (base_aviary.py:293-305)."""
         f = rm.F_BY_SYSTEM[self.system]
         step = rm.INTEGRATORS[self.integrator]
         h = self.CTRL_TIMESTEP / self.substeps
         x = list(self.state)
+        if self.drag and self.system != 'cartpole':
+            d = rm.drag_force(self.system, x, u, self.params)
+            fext = tuple(fext[i] + d[i] for i in range(3))
         for _ in range(self.substeps):
-            x = step(f, x, u, self.params, h, fext)
+            ue = rm.ground_effect_thrusts(self.system, x, u, self.params) if (self.ground_effect and self.system != 'cartpole') else u
+            x = step(f, x, ue, self.params, h, fext)
         self.state = np.array(x)
 
     def _get_observation(self):

@@ -22,6 +22,8 @@ CF2X = dict(
     M=0.03454, L=0.0397, IXX=1.4e-5, IYY=1.4e-5, IZZ=2.17e-5,
     KF=3.16e-10, KM=7.94e-12,
     PWM2RPM_SCALE=0.2685, PWM2RPM_CONST=4070.3, MIN_PWM=20000.0, MAX_PWM=65535.0,
+    THRUST2WEIGHT_RATIO=2.25, GND_EFF_COEFF=11.36859, PROP_RADIUS=2.31348e-2, DRAG_COEFF_XY=9.1785e-7,
+    DRAG_COEFF_Z=10.311e-7,                                          # assets/cf2x.urdf:5
 )
 GRAVITY_ACC = 9.8  # base_aviary.py:90
 
@@ -197,3 +199,60 @@ def motor_map(thrust, p):
         rpm = p.pwm2rpm_scale * pwm + p.pwm2rpm_const
         out.append(n_motor * p.kf * rpm * rpm)
     return out
+
+
+# --- base_aviary.py:437-500: aero terms of Physics.PYB_GND / PYB_DRAG, restated for the analytic model -------------
+# "Parity unpinned": the reference applies these forces inside PyBullet; here they enter the prior model as
+# zero-order-hold inputs (drag from the state at the start of the control step, ground effect per integration sub-step).
+def gnd_eff_h_clip():
+    """base_aviary.py:141-147 (computed from the URDF mass)."""
+    max_rpm2 = CF2X['THRUST2WEIGHT_RATIO'] * GRAVITY_ACC * CF2X['M'] / (4 * CF2X['KF'])
+    max_thrust = 4 * CF2X['KF'] * max_rpm2
+    return 0.25 * CF2X['PROP_RADIUS'] * math.sqrt(15 * max_rpm2 * CF2X['KF'] * CF2X['GND_EFF_COEFF'] / max_thrust)
+
+
+def _rot_for(system, x):
+    if system == 3:
+        return rot_xyz(x[6], x[7], x[8])
+    th = x[4] if system == 2 else 0.0
+    c, s = math.cos(th), math.sin(th)
+    return [[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]]
+
+
+def _vel_of(system, x):
+    if system == 1:
+        return [0.0, 0.0, x[1]]
+    if system == 2:
+        return [x[1], 0.0, x[3]]
+    return [x[1], x[3], x[5]]
+
+
+def drag_force(system, x, u, p):
+    """:478-496.  rpm_i from the per-motor thrust u_j / n_motor = KF rpm^2; world force = R (R (k * v))."""
+    nu = len(u)
+    n_motor = 4 // nu
+    srpm = n_motor * sum(math.sqrt(max(uj, 0.0) / (n_motor * p.kf)) for uj in u)
+    k = [-CF2X['DRAG_COEFF_XY'] * 2 * math.pi / 60 * srpm] * 2 + [-CF2X['DRAG_COEFF_Z'] * 2 * math.pi / 60 * srpm]
+    v = _vel_of(system, x)
+    R = _rot_for(system, x)
+    w = [k[i] * v[i] for i in range(3)]
+    b = [sum(R[i][j] * w[j] for j in range(3)) for i in range(3)]
+    return [sum(R[i][j] * b[j] for j in range(3)) for i in range(3)]
+
+
+def ground_effect_thrusts(system, x, u, p):
+    """:437-476: thrust of propeller i scaled by 1 + GND_EFF_COEFF (PROP_RADIUS / (4 h_i))^2 while |roll|, |pitch| < pi/2."""
+    a = p.l / math.sqrt(2.0)
+    clip = gnd_eff_h_clip()
+    gain = lambda h: 1.0 + CF2X['GND_EFF_COEFF'] * (CF2X['PROP_RADIUS'] / (4 * max(h, clip))) ** 2
+    if system == 1:
+        return [u[0] * gain(x[0])]
+    R = _rot_for(system, x)
+    if system == 2:
+        if abs(x[4]) >= math.pi / 2:
+            return list(u)
+        return [u[0] * gain(x[2] + R[2][0] * a), u[1] * gain(x[2] - R[2][0] * a)]        # T1 at x = +a, T2 at x = -a
+    if abs(x[6]) >= math.pi / 2 or abs(x[7]) >= math.pi / 2:
+        return list(u)
+    offs = [(a, a), (-a, a), (-a, -a), (a, -a)]                                         # cf2x.urdf:43-79
+    return [u[i] * gain(x[4] + R[2][0] * ox + R[2][1] * oy) for i, (ox, oy) in enumerate(offs)]

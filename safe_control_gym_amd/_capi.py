@@ -58,6 +58,8 @@ class ScgConfig(C.Structure):
         ('init_rand_low', _dbl * SCG_MAX_NX), ('init_rand_high', _dbl * SCG_MAX_NX),
         ('randomized_inertial', _i32), ('reserved2', _i32),
         ('inertial_rand_low', _dbl * 4), ('inertial_rand_high', _dbl * 4),
+        ('ground_effect', _i32), ('drag', _i32),
+        ('gnd_eff_coeff', _dbl), ('prop_radius', _dbl), ('gnd_eff_h_clip', _dbl), ('drag_coeff_xy', _dbl), ('drag_coeff_z', _dbl),
         ('seed', C.c_uint64),
         ('env_index_base', C.c_int64),
     ]

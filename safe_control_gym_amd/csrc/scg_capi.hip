@@ -95,6 +95,8 @@ static void derive_params(scg_handle* h) {
     if (c.task == SCG_TRAJ_TRACKING) f |= F_TRACKING;
     if (c.cost == SCG_QUADRATIC) f |= F_QUADRATIC;
     if (c.integrator == SCG_EULER) f |= F_EULER;
+    if (c.ground_effect && c.system != SCG_CARTPOLE) f |= F_GND;
+    if (c.drag && c.system != SCG_CARTPOLE) f |= F_DRAG;
     if (c.cost != SCG_QUADRATIC || (matrix_is_diag(c.Q, nx, SCG_MAX_NX) && matrix_is_diag(c.R, nu, SCG_MAX_NU)))
         f |= F_Q_DIAG;
     k.flags = f;
@@ -150,6 +152,10 @@ static void derive_params(scg_handle* h) {
     k.goal_tol2 = (float)(c.goal_tolerance * c.goal_tolerance);
     k.constraint_penalty = (float)c.constraint_penalty;
     k.cost_scale = (c.cost == SCG_QUADRATIC) ? -0.5f : -1.0f;
+    k.gnd_k = (float)(c.gnd_eff_coeff * (c.prop_radius / 4.0) * (c.prop_radius / 4.0));
+    k.gnd_h_clip = (float)c.gnd_eff_h_clip;
+    k.drag_xy = (float)(c.drag_coeff_xy * 2.0 * M_PI / 60.0);
+    k.drag_z = (float)(c.drag_coeff_z * 2.0 * M_PI / 60.0);
 }
 
 static void derive_tables(const scg_handle* h, KTables& t) {

@@ -23,6 +23,8 @@ enum Flags : uint32_t {
     F_EULER = 1u << 11,         // explicit Euler instead of RK4
     F_REF_IN_LDS = 1u << 12,    // reference table staged in LDS (else read through L1/L2)
     F_RAND_INERTIAL = 1u << 13, // per-env inertial properties re-drawn at every reset
+    F_GND = 1u << 14,           // ground effect (Physics.PYB_GND)
+    F_DRAG = 1u << 15,          // drag (Physics.PYB_DRAG)
 };
 
 // Physical constants of the model, in the real type the integrator runs in: float in the kernarg block for
@@ -64,6 +66,8 @@ struct KParams {
     float goal_tol2;
     float constraint_penalty;
     float cost_scale;           // -1 (rl_reward: rew = -dist) or -0.5 (quadratic: rew = -l/2 ... see w_state)
+    // aero terms: gnd_k = gnd_eff_coeff (prop_radius / 4)^2, drag_* = drag_coeff * 2 pi / 60 (per rpm)
+    float gnd_k, gnd_h_clip, drag_xy, drag_z;
     const DistTable* dist;   // device; null when the env has no passive disturbances
 };
 

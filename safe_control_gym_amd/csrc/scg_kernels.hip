@@ -277,7 +277,7 @@ template <class T> struct Inputs<SCG_CARTPOLE, T> { T F; };
 // ZOH inputs of one step.  In the precise mode the physical constants are the float-rounded kernarg values
 // widened to double -- the same constants the float path uses, so the two modes integrate the same model.
 template <int SYS, class T>
-__device__ __forceinline__ void make_inputs(const PhysT<T>& c, const T* u, float fx, float fy, float fz,
+__device__ __forceinline__ void make_inputs(const PhysT<T>& c, const T* u, T fx, T fy, T fz,
                                             Inputs<SYS, T>& in) {
     const T inv_m = c.inv_m, g = c.g;
     if constexpr (SYS == SCG_QUAD_1D) {
@@ -350,6 +350,83 @@ __device__ __forceinline__ void f_eval(const PhysT<T>& c, const Inputs<SYS, T>& 
         d[1] = fma_t(-c.cp_ml * c.cp_inv_Mm, thdd * co, tmp);
         d[2] = thd;
         d[3] = thdd;
+    }
+}
+
+// ---- aero terms of Physics.PYB_GND / PYB_DRAG (base_aviary.py:437-500) as zero-order-hold inputs -------------------
+// Drag (:478-496): drag_factors = -DRAG_COEFF * sum_i (2 pi rpm_i / 60); drag = base_rot (drag_factors * vel), applied to
+// the centre of mass with flags=LINK_FRAME, i.e. the world force is base_rot drag.  Evaluated from the state at the
+// start of the control step (the reference reads self.quat / self.vel, which it refreshes once per control step, :362-374).
+template <int SYS, class T>
+__device__ __forceinline__ void drag_force(const KParams& p, const PhysT<T>& c, const T* u, const T (&x)[Dim<SYS>::NX],
+                                           T& fx, T& fy, T& fz) {
+    constexpr int NU = Dim<SYS>::NU;
+    T srpm = (T)0;
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        const T q = (u[j] > (T)0 ? u[j] : (T)0) * c.inv_nmotor_kf;             // rpm^2 of one motor of actuator j
+        srpm += sizeof(T) == 8 ? (T)sqrt((double)q) : (T)sqrt_f((float)q);
+    }
+    srpm *= (T)(4 / NU);
+    const T kxy = -(T)p.drag_xy * srpm, kz = -(T)p.drag_z * srpm;
+    if constexpr (SYS == SCG_QUAD_1D) {
+        fx = (T)0; fy = (T)0; fz = kz * x[1];
+    } else if constexpr (SYS == SCG_QUAD_2D) {
+        T s, co;
+        Real<T>::sincos(x[4], s, co);
+        const T wx = kxy * x[1], wz = kz * x[3];
+        const T bx = fma_t(co, wx, s * wz), bz = fma_t(co, wz, -(s * wx));     // R (k * v), R = Ry(theta)
+        fx = fma_t(co, bx, s * bz); fy = (T)0; fz = fma_t(co, bz, -(s * bx));  // R again (link-frame application)
+    } else if constexpr (SYS == SCG_QUAD_3D) {
+        T sph, cph, sth, cth, sps, cps;
+        Real<T>::sincos(x[6], sph, cph);
+        Real<T>::sincos(x[7], sth, cth);
+        Real<T>::sincos(x[8], sps, cps);
+        // R = Rz(psi) Ry(theta) Rx(phi)  (transformations.py:125-182)
+        const T r00 = cps * cth, r01 = cps * sth * sph - sps * cph, r02 = cps * sth * cph + sps * sph;
+        const T r10 = sps * cth, r11 = sps * sth * sph + cps * cph, r12 = sps * sth * cph - cps * sph;
+        const T r20 = -sth, r21 = cth * sph, r22 = cth * cph;
+        const T wx = kxy * x[1], wy = kxy * x[3], wz = kz * x[5];
+        const T bx = r00 * wx + r01 * wy + r02 * wz, by = r10 * wx + r11 * wy + r12 * wz, bz = r20 * wx + r21 * wy + r22 * wz;
+        fx = r00 * bx + r01 * by + r02 * bz;
+        fy = r10 * bx + r11 * by + r12 * bz;
+        fz = r20 * bx + r21 * by + r22 * bz;
+    } else {
+        fx = fy = fz = (T)0;
+    }
+}
+// Ground effect (:437-476): every propeller gains KF rpm^2 GND_EFF_COEFF (PROP_RADIUS / (4 h))^2 along its axis, h = its
+// height clipped from below, while |roll| and |pitch| < pi/2: the actuator thrusts are scaled in place.  Propellers sit at
+// (l/sqrt2)(+-1, +-1, 0) in the body frame, numbered as in the mixer of quadrotor.py:667-669 (cf2x.urdf:43-79).
+template <int SYS, class T>
+__device__ __forceinline__ void ground_effect(const KParams& p, const PhysT<T>& c, const T (&x)[Dim<SYS>::NX],
+                                              const T* u, T* ug) {
+    constexpr int NU = Dim<SYS>::NU;
+    const T clip = (T)p.gnd_h_clip, gk = (T)p.gnd_k;
+    auto gain = [&](T h) { h = h > clip ? h : clip; const T r = Real<T>::rcp(h); return fma_t(gk * r, r, (T)1); };
+    if constexpr (SYS == SCG_QUAD_1D) {
+        ug[0] = u[0] * gain(x[0]);
+    } else if constexpr (SYS == SCG_QUAD_2D) {
+        T s, co;
+        Real<T>::sincos(x[4], s, co);
+        const bool on = fabs((double)x[4]) < 1.5707963267948966;
+        const T dz = s * c.arm_s2;                                              // -R[2][0] * x_offset
+        ug[0] = on ? u[0] * gain(x[2] - dz) : u[0];                             // T1: motors at x = +l/sqrt2
+        ug[1] = on ? u[1] * gain(x[2] + dz) : u[1];                             // T2: motors at x = -l/sqrt2
+    } else if constexpr (SYS == SCG_QUAD_3D) {
+        T sph, cph, sth, cth;
+        Real<T>::sincos(x[6], sph, cph);
+        Real<T>::sincos(x[7], sth, cth);
+        const bool on = fabs((double)x[6]) < 1.5707963267948966 && fabs((double)x[7]) < 1.5707963267948966;
+        const T ax = -sth * c.arm_s2, ay = cth * sph * c.arm_s2;                // R[2][0] l/sqrt2, R[2][1] l/sqrt2
+        const T z = x[4];
+        ug[0] = on ? u[0] * gain(z + ax + ay) : u[0];                           // (+, +)
+        ug[1] = on ? u[1] * gain(z - ax + ay) : u[1];                           // (-, +)
+        ug[2] = on ? u[2] * gain(z - ax - ay) : u[2];                           // (-, -)
+        ug[3] = on ? u[3] * gain(z + ax - ay) : u[3];                           // (+, -)
+    } else {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) ug[j] = u[j];
     }
 }
 
@@ -710,13 +787,32 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                 u[j] = th;
             }
             Inputs<SYS, RT> in;
-            make_inputs<SYS, RT>(ph, u, fx, fy, fz, in);
+            const bool aero = EXTRA && (p.flags & (F_GND | F_DRAG)) != 0;
+            RT efx = (RT)fx, efy = (RT)fy, efz = (RT)fz;                        // external force: disturbance (+ drag)
+            // one integration sub-step's inputs when aero terms are on: drag held from the start of the control step,
+            // ground effect re-evaluated at the start of every sub-step (the reference applies it per PyBullet step)
+            auto substep_inputs = [&](const RT (&xc)[NX]) {
+                if (p.flags & F_GND) {
+                    RT ug[NU];
+                    ground_effect<SYS, RT>(p, ph, xc, u, ug);
+                    make_inputs<SYS, RT>(ph, ug, efx, efy, efz, in);
+                } else {
+                    make_inputs<SYS, RT>(ph, u, efx, efy, efz, in);
+                }
+            };
+            if (!aero) make_inputs<SYS, RT>(ph, u, efx, efy, efz, in);
             if (sizeof(RT) == 8) {
                 RT xd[NX];
 #pragma unroll
                 for (int j = 0; j < NX; ++j) xd[j] = (RT)x[j] + (RT)xlo[COMP ? j : 0];
+                if (aero && (p.flags & F_DRAG)) {
+                    RT dx, dy, dz;
+                    drag_force<SYS, RT>(p, ph, u, xd, dx, dy, dz);
+                    efx += dx; efy += dy; efz += dz;
+                }
                 for (int s = 0; s < p.substeps; ++s) {
                     RT inc[NX];
+                    if (aero) substep_inputs(xd);
                     integrate<SYS, RT>(ph, p.flags, in, xd, inc);
 #pragma unroll
                     for (int j = 0; j < NX; ++j) xd[j] += inc[j];
@@ -730,8 +826,14 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                 RT xs[NX];
 #pragma unroll
                 for (int j = 0; j < NX; ++j) xs[j] = (RT)x[j];
+                if (aero && (p.flags & F_DRAG)) {
+                    RT dx, dy, dz;
+                    drag_force<SYS, RT>(p, ph, u, xs, dx, dy, dz);
+                    efx += dx; efy += dy; efz += dz;
+                }
                 for (int s = 0; s < p.substeps; ++s) {
                     RT inc[NX];
+                    if (aero) substep_inputs(xs);
                     integrate<SYS, RT>(ph, p.flags, in, xs, inc);
 #pragma unroll
                     for (int j = 0; j < NX; ++j) xs[j] += inc[j];
@@ -1587,7 +1689,7 @@ LaunchGeom step_geometry(const KParams& p, int system, int64_t n, int num_cus) {
 // Which instantiation covers this call.
 static uint32_t features_needed(const KParams& p, const scg_step_io& io) {
     const bool extra = io.inertial || io.action_disturbance || io.dynamics_force || io.obs_noise || io.obs || io.stats ||
-                       io.episode_id || p.dist || (p.flags & F_NORMALIZED) || !(p.flags & F_Q_DIAG);
+                       io.episode_id || p.dist || (p.flags & (F_NORMALIZED | F_GND | F_DRAG)) || !(p.flags & F_Q_DIAG);
     if (extra) return FT_TRACK | FT_CON | FT_EXTRA;
     uint32_t ft = 0;
     if (io.truncated || io.goal_reached || io.mse || io.terminal_record) ft |= FT_INFO;

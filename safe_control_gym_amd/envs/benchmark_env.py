@@ -49,7 +49,8 @@ class Environment(str, Enum):
 
 
 _INTEGRATORS = {'rk4': _capi.SCG_RK4, 'euler': _capi.SCG_EULER}
-# the reference's Physics enum values (base_aviary.py:34-43) all map to the analytic model here
+# the reference's Physics enum values (base_aviary.py:34-43): all integrate the analytic model; the *_gnd / *_drag
+# variants add the ground-effect / drag terms (quadrotor.py _fill_system_config), pyb_dw has no single-drone effect
 _PHYSICS_ALIASES = {'pyb': 'rk4', 'dyn': 'euler', 'pyb_gnd': 'rk4', 'pyb_drag': 'rk4', 'pyb_dw': 'rk4',
                     'pyb_gnd_drag_dw': 'rk4', 'rk4': 'rk4', 'euler': 'euler'}
 

@@ -36,7 +36,8 @@ class QuadType(IntEnum):
 # assets/cf2x.urdf:5,12,13 (parsed by base_aviary.py:612-651 in the reference)
 CF2X = dict(MASS=0.03454, L=0.0397, THRUST2WEIGHT_RATIO=2.25, IXX=1.4e-5, IYY=1.4e-5, IZZ=2.17e-5,
             KF=3.16e-10, KM=7.94e-12, PWM2RPM_SCALE=0.2685, PWM2RPM_CONST=4070.3, MIN_PWM=20000.0,
-            MAX_PWM=65535.0)
+            MAX_PWM=65535.0, GND_EFF_COEFF=11.36859, PROP_RADIUS=2.31348e-2, DRAG_COEFF_XY=9.1785e-7,
+            DRAG_COEFF_Z=10.311e-7)            # assets/cf2x.urdf:5
 
 _F32MAX = float(np.finfo(np.float32).max)
 
@@ -257,6 +258,15 @@ class Quadrotor(BenchmarkEnv):
         cfg.kf, cfg.km = self.KF, self.KM
         cfg.pwm2rpm_scale, cfg.pwm2rpm_const = self.PWM2RPM_SCALE, self.PWM2RPM_CONST
         cfg.pwm_min, cfg.pwm_max = self.MIN_PWM, self.MAX_PWM
+        # Physics.PYB_GND / PYB_DRAG / PYB_GND_DRAG_DW (base_aviary.py:35-45): aero terms of the analytic model; the
+        # downwash of PYB_DW acts between drones of one env and does not exist for a single drone
+        cfg.ground_effect = int(self.PHYSICS in ('pyb_gnd', 'pyb_gnd_drag_dw'))
+        cfg.drag = int(self.PHYSICS in ('pyb_drag', 'pyb_gnd_drag_dw'))
+        cfg.gnd_eff_coeff, cfg.prop_radius = CF2X['GND_EFF_COEFF'], CF2X['PROP_RADIUS']
+        max_rpm2 = CF2X['THRUST2WEIGHT_RATIO'] * self.GRAVITY_ACC * CF2X['MASS'] / (4 * self.KF)      # base_aviary.py:141-147 (URDF mass)
+        cfg.gnd_eff_h_clip = 0.25 * CF2X['PROP_RADIUS'] * math.sqrt(15 * max_rpm2 * self.KF * CF2X['GND_EFF_COEFF']
+                                                                    / (4 * self.KF * max_rpm2))
+        cfg.drag_coeff_xy, cfg.drag_coeff_z = CF2X['DRAG_COEFF_XY'], CF2X['DRAG_COEFF_Z']
         cfg.pole_length = cfg.pole_mass = cfg.cart_mass = 1.0
         cfg.norm_act_scale = self.norm_act_scale
         cfg.hover_thrust = getattr(self, 'hover_thrust', self.GRAVITY_ACC * self.MASS / self.action_dim)

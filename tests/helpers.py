@@ -57,7 +57,9 @@ def make_pair(system, n, seed=1337, device='cuda', engine_kwargs=None, init_stat
     sampler = PhiloxSampler(seed, system, kw.get('init_state_randomization_info'))
     okw = {k: v for k, v in kw.items() if k not in ('physics', 'disturbances')}
     if 'physics' in kw:
-        okw['integrator'] = {'rk4': 'rk4', 'euler': 'euler', 'pyb': 'rk4', 'dyn': 'euler'}[kw['physics']]
+        okw['integrator'] = 'euler' if kw['physics'] in ('euler', 'dyn') else 'rk4'
+        okw['ground_effect'] = kw['physics'] in ('pyb_gnd', 'pyb_gnd_drag_dw')
+        okw['drag'] = kw['physics'] in ('pyb_drag', 'pyb_gnd_drag_dw')
     for k_engine, k_oracle in (('integration_substeps', 'substeps'),):
         if k_engine in okw:
             okw[k_oracle] = okw.pop(k_engine)
@@ -132,7 +134,9 @@ def ill_conditioned_lanes(ref, info_r, theta_guard=1.5):
     for i, inf in enumerate(info_r['n']):
         if 'terminal_observation' in inf:
             x = inf['terminal_observation']
-            bad[i] = (not np.all(np.isfinite(x))) or abs(x[7]) >= theta_guard
+            # ... or a stage of the step crossed it: roll / yaw thrown far outside their +-85 / +-180 degree boxes within ONE
+            # step (from inside the box that takes > 100 rad/s of Euler rate, which only tan(theta), 1/cos(theta) deliver)
+            bad[i] = (not np.all(np.isfinite(x))) or abs(x[7]) >= theta_guard or abs(x[6]) > np.pi or abs(x[8]) > 2 * np.pi
         elif theta_guard < 1.5:
             bad[i] = abs(ref.envs[i].state[7]) >= theta_guard
     return bad

@@ -279,3 +279,43 @@ def test_golden_matches_oracle():
             o, r, d, info = vec.step(g['actions'][k].astype(np.float64))
             assert np.array_equal(o, g['obs'][k]) and np.array_equal(r, g['reward'][k])
             assert np.array_equal(d.astype(np.uint8), g['done'][k])
+
+
+def test_aero_terms_known_answers():
+    """Ground effect and drag of base_aviary.py:437-500 as restated for the analytic model (oracle.ref_model):
+    level hover at height h gains thrust by GND_EFF_COEFF (PROP_RADIUS / 4h)^2; the clip height follows :145-147;
+    drag at level attitude is k * v with k = -DRAG_COEFF * sum(2 pi rpm / 60); tilting by 90 deg about y maps a
+    pure x velocity to a world force along -x again (R R = Ry(180 deg) flips x and z, and k_xy acts on it)."""
+    from oracle import ref_model as rm
+    p = rm.QuadParams()
+    clip = rm.gnd_eff_h_clip()
+    assert clip == pytest.approx(0.25 * 2.31348e-2 * np.sqrt(15 * 11.36859 / 4), rel=1e-12)
+    hover = [p.m * p.g / 4] * 4
+    x = np.zeros(12); x[4] = 0.1
+    ug = rm.ground_effect_thrusts(3, x, hover, p)
+    assert np.allclose(ug, np.array(hover) * (1 + 11.36859 * (2.31348e-2 / 0.4) ** 2), rtol=1e-14)
+    x[4] = 0.001                                                      # below the clip height
+    assert np.allclose(rm.ground_effect_thrusts(3, x, hover, p), np.array(hover) * (1 + 11.36859 * (2.31348e-2 / (4 * clip)) ** 2))
+    x[4], x[6] = 0.1, 1.6                                             # |roll| >= pi/2: off (:463)
+    assert rm.ground_effect_thrusts(3, x, hover, p) == hover
+    x = np.zeros(12); x[4] = 0.05; x[7] = 0.2                         # pitched: front props (x > 0) are lower
+    ug = rm.ground_effect_thrusts(3, x, hover, p)
+    assert ug[0] > ug[1] and ug[3] > ug[2] and ug[0] == pytest.approx(ug[3]) and ug[1] == pytest.approx(ug[2])
+    # drag
+    x = np.zeros(12); x[1], x[3], x[5] = 1.0, -2.0, 0.5
+    srpm = 4 * np.sqrt(hover[0] / p.kf)
+    f = rm.drag_force(3, x, hover, p)
+    want = [-9.1785e-7 * 2 * np.pi / 60 * srpm * 1.0, -9.1785e-7 * 2 * np.pi / 60 * srpm * -2.0, -10.311e-7 * 2 * np.pi / 60 * srpm * 0.5]
+    assert np.allclose(f, want, rtol=1e-13)
+    x = np.zeros(12); x[1] = 1.0; x[7] = np.pi / 2
+    f = rm.drag_force(3, x, hover, p)
+    assert f[0] == pytest.approx(9.1785e-7 * 2 * np.pi / 60 * srpm, rel=1e-12) and abs(f[2]) < 1e-18
+    # the 2-D and 1-D reductions agree with the 3-D model restricted to their motion
+    x2 = [0.3, 1.0, 0.2, 0.5, 0.3, 0.0]
+    x3 = np.zeros(12); x3[0], x3[1], x3[4], x3[5], x3[7] = 0.3, 1.0, 0.2, 0.5, 0.3
+    T = [2 * hover[0] * 1.1, 2 * hover[0] * 0.9]                      # T1 <-> motors 0, 3 (x > 0); T2 <-> motors 1, 2
+    u3 = [T[0] / 2, T[1] / 2, T[1] / 2, T[0] / 2]
+    f2, f3 = rm.drag_force(2, x2, T, p), rm.drag_force(3, x3, u3, p)
+    assert np.allclose(f2, f3, rtol=1e-12, atol=1e-18)
+    g2, g3 = rm.ground_effect_thrusts(2, x2, T, p), rm.ground_effect_thrusts(3, x3, u3, p)
+    assert g2[0] == pytest.approx(g3[0] + g3[3], rel=1e-12) and g2[1] == pytest.approx(g3[1] + g3[2], rel=1e-12)

@@ -131,6 +131,18 @@ FEATURES = [
                                    done_on_out_of_bound=False, episode_len_sec=1)),
     ('cartpole_normalized', 'cartpole', dict(task='stabilization', cost='rl_reward', ctrl_freq=50, pyb_freq=50,
                                              normalized_rl_action_space=True)),
+    # Physics.PYB_GND / PYB_DRAG / PYB_GND_DRAG_DW (base_aviary.py:35-45,437-500) as terms of the analytic model; low
+    # start heights put the propellers inside the ground-effect range (and below its clip height)
+    ('q3_ground_effect', 3, dict(task='traj_tracking', cost='quadratic', ctrl_freq=60, pyb_freq=240, physics='pyb_gnd',
+                                 init_state=np.array([0, 0, 0, 0, 0.05, 0, 0, 0, 0, 0, 0, 0.]))),
+    ('q3_drag', 3, dict(task='traj_tracking', cost='quadratic', ctrl_freq=60, pyb_freq=240, physics='pyb_drag')),
+    ('q3_gnd_drag_dw_substeps4', 3, dict(task='stabilization', task_info=GOAL3, cost='rl_reward', ctrl_freq=60, pyb_freq=240,
+                                         physics='pyb_gnd_drag_dw', integration_substeps=4,
+                                         init_state=np.array([0, 0, 0, 0, 0.03, 0, 0, 0, 0, 0, 0, 0.]))),
+    ('q2_gnd_drag_dw', 2, dict(task='traj_tracking', cost='quadratic', ctrl_freq=60, pyb_freq=240, physics='pyb_gnd_drag_dw',
+                               init_state=np.array([0, 0, 0.04, 0, 0, 0.]))),
+    ('q1_gnd_drag_dw', 1, dict(task='stabilization', cost='rl_reward', ctrl_freq=60, pyb_freq=240, physics='pyb_gnd_drag_dw',
+                               init_state=np.array([0.05, 0.]))),
 ]
 
 

@@ -292,3 +292,31 @@ def test_checkpoint_resume_is_bit_exact(gpu):
     assert torch.equal(a.state, b.state) and torch.equal(a.episode_return, b.episode_return)
     assert int(sum(int(o[2].sum()) for o in outs_a)) > n          # episodes ended and were re-drawn after the snapshot
     a.close(), b.close()
+
+
+def test_aero_terms_known_answers_on_device(gpu):
+    """The ground-effect and drag terms really act in the kernel (base_aviary.py:437-500 as restated in DESIGN.md):
+    level hover at 5 cm climbs with a = g * GND_EFF_COEFF (PROP_RADIUS / 4h)^2, a level vehicle drifting at v is slowed
+    by k v / m with k = DRAG_COEFF * sum_i 2 pi rpm_i / 60; plain 'pyb' physics shows neither."""
+    n = 256
+    x0 = np.zeros(12); x0[4] = 0.05; x0[1] = 2.0                   # 5 cm above ground, drifting at 2 m/s along x
+    goal = {'stabilization_goal': [0, 0, 1], 'stabilization_goal_tolerance': 0.0}
+    res = {}
+    for phys in ('pyb', 'pyb_gnd', 'pyb_drag', 'pyb_gnd_drag_dw'):
+        env = scg.make('quadrotor', quad_type=3, num_envs=n, device='cuda', randomized_init=False, init_state=x0,
+                       physics=phys, task='stabilization', cost='rl_reward', task_info=goal, ctrl_freq=60, pyb_freq=60)
+        env.reset()
+        a = torch.tensor(env.U_GOAL, dtype=torch.float32, device='cuda').repeat(n, 1)
+        env.step(a)
+        res[phys] = env.state[0].cpu().numpy().astype(np.float64)
+        m, g, dt, kf = env.MASS, env.GRAVITY_ACC, env.CTRL_TIMESTEP, env.KF
+        env.close()
+    gain = 11.36859 * (2.31348e-2 / (4 * 0.05)) ** 2
+    assert abs(res['pyb'][5]) < 1e-6 and abs(res['pyb'][1] - 2.0) < 1e-6           # equilibrium, no drag
+    # one RK4 step with the thrust gain held over the step: vz = g * gain * dt
+    assert res['pyb_gnd'][5] == pytest.approx(g * gain * dt, rel=2e-4) and abs(res['pyb_gnd'][1] - 2.0) < 1e-6
+    srpm = 4 * np.sqrt(m * g / 4 / kf)
+    k = 9.1785e-7 * 2 * np.pi / 60 * srpm
+    assert res['pyb_drag'][1] - 2.0 == pytest.approx(-k * 2.0 / m * dt, rel=2e-3) and abs(res['pyb_drag'][5]) < 1e-6
+    assert res['pyb_gnd_drag_dw'][5] == pytest.approx(res['pyb_gnd'][5], rel=1e-3)
+    assert res['pyb_gnd_drag_dw'][1] - 2.0 == pytest.approx(res['pyb_drag'][1] - 2.0, rel=0.2)    # more thrust -> more rpm
