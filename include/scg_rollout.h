@@ -137,10 +137,11 @@ typedef struct scg_constraint_row {
 /* Device buffers of one step() call.  Nullable members are skipped (their bytes are not moved). */
 typedef struct scg_step_io {
     uint32_t struct_size;            /* = sizeof(scg_step_io) */
-    uint32_t reserved;
+    uint32_t action_rows;            /* 0: action is SoA planes [nu][ld]; 1: row-major [n][nu] (what a policy emits), read as
+                                        one 4 nu-byte vector per lane; must be 4 nu-byte aligned; scg_step only */
     int64_t ld;                      /* plane stride in elements (>= n) of every multi-plane array */
     /* in */
-    const float* action;             /* [nu][ld] raw action as passed to step() */
+    const float* action;             /* [nu][ld] (or [n][nu], see action_rows): raw action as passed to step() */
     const float* action_disturbance; /* nullable [nu][ld], added after clipping (quadrotor.py:835-838) */
     const float* dynamics_force;     /* nullable [3][ld] world-frame force (quadrotor.py:526-548) */
     const float* obs_noise;          /* nullable [nx][ld] added to obs only (quadrotor.py:879-880) */

@@ -75,7 +75,7 @@ class ScgConstraintRow(C.Structure):
 
 class ScgStepIO(C.Structure):
     _fields_ = [
-        ('struct_size', C.c_uint32), ('reserved', C.c_uint32),
+        ('struct_size', C.c_uint32), ('action_rows', C.c_uint32),
         ('ld', C.c_int64),
         ('action', _fp), ('action_disturbance', _fp), ('dynamics_force', _fp), ('obs_noise', _fp),
         ('reset_state', _fp),

@@ -494,6 +494,8 @@ int scg_step(scg_handle* h, const scg_step_io* io, int64_t n, void* stream) {
     if (io->terminal_record && (io->terminal_stride < h->obs_dim + 2 || (io->terminal_stride & 3)))
         return fail(SCG_ERR_INVALID, "scg_step: terminal_stride must be a multiple of 4 and >= obs_dim + 2 = %d (got %lld)",
                     h->obs_dim + 2, (long long)io->terminal_stride);
+    if (io->action_rows > 1 || (io->action_rows && (reinterpret_cast<uintptr_t>(io->action) % (4u * h->nu)) != 0))
+        return fail(SCG_ERR_INVALID, "scg_step: row-major actions must be %d-byte aligned (action_rows in {0, 1})", 4 * h->nu);
     if (int rc = check_dist_io(h, io, "scg_step")) return rc;
     if (n == 0) return SCG_OK;
     if (n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_step: n > 2^30 envs per device (32-bit lane offsets)");
@@ -506,6 +508,7 @@ int scg_rollout(scg_handle* h, const scg_step_io* io, int64_t n, int32_t steps, 
     if (!io) return fail(SCG_ERR_INVALID, "scg_rollout: null argument");
     if (steps < 0 || action_period < 1 || action_stride < 0)
         return fail(SCG_ERR_INVALID, "scg_rollout: need steps >= 0, action_period >= 1, action_stride >= 0");
+    if (io->action_rows) return fail(SCG_ERR_INVALID, "scg_rollout: actions are [period][nu][ld] planes (action_rows must be 0)");
     scg_step_io local = *io;
     for (int32_t k = 0; k < steps; ++k) {
         local.action = io->action + (int64_t)(k % action_period) * action_stride;
@@ -522,6 +525,7 @@ int scg_rollout_fused(scg_handle* h, const scg_step_io* io, int64_t n, int32_t s
     if (io->struct_size != sizeof(scg_step_io)) return fail(SCG_ERR_INVALID, "scg_rollout_fused: bad struct_size");
     if (steps < 0 || action_period < 1 || action_stride < 0)
         return fail(SCG_ERR_INVALID, "scg_rollout_fused: need steps >= 0, action_period >= 1, action_stride >= 0");
+    if (io->action_rows) return fail(SCG_ERR_INVALID, "scg_rollout_fused: actions are [period][nu][ld] planes (action_rows must be 0)");
     if (steps == 0 || n == 0) return SCG_OK;
     if (!fused_rollout_ok(h->kp, *io)) return scg_rollout(h, io, n, steps, action_stride, action_period, stream);
     if (n < 0 || io->ld < n || n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_rollout_fused: bad n / ld");

@@ -664,8 +664,23 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         const uint32_t b4 = idx * 4u;
 #pragma unroll
         for (int j = 0; j < NX; ++j) L.x[j] = ldp(PL(io.state, j), b4);
+        if (io.action_rows) {
+            // row-major [n][nu] (a policy's output): one 4 NU-byte vector per lane, as wide a wave transaction as NU planes
+            if constexpr (NU == 4) {
+                typedef float a4 __attribute__((ext_vector_type(4)));
+                const a4 v = __builtin_nontemporal_load(reinterpret_cast<const a4*>(io.action) + idx);
+                L.a_raw[0] = v[0]; L.a_raw[1] = v[1]; L.a_raw[2] = v[2]; L.a_raw[3] = v[3];
+            } else if constexpr (NU == 2) {
+                typedef float a2 __attribute__((ext_vector_type(2)));
+                const a2 v = __builtin_nontemporal_load(reinterpret_cast<const a2*>(io.action) + idx);
+                L.a_raw[0] = v[0]; L.a_raw[1] = v[1];
+            } else {
+                L.a_raw[0] = ldp(io.action, b4);
+            }
+        } else {
 #pragma unroll
-        for (int j = 0; j < NU; ++j) L.a_raw[j] = ldp(PL(io.action, j), b4);
+            for (int j = 0; j < NU; ++j) L.a_raw[j] = ldp(PL(io.action, j), b4);
+        }
         L.t = ldp(io.step_count, b4);                                       // ctrl_step_counter (pre-increment)
         if (COMP) {
 #pragma unroll
@@ -1731,7 +1746,7 @@ static bool packed_ok(const KParams& p, const scg_step_io& io, uint32_t ft) {
     // 155 VGPRs (3 waves/SIMD) and 8-byte streams lose more to exposed latency than that saves
     // (31.4 us vs 29.9 us at 2^20 envs).
     static const bool disabled = [] { const char* e = getenv("SCG_PACKED"); return !(e && e[0] == '1'); }();
-    if (disabled || (ft & (FT_EXTRA | FT_INFO)) || io.state_lo || (p.flags & F_REF_IN_LDS) || (io.ld & 1)) return false;
+    if (disabled || io.action_rows || (ft & (FT_EXTRA | FT_INFO)) || io.state_lo || (p.flags & F_REF_IN_LDS) || (io.ld & 1)) return false;
     auto al = [](const void* q, uintptr_t a) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) % a) == 0; };
     return al(io.state, 8) && al(io.action, 8) && al(io.step_count, 8) && al(io.reward, 8) && al(io.done, 2) &&
            al(io.ep_return, 8) && al(io.ep_length, 8) && al(io.reset_state, 4);

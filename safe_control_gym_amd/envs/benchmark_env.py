@@ -194,7 +194,7 @@ class BenchmarkEnv:
         self.RESEED_ON_RESET = kwargs.get('reseed_on_reset', False)
         self._bufs = None
         self._serial = 0
-        self._raw_action = None
+        self._raw_action, self._raw_action_rows = None, False
 
     # ------------------------------------------------------------------ seeding
     def seed(self, seed=None):
@@ -236,7 +236,7 @@ class BenchmarkEnv:
         self._serial = int(sd['serial'])
         self.initial_reset = bool(sd['initial_reset'])
         self._bound = False
-        self._raw_action = None
+        self._raw_action, self._raw_action_rows = None, False
 
     def set_cost_function_param(self, Q, R):
         """benchmark_env.py:237-254."""
@@ -479,10 +479,19 @@ class BenchmarkEnv:
     @property
     def current_raw_input_action(self):
         """[N, nu] view of the last raw action (benchmark_env.py:431 keeps it for the input constraints)."""
-        return None if self._raw_action is None else self._raw_action[:, :self.num_envs].T
+        if self._raw_action is None:
+            return None
+        return self._raw_action if self._raw_action_rows else self._raw_action[:, :self.num_envs].T
 
     def _raw_action_soa(self):
-        return getattr(self, '_raw_action', None) if getattr(self, '_raw_action', None) is not None else self._bufs['action']
+        """The last raw action as planes [nu, ld] (for the stand-alone constraint kernel)."""
+        if self._raw_action is None:
+            return self._bufs['action']
+        if self._raw_action_rows:
+            buf = self._bufs['action']
+            buf[:, :self.num_envs].copy_(self._raw_action.T)
+            return buf
+        return self._raw_action
 
     # -- batched prior-model queries (SURVEY.md section 8f rank 2) ---------------------------------------
     def _planes(self, t, dim, default=None):
@@ -599,7 +608,7 @@ class BenchmarkEnv:
         self._bound = False
         self._serial += steps
         k = (steps - 1) % actions.shape[0]
-        self._raw_action = actions[k]
+        self._raw_action, self._raw_action_rows = actions[k], False
 
     @property
     def plane_stride(self):
@@ -628,7 +637,7 @@ class BenchmarkEnv:
             self.seed(self.RND_SEED)
         self._ensure_engine()
         self.initial_reset = True
-        self._raw_action = None
+        self._raw_action, self._raw_action_rows = None, False
         for mode in self.disturbances:
             self.disturbances[mode].reset(self)
         if self.adversary_disturbance is not None:
@@ -660,16 +669,21 @@ class BenchmarkEnv:
         return info
 
     def _load_action(self, action):
-        """Raw action into the SoA planes.  [N, nu] row-major costs one transpose copy; a tensor that
-        already IS the SoA buffer (``env.action_buffer`` or its transpose) costs nothing."""
+        """-> (tensor, rows): the raw action as the kernel will read it.  A float32 device tensor [N, nu] (what a policy
+        emits) is read in place, one 4 nu-byte vector per lane (``rows=True``); a tensor that already IS SoA planes
+        (``env.action_buffer`` / its transpose, or [nu, ld]) is read in place as planes; anything else (host arrays, other
+        dtypes, odd strides) is copied into the env's action planes."""
         buf = self._bufs['action']
         n, nu = self.num_envs, self.action_dim
         if isinstance(action, torch.Tensor):
             if action.data_ptr() == buf.data_ptr():
-                return buf
+                return buf, False                      # env.action_buffer (or its [N, nu] view): the planes themselves
             if (action.shape == (nu, self._ld) and action.dtype == torch.float32 and action.is_contiguous()
                     and action.device == buf.device):
-                return action                      # already SoA with the engine's plane stride: zero copy
+                return action, False                   # already SoA with the engine's plane stride: zero copy
+            if (action.shape == (n, nu) and action.dtype == torch.float32 and action.is_contiguous()
+                    and action.device == buf.device and action.data_ptr() % (4 * nu) == 0):
+                return action, True                    # row-major rows, read as vectors: zero copy
             a = action.to(device=self.device, dtype=torch.float32)
         else:
             a = torch.as_tensor(np.asarray(action, dtype=np.float32), device=self.device)
@@ -682,13 +696,13 @@ class BenchmarkEnv:
         else:
             raise ValueError('[ERROR] action must have shape (num_envs, action_dim) = (%d, %d), got %s'
                              % (n, nu, tuple(a.shape)))
-        return buf
+        return buf, False
 
     def step(self, action):
         """Advance every env by one control step (quadrotor.py:507-558 + benchmark_env.py:422-463)."""
         self._check_initial_reset()
-        act = self._load_action(action)
-        self._raw_action = act
+        act, rows = self._load_action(action)
+        self._raw_action, self._raw_action_rows = act, rows
         b = self._bufs
         if self.adversary_disturbance is not None:
             # adversary inputs (benchmark_env.py:256-266, quadrotor.py:529-536,837-838) arrive as planes; the passive
@@ -697,7 +711,7 @@ class BenchmarkEnv:
             io['action'] = act
             io['reset_state'] = self._reset_state_buf
             self._adversary_planes(io)
-            self._engine.step(io, self.num_envs, self._ld, self._serial)
+            self._engine.step(io, self.num_envs, self._ld, self._serial, action_rows=rows)
             self._bound = False
         else:
             if not self._bound:
@@ -705,7 +719,7 @@ class BenchmarkEnv:
                 io['reset_state'] = self._reset_state_buf
                 self._engine.bind_static(io, self._ld)
                 self._bound = True
-            self._engine.step_bound(act, self.num_envs, self._serial)
+            self._engine.step_bound(act, self.num_envs, self._serial, action_rows=rows)
         self._serial += 1
         obs, rew, done = self._out_views
         info = dict(self._info_views)

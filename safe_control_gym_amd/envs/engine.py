@@ -84,9 +84,10 @@ class Engine:
             setattr(io, name, None if t is None else t.data_ptr())
         return io
 
-    def step(self, bufs, n, ld, serial):
+    def step(self, bufs, n, ld, serial, action_rows=False):
         io = self._bind(bufs, ld)
         io.reset_serial = serial & 0xffffffff
+        io.action_rows = int(action_rows)
         with torch.cuda.device(self.device):
             _capi.check(self.lib.scg_step(self.handle, C.byref(io), n, self._stream()), 'scg_step')
 
@@ -95,10 +96,11 @@ class Engine:
         self._bind(bufs, ld)
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
 
-    def step_bound(self, action, n, serial):
-        """Hot path of env.step(): ~3 ctypes stores and one foreign call."""
+    def step_bound(self, action, n, serial, action_rows=False):
+        """Hot path of env.step(): ~4 ctypes stores and one foreign call."""
         io = self._io
         io.action = action.data_ptr()
+        io.action_rows = int(action_rows)
         io.reset_serial = serial & 0xffffffff
         if torch.cuda.current_device() == self._dev_index:
             status = self.lib.scg_step(self.handle, C.byref(io), n, self._stream())
@@ -113,6 +115,7 @@ class Engine:
         used cyclically."""
         io = self._bind(bufs, ld)
         io.action = actions.data_ptr()
+        io.action_rows = 0
         io.reset_serial = serial & 0xffffffff
         period, stride = actions.shape[0], actions.shape[1] * actions.shape[2]
         with torch.cuda.device(self.device):

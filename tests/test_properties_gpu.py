@@ -320,3 +320,29 @@ def test_aero_terms_known_answers_on_device(gpu):
     assert res['pyb_drag'][1] - 2.0 == pytest.approx(-k * 2.0 / m * dt, rel=2e-3) and abs(res['pyb_drag'][5]) < 1e-6
     assert res['pyb_gnd_drag_dw'][5] == pytest.approx(res['pyb_gnd'][5], rel=1e-3)
     assert res['pyb_gnd_drag_dw'][1] - 2.0 == pytest.approx(res['pyb_drag'][1] - 2.0, rel=0.2)    # more thrust -> more rpm
+
+
+def test_row_major_actions_are_read_in_place(gpu):
+    """A policy's [N, nu] float32 output goes to the kernel as is (scg_step_io.action_rows: one vector load per lane);
+    results are bit-identical to the same actions given as SoA planes or as a host array, for nu = 1, 2, 4 and for an
+    env with input constraints (which judge the RAW action, constraints.py:167-168)."""
+    for make_kw, nu in ((dict(quad_type=1), 1), (dict(quad_type=2), 2), (dict(quad_type=3, task='traj_tracking'), 4)):
+        kw = dict(num_envs=3001, device='cuda', seed=4, randomized_init=True, cost='quadratic',
+                  constraints=[{'constraint_form': 'default_constraint', 'constrained_variable': 'input'}], **make_kw)
+        a, b, c = (scg.make('quadrotor', **kw) for _ in range(3))
+        a.reset(), b.reset(), c.reset()
+        g = torch.Generator(device='cuda'); g.manual_seed(nu)
+        lo, hi = float(a.action_space.low[0]), float(a.action_space.high[0])
+        for k in range(12):
+            act = (torch.rand((3001, nu), generator=g, device='cuda') * 1.4 - 0.2) * (hi - lo) + lo      # some out of bounds
+            planes = b.action_buffer
+            planes[:, :] = act
+            oa, ra, da, ia = a.step(act)                       # rows, in place
+            ob, rb, db, ib = b.step(planes)                    # SoA planes
+            oc, rc, dc, ic = c.step(act.cpu().numpy())         # host array (copied)
+            assert a._raw_action_rows and not b._raw_action_rows and not c._raw_action_rows
+            for x, y, z in ((oa, ob, oc), (ra, rb, rc), (da, db, dc), (ia['constraint_values'], ib['constraint_values'], ic['constraint_values'])):
+                assert torch.equal(x, y) and torch.equal(x, z), (nu, k)
+            assert torch.equal(a.current_raw_input_action, act)
+        for e in (a, b, c):
+            e.close()
