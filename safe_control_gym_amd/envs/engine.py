@@ -44,6 +44,7 @@ class Engine:
         self.obs_dim = self.lib.scg_obs_dim(handle)
         self._io = _capi.ScgStepIO()
         self._io.struct_size = C.sizeof(_capi.ScgStepIO)
+        self._io_ref = C.byref(self._io)
 
     def close(self):
         if getattr(self, 'handle', None):
@@ -56,7 +57,14 @@ class Engine:
         except Exception:
             pass
 
+    _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
     def _stream(self):
+        """The current HIP stream of this engine's device as a raw handle.  torch.cuda.current_stream() costs ~4 us of
+        Python per call (device-index normalisation, lazy-init checks); the raw accessor is what it ends up calling."""
+        if Engine._raw_stream is not None:
+            idx = self.device.index
+            return C.c_void_p(Engine._raw_stream(torch.cuda.current_device() if idx is None else idx))
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def reset(self, bufs, mask, reset_state, serial, n, ld):
@@ -102,11 +110,11 @@ class Engine:
         io.action = action.data_ptr()
         io.action_rows = int(action_rows)
         io.reset_serial = serial & 0xffffffff
-        if torch.cuda.current_device() == self._dev_index:
-            status = self.lib.scg_step(self.handle, C.byref(io), n, self._stream())
+        if Engine._raw_stream is not None and torch.cuda.current_device() == self._dev_index:
+            status = self.lib.scg_step(self.handle, self._io_ref, n, Engine._raw_stream(self._dev_index))
         else:
             with torch.cuda.device(self.device):
-                status = self.lib.scg_step(self.handle, C.byref(io), n, self._stream())
+                status = self.lib.scg_step(self.handle, self._io_ref, n, self._stream())
         if status != 0:
             _capi.check(status, 'scg_step')
 
