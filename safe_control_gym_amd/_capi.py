@@ -180,6 +180,15 @@ def check(status, what):
         raise ScgError('%s failed (status %d): %s' % (what, status, msg.decode() if msg else ''))
 
 
+def current_stream(device):
+    """Raw handle of torch's current HIP stream on ``device`` (the launches of the C ABI go there).  The raw accessor is
+    what ``torch.cuda.current_stream()`` ends up calling, without ~4 us of Python in front of it."""
+    import torch
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    raw = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+    return C.c_void_p(raw(idx) if raw is not None else torch.cuda.current_stream(device).cuda_stream)
+
+
 def ptr(t):
     """Device address of a torch tensor (or None)."""
     return None if t is None else C.c_void_p(t.data_ptr())

@@ -107,7 +107,7 @@ def compute_returns_and_advantages(rews, vals, masks, terminal_vals=0, last_val=
     rets = torch.empty((T, N), dtype=torch.float32, device=dev)
     advs = torch.empty((T, N), dtype=torch.float32, device=dev)
     stats = torch.zeros(2, dtype=torch.float64, device=dev) if normalize_advantages else None
-    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    stream = _capi.current_stream(dev)
     p = _capi.ptr
     with torch.cuda.device(dev):
         rew_out = rew if tv is not None else None                    # in-place, as the reference does

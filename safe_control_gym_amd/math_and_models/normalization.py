@@ -73,7 +73,7 @@ class RunningMeanStd:
 
 
 def _stream(device):
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return _capi.current_stream(device)
 
 
 class BaseNormalizer:
