@@ -7,7 +7,6 @@ step to host NumPy arrays of shape (T, N, ...) and walks T in Python; here the (
 (``env.step`` already returns device tensors) and the backward recursion is one HIP kernel launch
 (``scg_gae`` in ``include/scg_rollout.h``), one lane per env.
 """
-import ctypes as C
 
 import numpy as np
 import torch

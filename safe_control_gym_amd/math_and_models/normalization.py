@@ -12,7 +12,6 @@ NumPy arrays.
 Observations are taken zero-copy when they are the engine's own ``[N, d]`` view of SoA planes
 (``env.step()``'s obs: stride (1, ld)); any other tensor is transposed into planes first.
 """
-import ctypes as C
 import math
 
 import numpy as np

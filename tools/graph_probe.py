@@ -1,4 +1,4 @@
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import safe_control_gym_amd as scg
