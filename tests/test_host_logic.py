@@ -220,8 +220,10 @@ def test_c_abi_header_matches_library_and_binding():
     assert lib.scg_sizeof_config() == ctypes.sizeof(_capi.ScgConfig)
     assert lib.scg_sizeof_step_io() == ctypes.sizeof(_capi.ScgStepIO)
     assert lib.scg_sizeof_constraint_row() == ctypes.sizeof(_capi.ScgConstraintRow)
+    assert lib.scg_sizeof_disturbance() == ctypes.sizeof(_capi.ScgDisturbance)
     for macro, val in (('SCG_MAX_NX', _capi.SCG_MAX_NX), ('SCG_MAX_NU', _capi.SCG_MAX_NU), ('SCG_MAX_NV', _capi.SCG_MAX_NV),
-                       ('SCG_MAX_CONSTRAINT_ROWS', _capi.SCG_MAX_CONSTRAINT_ROWS), ('SCG_ABI_VERSION', _capi.SCG_ABI_VERSION)):
+                       ('SCG_MAX_CONSTRAINT_ROWS', _capi.SCG_MAX_CONSTRAINT_ROWS), ('SCG_ABI_VERSION', _capi.SCG_ABI_VERSION),
+                       ('SCG_MAX_DISTURBANCES', _capi.SCG_MAX_DISTURBANCES)):
         assert int(re.search(r'#define %s (\d+)' % macro, header).group(1)) == val
 
 
@@ -235,6 +237,15 @@ def test_c_abi_rejects_bad_arguments_without_gpu_work():
     assert b'struct_size' in lib.scg_last_error()
     assert lib.scg_step(None, None, 0, None) == -1
     assert lib.scg_destroy(None) == 0
+    # the next-row entry points validate before they launch anything, too
+    assert lib.scg_set_disturbances(None, None, 0) == -1
+    assert lib.scg_linearize(None, None, None, None, None, None, 0.0, 0, 0, None) == -1
+    assert lib.scg_model_eval(None, None, None, None, None, None, 0, 0, None) == -1
+    assert lib.scg_quadratic_loss(None, None, None, None, None, None, 0, None, 0, None, None, None, 0, 0, None) == -1
+    assert lib.scg_mean_std_normalize(None, None, 3, 8, 8, 4, None, None, None, 10.0, 1e-8, None) == -1
+    assert lib.scg_reward_normalize(None, None, None, None, 4, None, None, None, 0.99, 10.0, 1e-8, 0, None) == -1
+    assert lib.scg_gae(None, None, None, None, None, None, None, None, None, 4, 4, 4, 0.99, 0.95, 1, None) == -1
+    assert b'null' in lib.scg_last_error()
 
 
 def test_shard_bounds_partition():
