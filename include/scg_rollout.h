@@ -10,9 +10,11 @@
  * Conventions
  *   - plain C, no C++/torch types; every array argument of scg_step/scg_reset/scg_rollout is a
  *     DEVICE pointer owned by the caller (e.g. torch.Tensor.data_ptr() of a ROCm tensor);
- *     the handle owns only its constant tables (reference trajectory, constraint rows).
+ *     the handle owns only its constant tables (reference trajectory, constraint rows, disturbance entries).
  *   - struct-of-arrays layout: a "plane" is N consecutive values of one state/action/constraint
  *     component; plane j of an array starts at base + j*ld elements (ld >= n, the plane stride).
+ *     Row-major exceptions, each said where it is declared: scg_step_io.terminal_record, the action when
+ *     scg_step_io.action_rows = 1, and the Jacobian batches of scg_linearize.
  *   - every launch is asynchronous on the hipStream_t passed in; no implicit synchronisation.
  *   - return value: 0 on success, negative scg_status on error; nothing throws across the ABI;
  *     scg_last_error() returns a thread-local message for the last failing call.
