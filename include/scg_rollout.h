@@ -305,12 +305,12 @@ int scg_quadratic_loss(scg_handle* h, const double* Q, const double* R, const fl
  * update RunningMeanStd (:34-62) with the batch of n rows, then y = clip((x - mean) / sqrt(var + epsilon), +-clip).
  * state_in / state_out are device records of 2 d + 1 doubles: mean[d], var[d], count (the caller ping-pongs two
  * records; a fresh tracker is mean 0, var 1, count 1e-4, :28-30).  state_out == NULL is the read_only normaliser
- * (:126): no update.  scratch is device memory for 128 d doubles (per-workgroup partial sums).  y may alias x. */
+ * (:126): no update.  scratch is device memory for 2 max(64 d, 1024) doubles (per-workgroup partial sums).  y may alias x. */
 int scg_mean_std_normalize(const float* x, float* y, int32_t d, int64_t ld_x, int64_t ld_y, int64_t n,
                            const double* state_in, double* state_out, double* scratch, float clip, double epsilon,
                            void* stream);
 /* RewardStdNormalizer.__call__ (:172-189): ret = ret * gamma + rew; update the tracker (d = 1 record) with ret;
- * clear ret of finished envs; out = clip(rew / sqrt(var + epsilon), +-clip).  scratch: 192 doubles.
+ * clear ret of finished envs; out = clip(rew / sqrt(var + epsilon), +-clip).  scratch: 3072 doubles.
  * legacy_index_reset != 0 reproduces `self.ret[dones.astype(np.long)] = 0` literally (it indexes with the VALUES 0 / 1
  * of dones: ret[0] is cleared when some env is not done, ret[1] when some env is done); 0 clears ret where done. */
 int scg_reward_normalize(const float* rew, const uint8_t* done, float* ret, float* out, int64_t n,

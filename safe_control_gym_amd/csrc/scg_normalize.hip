@@ -33,7 +33,9 @@ __device__ __forceinline__ const double* st_mean(const double* s) { return s; }
 __device__ __forceinline__ const double* st_var(const double* s, int d) { return s + d; }
 
 // ---- pass 1 ---------------------------------------------------------------------------------------
-constexpr int kMaxPartials = 64;          // workgroups per feature (= lanes of the wave that sums them in pass 2)
+// workgroups (= partial sums) per feature: enough of them to occupy the chip when there are few features
+// (the reward tracker has one), few enough that every wave of pass 2 can re-sum them for pennies
+__host__ __device__ constexpr int max_partials(int d) { return d >= 16 ? 64 : 1024 / d; }
 typedef float nf4 __attribute__((ext_vector_type(4)));
 
 // block-wide sum of up to 3 doubles; result valid in thread 0
@@ -53,7 +55,7 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double* lds) {
     }
 }
 
-// partials: [d][kMaxPartials][2]
+// partials: [d][max_partials(d)][2]
 template <bool VEC>
 __global__ __launch_bounds__(256) void scg_moments_kernel(const float* __restrict__ x, int64_t ld, uint32_t n,
                                                           const double* __restrict__ state, int d,
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void scg_moments_kernel(const float* __restric
     }
     block_sum<2>(acc, lds);
     if (threadIdx.x == 0) {
-        double* out = partials + ((int64_t)j * kMaxPartials + blockIdx.x) * 2;
+        double* out = partials + ((int64_t)j * max_partials(d) + blockIdx.x) * 2;
         out[0] = acc[0];
         out[1] = acc[1];
     }
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void scg_moments_kernel(const float* __restric
 // "information leak" reset.  legacy == 0: ret[i] = 0 where done[i] (what the comment at :187 intends).
 // legacy != 0 reproduces the reference statement literally -- `self.ret[dones.astype(np.long)] = 0` indexes with
 // the 0 / 1 VALUES of dones, i.e. clears ret[0] when some env is not done and ret[1] when some env is done --
-// which the normalise pass applies once the done count is known.  partials: [kMaxPartials][3].
+// which the normalise pass applies once the done count is known.  partials: [max_partials(1)][3].
 __global__ __launch_bounds__(256) void scg_reward_moments_kernel(const float* __restrict__ rew,
                                                                  const uint8_t* __restrict__ done,
                                                                  float* __restrict__ ret, uint32_t n, float gamma,
@@ -124,12 +126,19 @@ __global__ __launch_bounds__(256) void scg_reward_moments_kernel(const float* __
     }
 }
 
-// every lane of the calling wave gets the sum over the feature's `count` partials (count <= 64)
+// every lane of the calling wave gets the sum over the feature's `count` partials (fixed order: bit-reproducible)
 template <int K>
 __device__ __forceinline__ void sum_partials(const double* __restrict__ p, int count, double (&tot)[K]) {
     const int lane = threadIdx.x & 63;
+    double acc[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) tot[k] = wsum(lane < count ? p[lane * K + k] : 0.0);
+    for (int k = 0; k < K; ++k) acc[k] = 0.0;
+    for (int q = lane; q < count; q += 64) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] += p[q * K + k];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) tot[k] = wsum(acc[k]);
 }
 
 // ---- RunningMeanStd.update_from_moments (:41-62) for one feature --------------------------------------
@@ -162,7 +171,7 @@ __global__ __launch_bounds__(256) void scg_mean_std_apply_kernel(const float* __
     double mean = state_in[j], var = state_in[d + j];
     if (state_out) {
         double tot[2];
-        sum_partials<2>(partials + (int64_t)j * kMaxPartials * 2, n_partials, tot);
+        sum_partials<2>(partials + (int64_t)j * max_partials(d) * 2, n_partials, tot);
         const Updated u = update_from_moments(mean, var, state_in[2 * d], mean, tot[0], tot[1], (double)n);
         mean = u.mean; var = u.var;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -225,9 +234,9 @@ __global__ __launch_bounds__(256) void scg_reward_apply_kernel(const float* __re
 }
 
 // ---- launchers ------------------------------------------------------------------------------------
-static unsigned partial_blocks(int64_t n) {
-    int64_t b = (n + 4095) / 4096;                              // >= 16 elements per thread
-    if (b > kMaxPartials) b = kMaxPartials;
+static unsigned partial_blocks(int64_t n, int d) {
+    int64_t b = (n + 1023) / 1024;                              // >= 4 elements per thread
+    if (b > max_partials(d)) b = max_partials(d);
     return (unsigned)(b < 1 ? 1 : b);
 }
 static unsigned apply_blocks(int64_t n, int d) {
@@ -237,11 +246,11 @@ static unsigned apply_blocks(int64_t n, int d) {
     return (unsigned)(b < 1 ? 1 : b);
 }
 
-// scratch: d * kMaxPartials * 2 doubles (mean / std normaliser), kMaxPartials * 3 doubles (reward normaliser)
+// scratch: 2 d max_partials(d) doubles (mean / std normaliser), 3 max_partials(1) = 3072 doubles (reward normaliser)
 hipError_t launch_mean_std_normalize(const float* x, float* y, int d, int64_t ld_x, int64_t ld_y, int64_t n,
                                      const double* state_in, double* state_out, double* partials, float clip,
                                      double epsilon, hipStream_t s) {
-    const unsigned pb = partial_blocks(n);
+    const unsigned pb = partial_blocks(n, d);
     if (state_out) {
         const dim3 grid(pb, (unsigned)d), block(256);
         const bool vec = ((reinterpret_cast<uintptr_t>(x) | (uintptr_t)(ld_x * 4)) & 15u) == 0;
@@ -261,7 +270,7 @@ hipError_t launch_mean_std_normalize(const float* x, float* y, int d, int64_t ld
 hipError_t launch_reward_normalize(const float* rew, const uint8_t* done, float* ret, float* out, int64_t n,
                                    const double* state_in, double* state_out, double* partials, float gamma,
                                    float clip, double epsilon, int legacy, hipStream_t s) {
-    const unsigned pb = partial_blocks(n);
+    const unsigned pb = partial_blocks(n, 1);
     if (state_out)
         hipLaunchKernelGGL(scg_reward_moments_kernel, dim3(pb), dim3(256), 0, s, rew, done, ret, (uint32_t)n, gamma,
                            state_in, legacy, partials);

@@ -37,7 +37,7 @@ class RunningMeanStd:
         self._state[:, self.d:2 * self.d] = 1.0
         self._state[:, 2 * self.d] = epsilon
         self._cur = 0
-        self._moments = torch.zeros(max(128 * self.d, 192), dtype=torch.float64, device=self.device)   # kernel scratch
+        self._moments = torch.zeros(max(2 * max(64 * self.d, 1024), 3072), dtype=torch.float64, device=self.device)   # kernel scratch
 
     # the reference's attributes, as views of the current record
     @property
