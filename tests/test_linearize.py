@@ -311,3 +311,44 @@ def test_model_eval_matches_oracle(gpu, system):
         assert torch.allclose(env2.state, env.model_step(xt, ut), rtol=1e-5, atol=2e-5)
         env2.close()
     env.close()
+
+
+@pytest.mark.gpu
+def test_golden_models_on_device(gpu):
+    """Replay tests/golden/models.npz (frozen oracle outputs) through the HIP kernels: df_func, fc_func, fd_func, the
+    quadratic loss with its gradients, and both normalisers."""
+    import os
+    import torch
+    from safe_control_gym_amd.math_and_models.normalization import MeanStdNormalizer, RewardStdNormalizer
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'models.npz'))
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32, device='cuda')
+    rel = lambda dev, ref, scale=1.0: float(np.max(np.abs(dev.cpu().numpy().astype(np.float64) - ref) / np.maximum(np.abs(ref), scale)))
+    for tag, system in (('q1', 1), ('q2', 2), ('q3', 3), ('cp', 'cartpole')):
+        env = _make(system, 16, ctrl_freq=50, pyb_freq=50, cost='quadratic')
+        env.reset()
+        x, u = t(g[tag + '_x']), t(g[tag + '_u'])
+        A, B = env.linearize(x, u)
+        assert rel(A, g[tag + '_A']) <= RTOL and rel(B, g[tag + '_B']) <= RTOL
+        # f cancels large terms (see test_model_eval_matches_oracle): bound relative to |A||x| + |B||u| + g
+        scale = 1.0 + np.abs(g[tag + '_A']) @ np.abs(g[tag + '_x'])[..., None] + np.abs(g[tag + '_B']) @ np.abs(g[tag + '_u'])[..., None] + 9.8
+        f = env.model_dynamics(x, u).cpu().numpy().astype(np.float64)
+        assert np.max(np.abs(f - g[tag + '_f']) / scale[..., 0]) <= RTOL
+        xn = env.model_step(x, u).cpu().numpy().astype(np.float64)
+        assert np.max(np.abs(xn - g[tag + '_xnext']) / np.maximum(np.abs(g[tag + '_xnext']), 1.0 + 0.02 * scale[..., 0])) <= RTOL
+        out = env.quadratic_loss(x, u, x_ref=g[tag + '_xr'], u_ref=g[tag + '_ur'], Q=g[tag + '_Q'], R=g[tag + '_R'])
+        assert rel(out['l'], g[tag + '_l'], max(1.0, np.abs(g[tag + '_l']).max())) <= 2e-5
+        assert rel(out['l_x'], g[tag + '_lx'], max(1.0, np.abs(g[tag + '_lx']).max())) <= 2e-5
+        assert rel(out['l_u'], g[tag + '_lu'], max(1.0, np.abs(g[tag + '_lu']).max())) <= 2e-5
+        env.close()
+    norm = MeanStdNormalizer(shape=(5,), clip=3.0)
+    for b in range(3):
+        y = norm(t(g['norm_x%d' % b]))
+        assert rel(y, g['norm_y%d' % b]) <= 5 * RTOL
+        assert np.allclose(norm.rms.mean.cpu().numpy(), g['norm_mean%d' % b], rtol=1e-12, atol=1e-12)
+        assert np.allclose(norm.rms.var.cpu().numpy(), g['norm_var%d' % b], rtol=1e-10)
+    rnorm = RewardStdNormalizer(gamma=0.9, clip=5.0)
+    for b in range(6):
+        out = rnorm(t(g['rnorm_rew%d' % b]), torch.as_tensor(g['rnorm_done%d' % b], device='cuda'))
+        assert rel(out, g['rnorm_out%d' % b]) <= 5 * RTOL
+        assert rel(rnorm.ret, g['rnorm_ret%d' % b]) <= 2e-5
+        assert float(rnorm.rms.var) == pytest.approx(float(g['rnorm_var%d' % b]), rel=1e-5)

@@ -319,3 +319,18 @@ def test_aero_terms_known_answers():
     assert np.allclose(f2, f3, rtol=1e-12, atol=1e-18)
     g2, g3 = rm.ground_effect_thrusts(2, x2, T, p), rm.ground_effect_thrusts(3, x3, u3, p)
     assert g2[0] == pytest.approx(g3[0] + g3[3], rel=1e-12) and g2[1] == pytest.approx(g3[1] + g3[2], rel=1e-12)
+
+
+def test_golden_models_match_oracle():
+    """tests/golden/models.npz (made by tests/golden/make_golden_models.py) freezes the oracle's model queries,
+    loss and normalisers: regenerate-and-compare."""
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location('make_golden_models', os.path.join(here, 'golden', 'make_golden_models.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    fresh = mod.build()
+    frozen = np.load(os.path.join(here, 'golden', 'models.npz'))
+    assert set(frozen.files) == set(fresh)
+    for k in frozen.files:
+        assert np.allclose(frozen[k], fresh[k], rtol=1e-13, atol=1e-15), k
