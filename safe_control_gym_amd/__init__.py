@@ -9,10 +9,10 @@ from safe_control_gym_amd.utils.registration import register, make, spec, get_co
 
 register(id='quadrotor',
          entry_point='safe_control_gym_amd.envs.quadrotor:Quadrotor',
-         config_entry_point='safe_control_gym_amd.envs:quadrotor.yaml')
+         config_entry_point='safe_control_gym_amd.envs:quadrotor_defaults.yaml')
 
 register(id='cartpole',
          entry_point='safe_control_gym_amd.envs.cartpole:CartPole',
-         config_entry_point='safe_control_gym_amd.envs:cartpole.yaml')
+         config_entry_point='safe_control_gym_amd.envs:cartpole_defaults.yaml')
 
 __version__ = '0.1.0'

@@ -11,6 +11,8 @@ import os
 
 import yaml
 
+_CONFIG_GROUPS = ('timing', 'vehicle', 'start', 'objective', 'actions', 'safety', 'perturbations', 'interface', 'engine')
+
 _SPECS = {}
 
 
@@ -39,7 +41,14 @@ class Spec:
             module, fname = cep.split(':')
             folder = os.path.dirname(importlib.import_module(module).__file__)
             with open(os.path.join(folder, fname)) as f:
-                return yaml.safe_load(f)
+                groups = yaml.safe_load(f)
+            flat = {}
+            for name, group in groups.items():           # the defaults files group the options; callers get them flat
+                if isinstance(group, dict) and name in _CONFIG_GROUPS:
+                    flat.update(group)
+                else:
+                    flat[name] = group
+            return flat
         return self._resolve(cep)
 
     def make(self, *args, **kwargs):
