@@ -238,8 +238,9 @@ def main():
                 'achieved_GBs': bytes2 * n / (bus * 1e-6) / 1e9, 'frac': bytes2 * n / (bus * 1e-6) / 1e9 / HBM_PEAK_GBS}
         env2.close()
 
+    two_queues = (n // 2) // 256 * 256 >= 131072 and os.environ.get('SCG_ROLLOUT_QUEUES', '2') != '1'
     if rank == 0:
-        kernel_us = dev_ms * 1e3 / args.steps            # HIP-event time over the timed region / launches
+        kernel_us = dev_ms * 1e3 / args.steps            # HIP-event time over the timed region / steps (passes over the batch)
         achieved = bytes_per * n / (kernel_us * 1e-6) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
@@ -258,12 +259,18 @@ def main():
                        'envs_per_gpu': n,
                        'total_envs': n * world, 'bytes_per_env_step': bytes_per,
                        'moved_bytes_per_env_step': bytes_per - (8 if not args.no_episode_stats else 0),
-                       'launch': 'one fused scg_step kernel per step (scg_rollout issues the launches)',
+                       'launch': ('scg_rollout: per step one fused scg_step kernel per HALF batch, the two halves advancing on two HIP '
+                                  'streams so that one kernel\'s ramp-up / drain overlaps the other\'s body; time per step = time per '
+                                  'pass over the whole batch') if two_queues else
+                                 'one fused scg_step kernel per step (scg_rollout issues the launches)',
+                       'launches_per_step': 2 if two_queues else 1,
                        'sharding': 'envs block-sharded by global index; all-gather of episode returns every '
                                    '%d steps' % gather_every if world > 1 else 'single GPU'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel_us_per_launch': kernel_us, 'algorithmic_bytes_per_launch': bytes_per * n},
+                         'kernel_us_per_launch': kernel_us, 'algorithmic_bytes_per_launch': bytes_per * n,
+                         'note': 'per step of the whole batch; with launches_per_step = 2 the two half-batch kernels of a step run '
+                                 'concurrently, each for about this long, and bytes are those of both'},
         }
         if bare is not None:
             out['c4_without_episode_stats'] = bare

@@ -346,3 +346,40 @@ def test_row_major_actions_are_read_in_place(gpu):
             assert torch.equal(a.current_raw_input_action, act)
         for e in (a, b, c):
             e.close()
+
+
+@pytest.mark.parametrize('tier', ['lean', 'full_info', 'extra'])
+def test_two_queue_rollout_is_bit_identical_to_the_step_loop(gpu, tier):
+    """scg_rollout cuts batches of >= 2^18 envs in two halves that advance on two HIP streams (the tail of one half's
+    kernel overlaps the body of the other's).  Per env nothing changes: same arithmetic, same Philox counters (global env
+    index) -- so the buffers after K steps equal those of K single-stream env.step() calls bit for bit.  Odd n: the second
+    half is ragged."""
+    n = 300001
+    kw = dict(quad_type=3, num_envs=n, device='cuda', seed=21, randomized_init=True, task='traj_tracking', cost='quadratic',
+              episode_len_sec=0.25)
+    if tier == 'lean':
+        kw.update(info_level='minimal')
+    elif tier == 'extra':
+        kw.update(randomized_inertial_prop=True,
+                  disturbances={'dynamics': [{'disturbance_func': 'white_noise', 'std': 0.01}],
+                                'observation': [{'disturbance_func': 'impulse', 'magnitude': 0.05, 'step_offset': None, 'duration': 2}]},
+                  constraints=[{'constraint_form': 'default_constraint', 'constrained_variable': 'state'}])
+    a, b = scg.make('quadrotor', **kw), scg.make('quadrotor', **kw)
+    a.reset(), b.reset()
+    g = torch.Generator(device='cuda'); g.manual_seed(8)
+    lo, hi = float(a.action_space.low[0]), float(a.action_space.high[0])
+    acts = torch.rand((5, 4, a.plane_stride), generator=g, device='cuda') * (hi - lo) + lo
+    K = 23
+    a.rollout(acts, steps=K)
+    for k in range(K):
+        b.step(acts[k % 5])
+    torch.cuda.synchronize()
+    for key in a._bufs:
+        if key == 'action':
+            continue
+        x, y = a._bufs[key], b._bufs[key]
+        if key == 'terminal_record':                      # rows of envs that never finished hold stale zeros on both sides
+            x, y = x[:n], y[:n]
+        assert torch.equal(x, y), (tier, key)
+    assert int(a.ctrl_step_counter.max()) < 15           # episodes of 15 steps: every env was reset at least once
+    a.close(), b.close()
