@@ -11,13 +11,13 @@ def mk(n, base):
     a = torch.rand((300, 4, e.plane_stride), device='cuda') * (hi - lo) + lo
     return e, a
 
-N = 1 << 20
+N = 3 * (1 << 18) * 1 + (1 << 18)
 full, af = mk(N, 0)
 full.rollout(af, steps=300); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); full.rollout(af, steps=1500); e1.record(); torch.cuda.synchronize()
 print('one kernel per step        : %.2f us/step' % (e0.elapsed_time(e1) / 1500 * 1e3))
-for parts in (2, 4):
+for parts in (2, 3):
     envs = [mk(N // parts, k * (N // parts)) for k in range(parts)]
     streams = [torch.cuda.Stream() for _ in range(parts)]
     for (e, a), s in zip(envs, streams):
