@@ -246,7 +246,10 @@ int scg_step(scg_handle* h, const scg_step_io* io, int64_t n, void* stream);
  * open-loop rollout loop of the reference's harnesses (tests/scripts/verbose_api.py:71-77: sample an
  * action, step, repeat) with the action sequence pre-generated on the device; every other buffer of
  * `io` is reused by all steps, so the outputs hold the LAST step's values and ep_return / ep_length /
- * stats accumulate.  Same kernel, one launch per step: per-step HBM traffic is that of scg_step(). */
+ * stats accumulate.  Same kernel and per-step HBM traffic as scg_step().  Batches of >= 2^18 envs are cut in two halves whose
+ * step chains are issued on `stream` and on a second, handle-owned stream (forked from and joined back into `stream` by
+ * events inside this call), so that one half's kernel ramp-up / drain overlaps the other half's body; per env the results
+ * are bit-identical to single-stream stepping.  SCG_ROLLOUT_QUEUES=1 in the environment keeps everything on `stream`. */
 int scg_rollout(scg_handle* h, const scg_step_io* io, int64_t n, int32_t steps, int64_t action_stride,
                 int32_t action_period, void* stream);
 
