@@ -549,8 +549,9 @@ int scg_rollout(scg_handle* h, const scg_step_io* io, int64_t n, int32_t steps, 
     // kernel overlaps the body of the other's (measured 24.9 vs 29.0 us per step of the whole batch; four queues are
     // slower again).  Per env the arithmetic, the Philox counters and therefore the results are unchanged.
     static const int queues = [] { const char* e = getenv("SCG_ROLLOUT_QUEUES"); const int v = e ? atoi(e) : 2; return v == 1 ? 1 : 2; }();
+    static const int64_t split_min = [] { const char* e = getenv("SCG_ROLLOUT_SPLIT_MIN"); return e ? (int64_t)atoll(e) : (int64_t)131072; }();
     const int64_t half = (n / 2) / 256 * 256;
-    if (queues == 2 && steps >= 2 && half >= 131072) {
+    if (queues == 2 && steps >= 2 && half >= split_min && half > 0) {
         scg_step_io first_io = *io;
         first_io.reset_serial = io->reset_serial;
         if (int rc = scg_step(h, &first_io, 0, stream)) return rc;          // validates the buffers, launches nothing (n = 0)
