@@ -9,10 +9,14 @@
 // wavefront is one fully coalesced 256-byte transaction (64 lanes x 4 B).  All per-step
 // constants are wave-uniform: they arrive in the kernarg block / constant tables and are read
 // with scalar loads into SGPRs; the per-step reference table X_GOAL (indexed by each lane's own
-// step counter, since envs de-synchronise after auto-reset) is staged once per workgroup into
-// LDS.  Batch reductions (reward sum, done / violation counts, finished-episode returns) use
-// wavefront shuffles and one atomic per wave.  No MFMA: a 12-state ODE per lane has no
-// contraction worth a matrix core; the kernel is HBM-bandwidth bound.
+// step counter, since envs de-synchronise after auto-reset) is gathered as float4 rows through the
+// L1 (14 KB: resident), or staged once per workgroup into LDS (SCG_REF_IN_LDS=1; measured slower at
+// this table size).  LDS also carries the wave-cooperative Philox reset: the lanes that finish an
+// episode publish their env index, every lane evaluates one Philox block for one (env, block) job,
+// the uniforms return through LDS.  Batch reductions (reward sum, done / violation counts,
+// finished-episode returns) use wavefront shuffles and one atomic per wave.  No MFMA: a 12-state ODE
+// per lane has no contraction worth a matrix core; the kernel is co-bound by HBM bandwidth and VALU
+// issue.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
