@@ -2,8 +2,9 @@
 """Headline benchmark: env-steps/sec of the fused HIP ``env.step()`` at N parallel envs.
 
 Contract (see the build prompt): ``python bench.py --gpus N --steps K --warmup W`` -> rank 0 prints
-ONE JSON line.  A "step" is one pass of the hot path (one ``scg_step`` kernel launch) over one batch
-of synthetic input: every env of the batch advances by one control step.
+ONE JSON line.  A "step" is one pass of the hot path over one batch of synthetic input: every env of the
+batch advances by one control step (``scg_rollout`` issues the fused ``scg_step`` kernel once per step, or --
+from 2^18 envs on -- once per half batch and step on two HIP streams; full HBM traffic every step).
 
 Workload (BASELINE.json ``configs``) -- the SAME per-GPU work at every N, so that the
 per-N values measure scaling and nothing else:
