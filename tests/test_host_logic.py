@@ -255,3 +255,18 @@ def test_shard_bounds_partition():
         assert spans[0][0] == 0 and spans[-1][1] == total
         assert all(spans[r][1] == spans[r + 1][0] for r in range(world - 1))
         assert [hi - lo for lo, hi in spans] == [len(c) for c in np.array_split(np.arange(total), world)]
+
+
+def test_bench_cli_contract_and_loud_failure_without_gpu():
+    """bench.py keeps the driver's flags (--gpus / --steps / --warmup) and, on a box without a ROCm device, fails loudly
+    instead of falling back to anything (the product has no CPU path)."""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, 'bench.py')
+    out = subprocess.run([sys.executable, bench, '--help'], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and all(f in out.stdout for f in ('--gpus', '--steps', '--warmup'))
+    import torch
+    if not torch.cuda.is_available():
+        run = subprocess.run([sys.executable, bench, '--steps', '2', '--warmup', '1', '--envs-per-gpu', '64', '--no-cpu-baseline'],
+                             capture_output=True, text=True, timeout=300)
+        assert run.returncode != 0 and not run.stdout.strip().startswith('{')
