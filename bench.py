@@ -1,27 +1,43 @@
 #!/usr/bin/env python
 """Headline benchmark: env-steps/sec of the fused HIP ``env.step()`` at N parallel envs.
 
-Contract (see the build prompt): ``python bench.py --gpus N --steps K --warmup W`` -> rank 0 prints
-ONE JSON line.  A "step" is one pass of the hot path over one batch of synthetic input: every env of the
-batch advances by one control step (``scg_rollout`` issues the fused ``scg_step`` kernel once per step, or --
-from 2^18 envs on -- once per half batch and step on two HIP streams; full HBM traffic every step).
+Contract (see the build prompt): ``python bench.py --gpus N --steps K --warmup W`` -> rank 0 prints ONE JSON line.
+A "step" is one pass of the hot path over one batch of synthetic input: every env of the batch advances by one control
+step (``scg_rollout`` issues the fused ``scg_step`` kernel once per step, or -- from 2^18 envs on -- once per half batch
+and step on two HIP streams; full HBM traffic every step).
 
-Workload (BASELINE.json ``configs``) -- the SAME per-GPU work at every N, so that the
-per-N values measure scaling and nothing else:
+Launch.  ``--gpus N`` with N > 1 and no torchrun environment: THIS process touches no GPU, starts N fresh child
+processes of this script (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set), relays
+rank 0's JSON line and exits non-zero if any child does -- the fan-out / gather of SubprocVecEnv
+(/root/reference/safe_control_gym/envs/env_wrappers/vectorized_env/subproc_vec_env.py:28-63) with processes instead of pipes.
+Under ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`` the ranks exist already and each runs the body.
+
+Workload (BASELINE.json ``configs``) -- the SAME per-GPU work at every N, so that the per-N
+values measure scaling and nothing else:
   * C4 = Quadrotor-3D trajectory tracking, 2^20 envs per GPU, quadratic cost, RK4, auto-reset, with the per-env
-    episode-return tracking every vectorised caller of the reference has (VecRecordEpisodeStatistics):
-    algorithmic bytes B = 8 nx + 4 nu + 13 + 16 = 141 per env-step.
+    episode-return tracking every vectorised caller of the reference has (VecRecordEpisodeStatistics).  SURVEY.md 8(d) counts
+    B = 8 nx + 4 nu + 13 + 16 = 141 bytes per env-step for it; the engine MOVES 133 (under auto-reset the episode length
+    is the step counter, so no ep_length plane exists) and ``roofline`` is computed on the bytes moved.
   * N > 1 -> C5: that shard on every GPU (weak scaling, envs sharded by contiguous global index) plus one RCCL
     all-gather of the episode returns every 300 steps (= one episode) inside the timed region.
-  * At N = 1 the line also carries ``c4_without_episode_stats``: the bare 125-byte step (``--no-episode-stats``
-    makes it the primary measurement).
-Actions are i.i.d. U(a_low, a_high) float32, pre-generated on the device ([300, nu, N]) and reused
-cyclically; initial / reset states are nominal + the reference's uniform offsets (Philox on device).
-Inputs are resident in HBM when the timed region starts.
+  * At N = 1 the line also carries sub-records, each a few hundred ms: ``c4_without_episode_stats`` (the bare 125-byte
+    step), ``precise_mode`` (the <= 1e-5-drift-over-1000-steps mode), ``c3`` and ``c2`` (BASELINE configs 3 and 2).
+Actions are i.i.d. U(a_low, a_high) float32, pre-generated on the device ([300, nu, N]) and reused cyclically; initial /
+reset states are nominal + the reference's uniform offsets (Philox on device).  Inputs are resident in HBM when the
+timed region starts.
+
+Clock.  ONE clock for ``value``, ``ms_per_step`` and ``roofline``: HIP events recorded on the stream the kernels are
+launched on, around EXACTLY K steps, between barrier + synchronize on both sides, MAX over ranks.  The region is repeated
+``--repeats`` times and the MEDIAN is reported (min / max beside it), so that K = 20 is not one noisy sample.  Each
+region's launches are queued behind a ~0.2 ms device-side delay, so the events see the kernels back to back (the steady
+state a long rollout is in) and not the host's first-launch latency; ``wall_ms_per_step`` is one more region of K steps
+timed with the host clock and no delay (sync -> K steps -> sync), reported beside it.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,61 +46,234 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.3 TB/s achievable)
+GATHER_EVERY = 300             # steps between two all-gathers of the episode returns (= one episode)
+C3_CONSTRAINTS = [{'constraint_form': 'bounded_constraint', 'constrained_variable': 'state', 'active_dims': [0, 2, 4],
+                   'lower_bounds': [-2, 0, -0.5], 'upper_bounds': [2, 2, 0.5]}]
 
 
-def build_env(args, rank, world):
-    import safe_control_gym_amd as scg
-    n = args.envs_per_gpu
-    track = not args.no_episode_stats
-    common = dict(num_envs=n, device='cuda', seed=1337, env_index_base=rank * n, randomized_init=True,
-                  info_level='minimal', track_episode_stats=track, ctrl_freq=60, pyb_freq=240, episode_len_sec=5)
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3000)
+    ap.add_argument('--warmup', type=int, default=100)
+    ap.add_argument('--repeats', type=int, default=5, help='timed regions of --steps steps each; the median is reported')
+    ap.add_argument('--envs-per-gpu', type=int, default=1 << 20)
+    ap.add_argument('--workload', default=None, help='c4 (default; called c5 when sharded over > 1 GPU), c3, c2')
+    ap.add_argument('--no-episode-stats', action='store_true', help='bare step without episode-return tracking (1 GPU only)')
+    ap.add_argument('--action-period', type=int, default=300)
+    ap.add_argument('--queues', type=int, default=0, help='scg_config.rollout_queues: 0 library default (2), 1, 2')
+    ap.add_argument('--python-loop', action='store_true', help='also time env.step() called from Python per step')
+    ap.add_argument('--fused', action='store_true', help='also time the one-launch multi-step rollout (own byte count)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-sub-records', '--no-bare', dest='no_sub', action='store_true',
+                    help='skip the secondary measurements (bare C4 step, precise mode, C3, C2)')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--env-kw', action='append', default=[], help='extra make() kwargs key=value (yaml), for experiments')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='rendezvous only (gloo, no GPU, no engine): every rank joins the process group, the collectives of the '
+                         'timed region run on tiny host tensors and rank 0 prints a line with "dry_run": true and no value -- '
+                         'what the CPU tests drive the launcher with')
+    ap.add_argument('--spawn-timeout', type=float, default=3000.0, help='seconds the launcher waits for its ranks')
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher: N fresh rank processes, no GPU call in this one
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def must_spawn(args, environ):
+    """The dispatch decision: spawn when N > 1 ranks are asked for and no launcher has created them already."""
+    return args.gpus > 1 and 'WORLD_SIZE' not in environ
+
+
+def spawn_ranks(args, argv):
+    """Start args.gpus children of this script, one per GPU; relay rank 0's JSON line; non-zero if any child fails.
+    Nothing here initialises HIP (no torch import): the children are new processes, never an exec of this one."""
+    world = args.gpus
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    deadline = time.time() + args.spawn_timeout
+    failed = None
+    pending = set(range(world))
+    while pending and failed is None:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0:
+                failed = (r, rc)
+                break
+        if time.time() > deadline:
+            failed = (-1, 124)
+        if pending and failed is None:
+            time.sleep(0.05)
+    if failed is not None:
+        # a dead rank leaves the others waiting in a rendezvous or a barrier: end exactly the children started here
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        who = 'timeout after %.0f s' % args.spawn_timeout if failed[0] < 0 else 'rank %d exited with %d' % failed
+        sys.stderr.write('bench.py: %s; the other ranks were stopped\n' % who)
+        return failed[1] if failed[1] != 0 else 1
+    out = procs[0].stdout.read()
+    line = None
+    for ln in out.splitlines():
+        if ln.startswith('{'):
+            line = ln
+    if line is None:
+        sys.stderr.write('bench.py: rank 0 printed no JSON line\n')
+        return 1
+    print(line)
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------------------------
+def build_env(args, workload, rank, n, track, extra=None):
+    """-> (env, name, survey_bytes, moved_bytes) per env-step."""
     import yaml
+    import safe_control_gym_amd as scg
+    common = dict(num_envs=n, device='cuda', seed=1337, env_index_base=rank * n, randomized_init=True,
+                  info_level='minimal', track_episode_stats=track, ctrl_freq=60, pyb_freq=240, episode_len_sec=5,
+                  rollout_queues=args.queues)
     for kv in args.env_kw:
         k, v = kv.split('=', 1)
         common[k] = yaml.safe_load(v)
-    w = args.workload
-    if w in ('c4', 'c5'):
+    common.update(extra or {})
+    if workload in ('c4', 'c5'):
         env = scg.make('quadrotor', quad_type=3, task='traj_tracking', cost='quadratic', **common)
         name = 'Quadrotor-3D traj_tracking (circle), quadratic cost Q=R=I, RK4 dt=1/60, auto-reset'
-    elif w == 'c3':
-        cons = [{'constraint_form': 'bounded_constraint', 'constrained_variable': 'state', 'active_dims': [0, 2, 4],
-                 'lower_bounds': [-2, 0, -0.5], 'upper_bounds': [2, 2, 0.5]}]
-        env = scg.make('quadrotor', quad_type=2, task='stabilization', cost='rl_reward', constraints=cons, **common)
+    elif workload == 'c3':
+        env = scg.make('quadrotor', quad_type=2, task='stabilization', cost='rl_reward', constraints=C3_CONSTRAINTS, **common)
         name = 'Quadrotor-2D stabilization, rl_reward, BoundedConstraint(active_dims [0,2,4])'
-    elif w == 'c2':
+    elif workload == 'c2':
         common.update(ctrl_freq=50, pyb_freq=50)
         env = scg.make('cartpole', task='stabilization', cost='quadratic', **common)
         name = 'CartPole stabilization, quadratic cost, RK4 dt=1/50 (no reference env: parity unpinned)'
     else:
-        raise SystemExit('unknown workload %r' % w)
+        raise SystemExit('unknown workload %r' % workload)
     nx, nu = env.state_dim, env.action_dim
-    bytes_per = 8 * nx + 4 * nu + 13
+    survey = 8 * nx + 4 * nu + 13                            # SURVEY.md 8(d): read state, action, t; write state, rew, done, t
+    moved = survey
+    if env.COMPENSATED_STATE:
+        survey += 8 * nx                                     # hi + lo planes (SURVEY.md 8d: "Kahan residual +8 nx")
+        moved += 8 * nx
     if track:
-        bytes_per += 16                                  # ep_return + ep_length read-modify-write (141 B for C5);
-        # the engine moves 8 of them: under auto-reset the episode length IS the step counter, so no ep_length plane exists
+        survey += 16                                         # ep_return + ep_length read-modify-write (141 B for C5)
+        moved += 8                                           # the engine has no ep_length plane under auto-reset
     if env.constraints is not None:
-        bytes_per += 4 * env.constraints.num_device_rows + 1
-    return env, name, bytes_per
+        survey += 4 * env.constraints.num_device_rows + 1
+        moved += 4 * env.constraints.num_device_rows + 1
+    return env, name, survey, moved
 
 
-def cpu_baseline(args, env_kwargs_name):
+def make_actions(env, rank, period, dev):
+    import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(1337 + rank)
+    lo = torch.as_tensor(env.action_space.low, device=dev)[None, :, None]
+    hi = torch.as_tensor(env.action_space.high, device=dev)[None, :, None]
+    return torch.rand((period, env.action_dim, env.plane_stride), generator=g, device=dev, dtype=torch.float32) * (hi - lo) + lo
+
+
+class Timer:
+    """Timed regions of exactly `steps` steps: barrier + synchronize on both sides, HIP events inside."""
+
+    def __init__(self, world, dev):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.world, self.dev = torch, dist, world, dev
+        self.on_host = world > 1 and dist.get_backend() != 'nccl'
+
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, values):
+        t = self.torch.tensor(values, dtype=self.torch.float64, device='cpu' if self.on_host else self.dev)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(v) for v in t]
+
+    def region(self, run, steps, prequeue=True):
+        """-> (device ms, wall ms) of one region, each the max over ranks."""
+        torch = self.torch
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.fence()
+        t0 = time.perf_counter()
+        if prequeue:
+            torch.cuda._sleep(400000)          # ~0.2 ms on the device: the host queues the launches behind it
+        ev0.record()
+        run(steps)
+        ev1.record()
+        self.fence()
+        wall_ms = (time.perf_counter() - t0) * 1e3
+        return self.max_over_ranks([ev0.elapsed_time(ev1), wall_ms])
+
+    def measure(self, run, steps, warmup, repeats):
+        run(warmup)
+        dev = sorted(self.region(run, steps)[0] for _ in range(max(1, repeats)))
+        wall = self.region(run, steps, prequeue=False)[1]
+        med = dev[len(dev) // 2] if len(dev) % 2 else 0.5 * (dev[len(dev) // 2 - 1] + dev[len(dev) // 2])
+        return {'ms': med, 'ms_min': dev[0], 'ms_max': dev[-1], 'wall_ms': wall, 'regions': len(dev)}
+
+
+def sub_record(args, timer, workload, n, steps, track=False, extra=None, note=None):
+    """One secondary measurement on this GPU (its own env, a few hundred ms)."""
+    import torch
+    env, name, survey, moved = build_env(args, workload, 0, n, track, extra)
+    acts = make_actions(env, 0, min(args.action_period, 64), timer.dev)
+    env.reset()
+    m = timer.measure(lambda k: env.rollout(acts, steps=k), steps, min(args.warmup, 20) + 5, 3)
+    us = m['ms'] * 1e3 / steps
+    rec = {'workload': '%s: %s' % (workload.upper(), name), 'envs': n, 'steps': steps, 'value': n / (us * 1e-6), 'unit': 'env-steps/s',
+           'us_per_step': us, 'us_per_step_min_max': [m['ms_min'] * 1e3 / steps, m['ms_max'] * 1e3 / steps],
+           'moved_bytes_per_env_step': moved, 'survey_bytes_per_env_step': survey,
+           'achieved_GBs': moved * n / (us * 1e-6) / 1e9, 'frac': moved * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    if note:
+        rec['note'] = note
+    env.close()
+    del env, acts
+    torch.cuda.empty_cache()
+    return rec
+
+
+def cpu_baseline(args):
     """The C float64 port of the same step (oracle/c), timed on this box's host cores (bounded sample)."""
     import numpy as np
-    from oracle.ref_env import RefEnv
+    from oracle.ref_env import RefEnv, INIT_STATE_LABELS
     from oracle.c_port import CPort
     w = args.workload
     if w in ('c4', 'c5'):
         ref = RefEnv(system=3, task='traj_tracking', cost='quadratic', ctrl_freq=60, pyb_freq=240)
     elif w == 'c3':
-        cons = [{'constraint_form': 'bounded_constraint', 'constrained_variable': 'state', 'active_dims': [0, 2, 4],
-                 'lower_bounds': [-2, 0, -0.5], 'upper_bounds': [2, 2, 0.5]}]
-        ref = RefEnv(system=2, task='stabilization', cost='rl_reward', ctrl_freq=60, pyb_freq=240, constraints=cons)
+        ref = RefEnv(system=2, task='stabilization', cost='rl_reward', ctrl_freq=60, pyb_freq=240, constraints=C3_CONSTRAINTS)
     else:
         ref = RefEnv(system='cartpole', task='stabilization', cost='quadratic', ctrl_freq=50, pyb_freq=50)
     port = CPort.from_ref_env(ref)
     n = 1 << 18
     rng = np.random.default_rng(1337)
-    from oracle.ref_env import INIT_STATE_LABELS
     lo = np.array([ref.INIT_STATE_RAND_INFO[k]['low'] for k in INIT_STATE_LABELS[ref.system]])
     hi = np.array([ref.INIT_STATE_RAND_INFO[k]['high'] for k in INIT_STATE_LABELS[ref.system]])
     x0 = rng.uniform(lo, hi, size=(n, ref.nx))
@@ -100,7 +289,6 @@ def cpu_baseline(args, env_kwargs_name):
         if el > args.cpu_seconds or steps >= 400:
             break
     # one-core Python oracle (the structure-equivalent stand-in for the reference's own step()): tiny sample
-    from oracle.ref_env import RefEnv as _R
     ref.reset_sampler = lambda i, e: np.zeros(ref.nx)
     ref.RANDOMIZED_INIT = False
     ref.reset()
@@ -116,82 +304,97 @@ def cpu_baseline(args, env_kwargs_name):
                       'python oracle 1 core: %.0f env-steps/s' % (n, steps, el, py_rate)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3000)
-    ap.add_argument('--warmup', type=int, default=100)
-    ap.add_argument('--envs-per-gpu', type=int, default=1 << 20)
-    ap.add_argument('--workload', default=None, help='c4 (default; called c5 when sharded over > 1 GPU), c3, c2')
-    ap.add_argument('--episode-stats', action='store_true', help='(default now) track episode returns (B += 16)')
-    ap.add_argument('--no-episode-stats', action='store_true', help='bare step without episode-return tracking (1 GPU only)')
-    ap.add_argument('--action-period', type=int, default=300)
-    ap.add_argument('--python-loop', action='store_true', help='also time env.step() called from Python per step')
-    ap.add_argument('--fused', action='store_true', help='also time the one-launch multi-step rollout (own byte count)')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-bare', action='store_true', help='skip the secondary c4_without_episode_stats measurement')
-    ap.add_argument('--cpu-seconds', type=float, default=12.0)
-    ap.add_argument('--env-kw', action='append', default=[], help='extra make() kwargs key=value (yaml), for experiments')
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------------------------------
+def dry_run_rank(args):
+    """Rendezvous + the collectives of the timed region on host tensors (gloo).  No GPU, no engine: launcher tests."""
+    import torch
+    import torch.distributed as dist
+    from safe_control_gym_amd import parallel
+    rank, world, _ = parallel.init_from_env(backend='gloo')
+    fail_rank = int(os.environ.get('SCG_BENCH_DRYRUN_FAIL_RANK', '-1'))
+    if rank == fail_rank:
+        sys.stderr.write('dry run: rank %d fails on request\n' % rank)
+        os._exit(3)
+    ones = torch.ones(1)
+    n = 8
+    returns = torch.arange(rank * n, (rank + 1) * n, dtype=torch.float32)
+    if world > 1:
+        dist.all_reduce(ones)
+        gathered = parallel.all_gather_episode_returns(returns, total_envs=n * world)
+    else:
+        gathered = returns
+    ok = bool(torch.equal(gathered, torch.arange(n * world, dtype=torch.float32)))
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({'metric': 'env-steps/sec at N parallel envs, 1/2/4/8 GPUs; % HBM-BW roofline', 'value': None,
+                          'dry_run': True, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'backend': dist.get_backend() if world > 1 else 'none', 'ranks_seen': int(ones.item()),
+                          'gather_ok': ok}))
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
+
+def run_rank(args):
     import torch
     import torch.distributed as dist
     from safe_control_gym_amd import parallel
 
     rank, world, local_rank = parallel.init_from_env()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`'
-                             % (args.gpus, args.gpus))
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE is %d (start it as `python bench.py --gpus N`, or under '
+                         '`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)' % (args.gpus, world))
     if args.workload is None:
         args.workload = 'c4' if world == 1 else 'c5'        # same env; 'c5' = sharded + all-gather
     if world > 1 and args.no_episode_stats:
         raise SystemExit('--no-episode-stats is a single-GPU option (the sharded run gathers the episode returns)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    timer = Timer(world, dev)
 
-    env, wname, bytes_per = build_env(args, rank, world)
-    n, nu = env.num_envs, env.action_dim
-    ld = env.plane_stride
-    g = torch.Generator(device=dev)
-    g.manual_seed(1337 + rank)
-    lo = torch.as_tensor(env.action_space.low, device=dev)[None, :, None]
-    hi = torch.as_tensor(env.action_space.high, device=dev)[None, :, None]
-    actions = torch.rand((args.action_period, nu, ld), generator=g, device=dev, dtype=torch.float32) * (hi - lo) + lo
+    n = args.envs_per_gpu
+    track = not args.no_episode_stats
+    env, wname, survey_bytes, moved_bytes = build_env(args, args.workload, rank, n, track)
+    nu = env.action_dim
+    actions = make_actions(env, rank, args.action_period, dev)
     env.reset()
-    gather_every = 300
 
     def run(steps):
         done_steps = 0
         while done_steps < steps:
-            chunk = min(gather_every, steps - done_steps) if world > 1 else steps - done_steps
+            chunk = min(GATHER_EVERY, steps - done_steps) if world > 1 else steps - done_steps
             env.rollout(actions, steps=chunk)
             done_steps += chunk
             if world > 1:
                 parallel.all_gather_episode_returns(env.episode_return, total_envs=n * world)
 
-    run(args.warmup)
-    torch.cuda.synchronize()
+    # every rank proves itself to the collective backend: a sum of ones on the device the rank computes on
+    ranks_seen, backend = 1, 'none'
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    run(args.steps)
-    ev1.record()
-    torch.cuda.synchronize()
+        backend = dist.get_backend()
+        ones = torch.ones(1, device='cpu' if timer.on_host else dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+
+    m = timer.measure(run, args.steps, args.warmup, args.repeats)
+    ms_per_step = m['ms'] / args.steps
+    value = n * world * args.steps / (m['ms'] * 1e-3)
+    local_ms = None
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall_ms = (time.perf_counter() - t0) * 1e3
-    dev_ms = ev0.elapsed_time(ev1)
-    t = torch.tensor([wall_ms, dev_ms], dtype=torch.float64, device=dev if (world == 1 or dist.get_backend() == 'nccl') else 'cpu')
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall_ms, dev_ms = float(t[0]), float(t[1])
-    ms_per_step = wall_ms / args.steps
-    value = n * world * args.steps / (wall_ms * 1e-3)
+        # spread of the per-rank step time: one more region, every rank's OWN event time gathered
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        timer.fence()
+        ev0.record(); run(args.steps); ev1.record()
+        timer.fence()
+        mine = torch.tensor([ev0.elapsed_time(ev1) / args.steps], dtype=torch.float64, device='cpu' if timer.on_host else dev)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        local_ms = [float(v) for v in allv]
 
     py_value = None
     if args.python_loop and world == 1:
@@ -206,86 +409,97 @@ def main():
 
     fused = None
     if args.fused and world == 1:
-        env.rollout(actions, steps=50, fused=True)
-        torch.cuda.synchronize()
-        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        f0.record()
-        env.rollout(actions, steps=args.steps, fused=True)
-        f1.record()
-        torch.cuda.synchronize()
-        fms = f0.elapsed_time(f1)
+        fm = timer.measure(lambda k: env.rollout(actions, steps=k, fused=True), args.steps, 50, 3)
         fbytes = 4 * nu                                  # per env-step: the action plane only (state stays in registers)
-        fused = {'value': n * args.steps / (fms * 1e-3), 'unit': 'env-steps/s', 'us_per_step': fms * 1e3 / args.steps,
-                 'bytes_per_env_step': fbytes, 'achieved_GBs': fbytes * n * args.steps / (fms * 1e-3) / 1e9,
+        fused = {'value': n * args.steps / (fm['ms'] * 1e-3), 'unit': 'env-steps/s', 'us_per_step': fm['ms'] * 1e3 / args.steps,
+                 'bytes_per_env_step': fbytes, 'achieved_GBs': fbytes * n * args.steps / (fm['ms'] * 1e-3) / 1e9,
                  'note': 'scg_rollout_fused: ONE launch for all steps, envs stay in registers; not comparable with the '
                          'per-step roofline above (its algorithmic bytes are 4*nu per env-step); VALU-bound'}
 
-    bare = None
-    if world == 1 and not args.no_episode_stats and not args.no_bare and args.workload == 'c4' and not args.env_kw:
-        # the same step without episode-return tracking (B = 125): the bare C4 roofline number
-        args.no_episode_stats = True
-        env2, _, bytes2 = build_env(args, rank, world)
-        args.no_episode_stats = False
-        env2.reset()
-        env2.rollout(actions, steps=args.warmup)
-        torch.cuda.synchronize()
-        b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        b0.record()
-        env2.rollout(actions, steps=args.steps)
-        b1.record()
-        torch.cuda.synchronize()
-        bus = b0.elapsed_time(b1) * 1e3 / args.steps
-        bare = {'value': n / (bus * 1e-6), 'unit': 'env-steps/s', 'bytes_per_env_step': bytes2, 'kernel_us_per_launch': bus,
-                'achieved_GBs': bytes2 * n / (bus * 1e-6) / 1e9, 'frac': bytes2 * n / (bus * 1e-6) / 1e9 / HBM_PEAK_GBS}
-        env2.close()
-
-    two_queues = (n // 2) // 256 * 256 >= 131072 and os.environ.get('SCG_ROLLOUT_QUEUES', '2') != '1'
+    queues = 1 if args.queues == 1 else 2
+    two_queues = queues == 2 and (n // 2) // 256 * 256 >= (env.ROLLOUT_SPLIT_MIN or 131072) and args.steps >= 2
+    out = None
     if rank == 0:
-        kernel_us = dev_ms * 1e3 / args.steps            # HIP-event time over the timed region / steps (passes over the batch)
-        achieved = bytes_per * n / (kernel_us * 1e-6) / 1e9
-        traffic = None
+        step_us = ms_per_step * 1e3
+        achieved = moved_bytes * n / (step_us * 1e-6) / 1e9
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.workload in ('c4', 'c5') and not args.env_kw:
             with open(tpath) as f:
-                rec = json.load(f).get(args.workload if args.no_episode_stats else 'c5', {}) if args.workload in ('c4', 'c5') else {}
-            if rec.get('envs', 1 << 20) == n and not args.env_kw:       # counters were collected at this size only
+                rec = json.load(f).get('c4' if args.no_episode_stats else 'c5', {})
+            if rec.get('envs', 1 << 20) == n:                           # counters were collected at this size only
                 traffic = rec.get('bytes_per_launch')
+                traffic_source = 'profiles/hbm_traffic.json (%s): PMC FETCH_SIZE x 2 + WRITE_SIZE of an earlier rocprofv3 --pmc ' \
+                                 'run of this command, not collected in this run' % rec.get('collected', 'round 1')
         out = {
             'metric': 'env-steps/sec at N parallel envs, 1/2/4/8 GPUs; % HBM-BW roofline',
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
+            'clock': 'HIP events around exactly %d steps, max over ranks; median of %d regions' % (args.steps, m['regions']),
+            'ms_per_step_min_max': [m['ms_min'] / args.steps, m['ms_max'] / args.steps],
+            'wall_ms_per_step': m['wall_ms'] / args.steps,
+            'backend': backend if world > 1 else 'none (single process)', 'ranks_seen': ranks_seen,
             'config': {'workload': '%s: %s%s' % (args.workload.upper(), wname,
                                                   '' if args.no_episode_stats else ' + per-env episode-return tracking'),
-                       'envs_per_gpu': n,
-                       'total_envs': n * world, 'bytes_per_env_step': bytes_per,
-                       'moved_bytes_per_env_step': bytes_per - (8 if not args.no_episode_stats else 0),
+                       'envs_per_gpu': n, 'total_envs': n * world,
+                       'moved_bytes_per_env_step': moved_bytes, 'survey_bytes_per_env_step': survey_bytes,
                        'launch': ('scg_rollout: per step one fused scg_step kernel per HALF batch, the two halves advancing on two HIP '
                                   'streams so that one kernel\'s ramp-up / drain overlaps the other\'s body; time per step = time per '
                                   'pass over the whole batch') if two_queues else
                                  'one fused scg_step kernel per step (scg_rollout issues the launches)',
                        'launches_per_step': 2 if two_queues else 1,
                        'sharding': 'envs block-sharded by global index; all-gather of episode returns every '
-                                   '%d steps' % gather_every if world > 1 else 'single GPU'},
+                                   '%d steps' % GATHER_EVERY if world > 1 else 'single GPU'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel_us_per_launch': kernel_us, 'algorithmic_bytes_per_launch': bytes_per * n,
-                         'note': 'per step of the whole batch; with launches_per_step = 2 the two half-batch kernels of a step run '
-                                 'concurrently, each for about this long, and bytes are those of both'},
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
+                         'kernel_us_per_launch': step_us, 'bytes_per_launch': moved_bytes * n,
+                         'note': 'bytes MOVED per pass over the batch / the event-clock time per pass (the same clock as value: '
+                                 'value x moved_bytes_per_env_step = achieved); with launches_per_step = 2 a pass is two '
+                                 'concurrent half-batch kernels and kernel_us_per_launch is the period of a pass'},
         }
-        if bare is not None:
-            out['c4_without_episode_stats'] = bare
+        if local_ms is not None:
+            out['per_rank_ms_per_step_min_max'] = [min(local_ms), max(local_ms)]
         if py_value is not None:
             out['python_step_api_value'] = py_value
         if fused is not None:
             out['fused_rollout'] = fused
+    env.close()
+    del env, actions
+    torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and not args.no_sub and not args.env_kw and args.workload == 'c4':
+        sub_steps = max(args.steps, 200)
+        if track:
+            out['c4_without_episode_stats'] = sub_record(args, timer, 'c4', n, sub_steps)
+        out['precise_mode'] = sub_record(
+            args, timer, 'c4', n, sub_steps, extra={'compensated_state': True},
+            note='compensated_state=True: state as hi + lo float32 planes, action clip / motor map / RK4 in float64 -- the '
+                 'mode that meets <= 1e-5 state drift over 1000 open-loop steps (tests/test_parity_gpu.py::test_precise_mode_open_loop_1000_step_drift)')
+        out['c3'] = sub_record(args, timer, 'c3', 1 << 18, max(sub_steps, 1000))
+        out['c2'] = sub_record(args, timer, 'c2', 1 << 16, max(sub_steps, 1000))
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args, wname)
+            out['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if must_spawn(args, os.environ):
+        return spawn_ranks(args, argv)
+    if args.dry_run:
+        return dry_run_rank(args)
+    return run_rank(args)
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

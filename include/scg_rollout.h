@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SCG_ABI_VERSION 3
+#define SCG_ABI_VERSION 4
 #define SCG_MAX_NX 12        /* quadrotor.py:625  (3-D: nx = 12) */
 #define SCG_MAX_NU 4         /* quadrotor.py:625  (3-D: nu = 4)  */
 #define SCG_MAX_NV 16        /* constrained variable: [state ; raw action], constraints.py:58-63 */
@@ -98,7 +98,7 @@ typedef struct scg_config {
     int32_t use_constraint_penalty;  /* benchmark_env.py:454-456 */
     int32_t obs_goal_horizon;        /* benchmark_env.py:406-420 */
     double constraint_penalty;
-    /* reset: quadrotor.py:478-493, benchmark_env.py:277-308 (uniform draws only) */
+    /* reset: quadrotor.py:478-493, benchmark_env.py:277-308 (distribution per dim: init_rand_kind below) */
     int32_t randomized_init;
     int32_t auto_reset;              /* dummy_vec_env.py:41-47 fused into step */
     double init_state[SCG_MAX_NX];
@@ -120,7 +120,37 @@ typedef struct scg_config {
     uint64_t seed;                   /* Philox key */
     int64_t env_index_base;          /* global index of this shard's env 0 (seed + rank analogue,
                                         env_wrappers/vectorized_env/__init__.py:29) */
+    /* Distribution of every randomised quantity: benchmark_env.py:297-307 calls np_random.<distrib>(*args, **kwargs)
+     * for whatever name the yaml gives.  kind = SCG_RAND_UNIFORM keeps the low / high fields above; the other kinds take
+     * their parameters from *_rand_p[dim][0..2] (scg_distribution below).  Value = nominal + draw, as the reference. */
+    int32_t init_rand_kind[SCG_MAX_NX];
+    double init_rand_p[SCG_MAX_NX][3];
+    int32_t inertial_rand_kind[4];
+    double inertial_rand_p[4][3];
+    /* Launch policy of THIS handle (no process-wide switches: two handles in one process may differ).
+     * rollout_queues: 0 = default (2), 1 = everything on the caller's stream, 2 = scg_rollout cuts batches whose half is
+     *   >= rollout_split_min envs in two halves advancing on two HIP streams.
+     * rollout_split_min: 0 = default (131072 envs per half).
+     * ref_in_lds: stage the X_GOAL table in LDS once per workgroup instead of gathering it through L1/L2.
+     * grid_cap_per_cu: 0 = one lane per env (no grid-stride loop); > 0 caps the grid at that many workgroups per CU. */
+    int32_t rollout_queues;
+    int32_t ref_in_lds;
+    int64_t rollout_split_min;
+    int32_t grid_cap_per_cu;
+    int32_t reserved3;
 } scg_config;
+
+/* np.random.RandomState methods the reset path can draw from on the device (benchmark_env.py:297-307); u, u2 are
+ * Philox uniforms in [0, 1).  Anything else (choice, multivariate draws ...) is rejected by the Python layer. */
+typedef enum scg_distribution {
+    SCG_RAND_UNIFORM = 0,        /* uniform(low, high): low + (high - low) u              (fields *_rand_low / high) */
+    SCG_RAND_NORMAL = 1,         /* normal(loc = p0, scale = p1): Box-Muller on (u, u2); standard_normal: p = (0, 1) */
+    SCG_RAND_EXPONENTIAL = 2,    /* exponential(scale = p0): -p0 ln(1 - u) */
+    SCG_RAND_LAPLACE = 3,        /* laplace(loc = p0, scale = p1): inverse CDF */
+    SCG_RAND_LOGISTIC = 4,       /* logistic(loc = p0, scale = p1): p0 + p1 ln(u / (1 - u)) */
+    SCG_RAND_TRIANGULAR = 5,     /* triangular(left = p0, mode = p1, right = p2): inverse CDF */
+    SCG_RAND_RANDINT = 6         /* randint(low = p0, high = p1): floor(p0 + (p1 - p0) u) */
+} scg_distribution;
 
 /* One scalar constraint g(v) <= 0 over v = [state ; RAW action] (constraints.py:160-172).
  * LinearConstraint / BoundedConstraint / DefaultConstraint (constraints.py:226-368) compile to
@@ -248,8 +278,9 @@ int scg_step(scg_handle* h, const scg_step_io* io, int64_t n, void* stream);
  * `io` is reused by all steps, so the outputs hold the LAST step's values and ep_return / ep_length /
  * stats accumulate.  Same kernel and per-step HBM traffic as scg_step().  Batches of >= 2^18 envs are cut in two halves whose
  * step chains are issued on `stream` and on a second, handle-owned stream (forked from and joined back into `stream` by
- * events inside this call), so that one half's kernel ramp-up / drain overlaps the other half's body; per env the results
- * are bit-identical to single-stream stepping.  SCG_ROLLOUT_QUEUES=1 in the environment keeps everything on `stream`. */
+ * events inside this call -- on error paths too), so that one half's kernel ramp-up / drain overlaps the other half's body;
+ * per env the results are bit-identical to single-stream stepping.  scg_config.rollout_queues = 1 keeps everything on
+ * `stream`; scg_config.rollout_split_min moves the threshold. */
 int scg_rollout(scg_handle* h, const scg_step_io* io, int64_t n, int32_t steps, int64_t action_stride,
                 int32_t action_period, void* stream);
 

@@ -7,7 +7,7 @@ module raises.  Struct layouts mirror the header field for field; ``load()`` cro
 import ctypes as C
 import os
 
-SCG_ABI_VERSION = 3
+SCG_ABI_VERSION = 4
 SCG_MAX_NX = 12
 SCG_MAX_NU = 4
 SCG_MAX_NV = 16
@@ -22,6 +22,8 @@ SCG_STABILIZATION, SCG_TRAJ_TRACKING = 0, 1
 SCG_RL_REWARD, SCG_QUADRATIC = 0, 1
 SCG_DIST_ACTION, SCG_DIST_DYNAMICS, SCG_DIST_OBSERVATION = 0, 1, 2
 SCG_DIST_IMPULSE, SCG_DIST_STEP, SCG_DIST_UNIFORM, SCG_DIST_WHITE_NOISE, SCG_DIST_PERIODIC = 0, 1, 2, 3, 4
+(SCG_RAND_UNIFORM, SCG_RAND_NORMAL, SCG_RAND_EXPONENTIAL, SCG_RAND_LAPLACE, SCG_RAND_LOGISTIC, SCG_RAND_TRIANGULAR,
+ SCG_RAND_RANDINT) = range(7)
 
 _dbl = C.c_double
 _i32 = C.c_int32
@@ -62,6 +64,10 @@ class ScgConfig(C.Structure):
         ('gnd_eff_coeff', _dbl), ('prop_radius', _dbl), ('gnd_eff_h_clip', _dbl), ('drag_coeff_xy', _dbl), ('drag_coeff_z', _dbl),
         ('seed', C.c_uint64),
         ('env_index_base', C.c_int64),
+        ('init_rand_kind', _i32 * SCG_MAX_NX), ('init_rand_p', (_dbl * 3) * SCG_MAX_NX),
+        ('inertial_rand_kind', _i32 * 4), ('inertial_rand_p', (_dbl * 3) * 4),
+        ('rollout_queues', _i32), ('ref_in_lds', _i32), ('rollout_split_min', C.c_int64),
+        ('grid_cap_per_cu', _i32), ('reserved3', _i32),
     ]
 
 

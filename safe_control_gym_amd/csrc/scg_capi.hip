@@ -108,6 +108,7 @@ static void derive_params(scg_handle* h) {
     k.obs_goal_horizon = (c.cost == SCG_RL_REWARD) ? c.obs_goal_horizon : 0;
     if (c.task == SCG_STABILIZATION && k.obs_goal_horizon > 1) k.obs_goal_horizon = 1;
     k.n_con_rows = 0;
+    k.grid_cap_per_cu = c.grid_cap_per_cu > 0 ? c.grid_cap_per_cu : 0;
     k.seed_lo = (uint32_t)(c.seed & 0xffffffffull);
     k.seed_hi = (uint32_t)(c.seed >> 32);
     k.env_base = c.env_index_base;
@@ -234,6 +235,17 @@ int scg_create(const scg_config* cfg, scg_handle** out) {
     } else if (!(cfg->pole_length > 0 && cfg->pole_mass > 0 && cfg->cart_mass > 0)) {
         return fail(SCG_ERR_INVALID, "scg_create: non-positive cartpole constant");
     }
+
+    if (cfg->rollout_queues < 0 || cfg->rollout_queues > 2)
+        return fail(SCG_ERR_INVALID, "scg_create: rollout_queues %d out of {0 (default), 1, 2}", cfg->rollout_queues);
+    if (cfg->rollout_split_min < 0 || cfg->grid_cap_per_cu < 0)
+        return fail(SCG_ERR_INVALID, "scg_create: rollout_split_min and grid_cap_per_cu must be >= 0");
+    for (int j = 0; j < SCG_MAX_NX; ++j)
+        if (cfg->init_rand_kind[j] < SCG_RAND_UNIFORM || cfg->init_rand_kind[j] > SCG_RAND_RANDINT)
+            return fail(SCG_ERR_INVALID, "scg_create: init_rand_kind[%d] = %d is not a scg_distribution", j, cfg->init_rand_kind[j]);
+    for (int q = 0; q < 4; ++q)
+        if (cfg->inertial_rand_kind[q] < SCG_RAND_UNIFORM || cfg->inertial_rand_kind[q] > SCG_RAND_RANDINT)
+            return fail(SCG_ERR_INVALID, "scg_create: inertial_rand_kind[%d] = %d is not a scg_distribution", q, cfg->inertial_rand_kind[q]);
 
     if (cfg->randomized_inertial) {
         const double nominal[4] = {cfg->system == SCG_CARTPOLE ? cfg->pole_length : cfg->mass,
@@ -379,10 +391,9 @@ int scg_set_reference(scg_handle* h, const double* x_goal, int32_t rows) {
     h->ref_rows = rows;
     h->kp.ref_rows = rows;
     // Reference-table placement.  Default: gathered from global memory through L1/L2 (measured faster
-    // at the default table size).  SCG_REF_IN_LDS=1 stages it in LDS instead
+    // at the default table size).  scg_config.ref_in_lds stages it in LDS instead
     // (when it leaves room for >= 2 workgroups per CU).
-    const char* lds_env = getenv("SCG_REF_IN_LDS");
-    const bool want_lds = lds_env && lds_env[0] == '1';
+    const bool want_lds = h->cfg.ref_in_lds != 0;
     const int lds_budget = h->max_lds_bytes > 0 ? h->max_lds_bytes / 2 : 32768;
     if (want_lds && (int64_t)bytes <= lds_budget) h->kp.flags |= F_REF_IN_LDS; else h->kp.flags &= ~F_REF_IN_LDS;
     return SCG_OK;
@@ -548,34 +559,54 @@ int scg_rollout(scg_handle* h, const scg_step_io* io, int64_t n, int32_t steps, 
     // independent, so the batch is cut in two halves whose step chains run on two streams: the tail of one half's
     // kernel overlaps the body of the other's (measured 24.9 vs 29.0 us per step of the whole batch; four queues are
     // slower again).  Per env the arithmetic, the Philox counters and therefore the results are unchanged.
-    static const int queues = [] { const char* e = getenv("SCG_ROLLOUT_QUEUES"); const int v = e ? atoi(e) : 2; return v == 1 ? 1 : 2; }();
-    static const int64_t split_min = [] { const char* e = getenv("SCG_ROLLOUT_SPLIT_MIN"); return e ? (int64_t)atoll(e) : (int64_t)131072; }();
+    const int queues = h->cfg.rollout_queues == 1 ? 1 : 2;
+    const int64_t split_min = h->cfg.rollout_split_min > 0 ? h->cfg.rollout_split_min : (int64_t)131072;
     const int64_t half = (n / 2) / 256 * 256;
     if (queues == 2 && steps >= 2 && half >= split_min && half > 0) {
-        scg_step_io first_io = *io;
-        first_io.reset_serial = io->reset_serial;
-        if (int rc = scg_step(h, &first_io, 0, stream)) return rc;          // validates the buffers, launches nothing (n = 0)
+        if (int rc = scg_step(h, io, 0, stream)) return rc;                 // validates the buffers, launches nothing (n = 0)
         if (!h->aux_stream) {
-            HIP_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+            hipStream_t s = nullptr;
+            hipEvent_t ef = nullptr, ej = nullptr;
+            hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ef, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ej, hipEventDisableTiming);
+            if (e != hipSuccess) {
+                if (ej) (void)hipEventDestroy(ej);
+                if (ef) (void)hipEventDestroy(ef);
+                if (s) (void)hipStreamDestroy(s);
+                return fail(SCG_ERR_HIP, "scg_rollout: second launch queue: %s", hipGetErrorString(e));
+            }
+            h->aux_stream = s; h->ev_fork = ef; h->ev_join = ej;
         }
         hipStream_t s0 = (hipStream_t)stream, s1 = h->aux_stream;
-        HIP_TRY(hipEventRecord(h->ev_fork, s0));
+        HIP_TRY(hipEventRecord(h->ev_fork, s0));                            // nothing runs on s1 yet: plain returns are safe
         HIP_TRY(hipStreamWaitEvent(s1, h->ev_fork, 0));
         scg_step_io a = *io, b = shifted_io(*io, half);
         KParams kb = h->kp;
         kb.env_base += half;                                               // Philox streams follow the global env index
-        for (int32_t k = 0; k < steps; ++k) {
+        // From here on s1 may hold work on the caller's buffers: whatever fails, s1 is joined back into s0 before this
+        // call returns, so the caller never sees an un-joined queue running against its tensors.
+        hipError_t err = hipSuccess;
+        const char* what = "";
+        for (int32_t k = 0; k < steps && err == hipSuccess; ++k) {
             const float* act = io->action + (int64_t)(k % action_period) * action_stride;
             a.action = act;
             b.action = act + half;
             a.reset_serial = b.reset_serial = io->reset_serial + (uint32_t)k;
-            HIP_TRY(launch_step(h->system, h->kp, a, h->d_tb, h->d_con, h->d_ref, half, h->num_cus, s0));
-            HIP_TRY(launch_step(h->system, kb, b, h->d_tb, h->d_con, h->d_ref, n - half, h->num_cus, s1));
+            err = launch_step(h->system, h->kp, a, h->d_tb, h->d_con, h->d_ref, half, h->num_cus, s0);
+            what = "launch_step (first half)";
+            if (err != hipSuccess) break;
+            err = launch_step(h->system, kb, b, h->d_tb, h->d_con, h->d_ref, n - half, h->num_cus, s1);
+            what = "launch_step (second half)";
         }
-        HIP_TRY(hipEventRecord(h->ev_join, s1));
-        HIP_TRY(hipStreamWaitEvent(s0, h->ev_join, 0));
+        hipError_t je = hipEventRecord(h->ev_join, s1);
+        if (je == hipSuccess) je = hipStreamWaitEvent(s0, h->ev_join, 0);
+        if (je != hipSuccess) {
+            // the device-side join could not be queued: fall back to a host-side one so that s1 is quiescent on return
+            (void)hipStreamSynchronize(s1);
+            if (err == hipSuccess) { err = je; what = "join of the second launch queue"; }
+        }
+        if (err != hipSuccess) return fail(SCG_ERR_HIP, "scg_rollout: %s failed: %s", what, hipGetErrorString(err));
         return SCG_OK;
     }
     scg_step_io local = *io;

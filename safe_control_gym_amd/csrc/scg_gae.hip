@@ -23,10 +23,12 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 #endif
 constexpr int kGaeDepth = SCG_GAE_DEPTH;
 
-__global__ __launch_bounds__(256) void scg_gae_kernel(const float* __restrict__ rew, const float* __restrict__ val,
+// rew and rew_out carry NO __restrict__: the reference updates the rewards in place (ppo_utils.py:443) and callers pass the
+// same buffer for both; each element is loaded before the same lane stores it.
+__global__ __launch_bounds__(256) void scg_gae_kernel(const float* rew, const float* __restrict__ val,
                                                       const float* __restrict__ mask, const float* __restrict__ term_val,
                                                       const float* __restrict__ last_val, float* __restrict__ ret_out,
-                                                      float* __restrict__ adv_out, float* __restrict__ rew_out,
+                                                      float* __restrict__ adv_out, float* rew_out,
                                                       double* __restrict__ stats, int T, uint32_t n, int64_t ld,
                                                       float gamma, float lam, int use_gae) {
     double s1 = 0.0, s2 = 0.0;

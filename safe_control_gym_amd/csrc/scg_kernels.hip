@@ -35,12 +35,6 @@ namespace scg {
 #ifndef SCG_PREFETCH
 #define SCG_PREFETCH 0         // load the next grid-stride iteration's lane inputs before computing this one
 #endif
-#ifndef SCG_PREFETCH2
-#define SCG_PREFETCH2 1        // packed kernel: software-pipelined input loads (see scg_step2_kernel)
-#endif
-#ifndef SCG_PACKED_BLOCKS_PER_CU
-#define SCG_PACKED_BLOCKS_PER_CU 2   // packed kernel grid cap: resident workgroups per CU (2 waves per SIMD)
-#endif
 constexpr int kBlock = SCG_BLOCK;
 #if SCG_MIN_WAVES > 0
 #define SCG_BOUNDS __launch_bounds__(kBlock, SCG_MIN_WAVES)
@@ -1109,441 +1103,6 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
 }
 
 // ------------------------------------------------------------------------------------------
-// packed variant: TWO envs per lane, arithmetic on v_pk_{fma,mul,add}_f32
-// ------------------------------------------------------------------------------------------
-// On gfx950 a wave64 VALU instruction holds its SIMD for 4 cycles whether it produces one fp32 result per
-// lane or two (tools/ubench/pk_fma.hip: v_fma_f32 68.6 TFLOP/s, v_pk_fma_f32 124 TFLOP/s), and the
-// one-env-per-lane kernel above is VALU-issue bound.  Here each lane owns the two
-// consecutive envs (2L, 2L+1): every plane access is a 8-byte load/store (512-B wave transaction), every
-// add / mul / fma of the dynamics, RK4, sincos polynomials and cost is packed, and only the inherently
-// per-value work (rounding to the quadrant, reciprocals, square roots, compares, the reset) is done per
-// component.  Results are bit-identical to the one-env kernel except where noted (sincos quadrant fix-up
-// is the same integer logic; fma contraction is identical).  Lean feature tiers only (no FT_EXTRA, no
-// compensated planes): the launcher falls back to the kernel above otherwise.
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef int i2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f2 fma2(f2 a, float b, f2 c) { return __builtin_elementwise_fma(a, (f2){b, b}, c); }
-__device__ __forceinline__ f2 fma2(float a, f2 b, f2 c) { return __builtin_elementwise_fma((f2){a, a}, b, c); }
-__device__ __forceinline__ f2 fma2(f2 a, f2 b, float c) { return __builtin_elementwise_fma(a, b, (f2){c, c}); }
-__device__ __forceinline__ f2 fma2(f2 a, float b, float c) { return __builtin_elementwise_fma(a, (f2){b, b}, (f2){c, c}); }
-__device__ __forceinline__ f2 fma2(float a, f2 b, float c) { return __builtin_elementwise_fma((f2){a, a}, b, (f2){c, c}); }
-__device__ __forceinline__ f2 rcp2(f2 x) { return (f2){rcp_f(x.x), rcp_f(x.y)}; }
-
-__device__ __forceinline__ void sincos2(f2 x, f2& s, f2& c) {
-#if SCG_FAST_TRIG
-    const f2 rev = x * 0.15915494309189535f;
-    s = (f2){__builtin_amdgcn_sinf(rev.x), __builtin_amdgcn_sinf(rev.y)};
-    c = (f2){__builtin_amdgcn_cosf(rev.x), __builtin_amdgcn_cosf(rev.y)};
-#else
-    const f2 q = x * 0.636619772367581343f;
-    const f2 kf = (f2){rintf(q.x), rintf(q.y)};
-    f2 r = fma2(kf, -1.5707963705062866f, x);
-    r = fma2(kf, 4.371138828673793e-08f, r);
-    const f2 r2 = r * r;
-    f2 ps = fma2(r2, 2.716089966270374e-06f, -0.0001983909896807745f);
-    ps = fma2(ps, r2, 0.008333329111337662f);
-    ps = fma2(ps, r2, -0.1666666716337204f);
-    const f2 sr = fma2(r * r2, ps, r);
-    f2 pc = fma2(r2, 2.4417491658823565e-05f, -0.0013887188397347927f);
-    pc = fma2(pc, r2, 0.04166664183139801f);
-    const f2 cr = fma2(r2 * r2, pc, fma2(r2, -0.5f, 1.0f));
-    // Quadrant fix-up WITHOUT per-lane integer logic (and / cmp / cndmask cannot be packed): with
-    // m = k - 4 rint(k/4) in {-2,..,2},  (a, b) = (cos, sin)(m pi/2) are the integer-valued polynomials
-    //   a = 1 - m^2 (7 - m^2) / 6,   b = m (4 - m^2) / 3     (exact at m = 0, +-2; |a(+-1)| <= 3e-8)
-    // and  sin x = sr a + cr b,  cos x = cr a - sr b.
-    const f2 kq = kf * 0.25f;
-    const f2 m = fma2((f2){rintf(kq.x), rintf(kq.y)}, -4.0f, kf);
-    const f2 m2 = m * m;
-    const f2 a = fma2(m2 * (m2 - 7.0f), 0.16666667163372040f, 1.0f);
-    const f2 b = m * ((4.0f - m2) * 0.33333334326744080f);
-    s = fma2(sr, a, cr * b);
-    c = fma2(cr, a, -(sr * b));
-#endif
-}
-
-template <int SYS> struct Inputs2;
-template <> struct Inputs2<SCG_QUAD_1D> { f2 acc; };
-template <> struct Inputs2<SCG_QUAD_2D> { f2 Tm, thdd; float az; };
-template <> struct Inputs2<SCG_QUAD_3D> { f2 Tm, mx, my, mz; float az; };
-template <> struct Inputs2<SCG_CARTPOLE> { f2 F; };
-
-template <int SYS>
-__device__ __forceinline__ void make_inputs2(const KParams& p, const f2* u, Inputs2<SYS>& in);
-template <>
-__device__ __forceinline__ void make_inputs2<SCG_QUAD_1D>(const KParams& p, const f2* u, Inputs2<SCG_QUAD_1D>& in) {
-    in.acc = fma2(u[0], p.ph.inv_m, -p.ph.g);
-}
-template <>
-__device__ __forceinline__ void make_inputs2<SCG_QUAD_2D>(const KParams& p, const f2* u, Inputs2<SCG_QUAD_2D>& in) {
-    in.Tm = (u[0] + u[1]) * p.ph.inv_m;
-    in.az = -p.ph.g;
-    in.thdd = (u[1] - u[0]) * p.ph.l_s2_iyy;
-}
-template <>
-__device__ __forceinline__ void make_inputs2<SCG_QUAD_3D>(const KParams& p, const f2* u, Inputs2<SCG_QUAD_3D>& in) {
-    in.Tm = ((u[0] + u[1]) + (u[2] + u[3])) * p.ph.inv_m;
-    in.az = -p.ph.g;
-    in.mx = (((u[0] + u[1]) - (u[2] + u[3])) * p.ph.arm_s2) * p.ph.inv_ixx;
-    in.my = (((u[1] + u[2]) - (u[0] + u[3])) * p.ph.arm_s2) * p.ph.inv_iyy;
-    in.mz = (((u[0] + u[2]) - (u[1] + u[3])) * p.ph.gamma) * p.ph.inv_izz;
-}
-template <>
-__device__ __forceinline__ void make_inputs2<SCG_CARTPOLE>(const KParams& p, const f2* u, Inputs2<SCG_CARTPOLE>& in) {
-    in.F = u[0];
-}
-
-template <int SYS>
-__device__ __forceinline__ void f_eval2(const KParams& p, const Inputs2<SYS>& in, const f2 (&x)[Dim<SYS>::NX],
-                                        f2 (&d)[Dim<SYS>::NX]);
-template <>
-__device__ __forceinline__ void f_eval2<SCG_QUAD_1D>(const KParams& p, const Inputs2<SCG_QUAD_1D>& in,
-                                                     const f2 (&x)[2], f2 (&d)[2]) {
-    d[0] = x[1];
-    d[1] = in.acc;
-}
-template <>
-__device__ __forceinline__ void f_eval2<SCG_QUAD_2D>(const KParams& p, const Inputs2<SCG_QUAD_2D>& in,
-                                                     const f2 (&x)[6], f2 (&d)[6]) {
-    f2 s, c;
-    sincos2(x[4], s, c);
-    d[0] = x[1];
-    d[1] = s * in.Tm;
-    d[2] = x[3];
-    d[3] = fma2(c, in.Tm, in.az);
-    d[4] = x[5];
-    d[5] = in.thdd;
-}
-template <>
-__device__ __forceinline__ void f_eval2<SCG_QUAD_3D>(const KParams& p, const Inputs2<SCG_QUAD_3D>& in,
-                                                     const f2 (&x)[12], f2 (&d)[12]) {
-    f2 sph, cph, sth, cth, sps, cps;
-    sincos2(x[6], sph, cph);
-    sincos2(x[7], sth, cth);
-    sincos2(x[8], sps, cps);
-    const f2 P = x[9], Q = x[10], R = x[11];
-    const f2 sthcph = sth * cph;
-    d[0] = x[1];
-    d[1] = fma2(cps, sthcph, sps * sph) * in.Tm;
-    d[2] = x[3];
-    d[3] = fma2(sps, sthcph, -(cps * sph)) * in.Tm;
-    d[4] = x[5];
-    d[5] = fma2(cth * cph, in.Tm, in.az);
-    const f2 rcth = rcp2(cth);
-    const f2 w = fma2(sph, Q, cph * R);
-    d[6] = fma2(sth * rcth, w, P);
-    d[7] = fma2(cph, Q, -(sph * R));
-    d[8] = w * rcth;
-    d[9] = fma2(Q * R, -p.ph.cxx, in.mx);
-    d[10] = fma2(R * P, -p.ph.cyy, in.my);
-    d[11] = fma2(P * Q, -p.ph.czz, in.mz);
-}
-template <>
-__device__ __forceinline__ void f_eval2<SCG_CARTPOLE>(const KParams& p, const Inputs2<SCG_CARTPOLE>& in,
-                                                      const f2 (&x)[4], f2 (&d)[4]) {
-    f2 s, c;
-    sincos2(x[2], s, c);
-    const f2 thd = x[3];
-    const f2 tmp = fma2((thd * thd) * p.ph.cp_ml, s, in.F) * p.ph.cp_inv_Mm;
-    const f2 den = fma2(c * c, -p.ph.cp_m * p.ph.cp_inv_Mm, 4.0f / 3.0f) * p.ph.cp_l;
-    const f2 thdd = fma2(s, p.ph.cp_g, -(c * tmp)) * rcp2(den);
-    d[0] = x[1];
-    d[1] = fma2(thdd * c, -p.ph.cp_ml * p.ph.cp_inv_Mm, tmp);
-    d[2] = thd;
-    d[3] = thdd;
-}
-
-template <int SYS>
-__device__ __forceinline__ void integrate2(const KParams& p, const Inputs2<SYS>& in, f2 (&x)[Dim<SYS>::NX]) {
-    constexpr int NX = Dim<SYS>::NX;
-    const float h = p.ph.h;
-    f2 k[NX];
-    f_eval2<SYS>(p, in, x, k);
-    if (p.flags & F_EULER) {
-#pragma unroll
-        for (int j = 0; j < NX; ++j) x[j] = fma2(k[j], h, x[j]);
-        return;
-    }
-    f2 xt[NX], acc[NX];
-    const float hh = 0.5f * h;
-#pragma unroll
-    for (int j = 0; j < NX; ++j) { acc[j] = k[j]; xt[j] = fma2(k[j], hh, x[j]); }
-    f_eval2<SYS>(p, in, xt, k);
-#pragma unroll
-    for (int j = 0; j < NX; ++j) { acc[j] = fma2(k[j], 2.0f, acc[j]); xt[j] = fma2(k[j], hh, x[j]); }
-    f_eval2<SYS>(p, in, xt, k);
-#pragma unroll
-    for (int j = 0; j < NX; ++j) { acc[j] = fma2(k[j], 2.0f, acc[j]); xt[j] = fma2(k[j], h, x[j]); }
-    f_eval2<SYS>(p, in, xt, k);
-    const float h6 = h * (1.0f / 6.0f);
-#pragma unroll
-    for (int j = 0; j < NX; ++j) x[j] = x[j] + (acc[j] + k[j]) * h6;
-}
-
-template <class T2, class T>
-__device__ __forceinline__ T2 ldp2(const T* base, uint32_t boff) {
-    return ldp(reinterpret_cast<const T2*>(base), boff);
-}
-
-// Two-component form of reset_state_coop: the jobs of BOTH envs of every lane go through one pass
-// (up to 64 / ceil(NX/4) resetting envs per Philox evaluation).  need0 / need1: does env i / i+1 reset.
-template <int NX>
-__device__ __forceinline__ void reset_state_coop2(const KParams& p, const KTables* __restrict__ tb,
-                                                  const float* __restrict__ reset_state, int64_t ld, uint32_t i,
-                                                  uint32_t serial, bool need0, bool need1, float* scratch,
-                                                  f2 (&x)[NX]) {
-    constexpr int NB = (NX + 3) / 4, W = 4 * NB, JOBS = 64 / NB;
-    const unsigned long long exec = __ballot(1);
-    if (!(p.flags & F_RAND_INIT) || exec != ~0ull) {
-        float xr[NX];
-        if (need0) {
-            reset_state_of<NX>(p, tb, reset_state, ld, i, serial, xr);
-#pragma unroll
-            for (int j = 0; j < NX; ++j) x[j].x = xr[j];
-        }
-        if (need1) {
-            reset_state_of<NX>(p, tb, reset_state, ld, i + 1u, serial, xr);
-#pragma unroll
-            for (int j = 0; j < NX; ++j) x[j].y = xr[j];
-        }
-        return;
-    }
-    // nominal part
-    if (reset_state) {
-        if (need0 | need1) {
-#pragma unroll
-            for (int j = 0; j < NX; ++j) {
-                const f2 v = ldp2<f2>(uptr(reset_state + j * opaque_s(ld)), i * 4u);
-                if (need0) x[j].x = v.x;
-                if (need1) x[j].y = v.y;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NX; ++j) {
-            const float v = tb->init_state[j];
-            if (need0) x[j].x = v;
-            if (need1) x[j].y = v;
-        }
-    }
-    const unsigned long long m0 = __ballot(need0), m1 = __ballot(need1);
-    const int n0 = __popcll(m0), total = n0 + __popcll(m1);
-    const int lane = (int)__lane_id();
-    const int rank0 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
-    const int rank1 = n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
-    uint32_t* s_idx = reinterpret_cast<uint32_t*>(scratch);          // [128] env indices of the resetting envs
-    float* s_u = scratch + 128;                                       // [JOBS][W] uniforms of the current pass
-    if (need0) s_idx[rank0] = i;
-    if (need1) s_idx[rank1] = i + 1u;
-    const int k = lane / NB, blk = lane - k * NB;
-    for (int base = 0; base < total; base += JOBS) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        const int slot = base + k;
-        if (lane < JOBS * NB && slot < total) {
-            const uint64_t g = (uint64_t)(p.env_base + (int64_t)s_idx[slot]);
-            uint32_t w[4];
-            philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), serial, (uint32_t)blk, p.seed_lo, p.seed_hi, w);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) s_u[k * W + 4 * blk + q] = (float)(w[q] >> 8) * 5.9604644775390625e-8f;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        if (need0 && rank0 >= base && rank0 < base + JOBS) {
-            const float* mine = s_u + (rank0 - base) * W;
-#pragma unroll
-            for (int d = 0; d < NX; ++d) x[d].x += fmaf(tb->init_span[d], mine[d], tb->init_lo[d]);
-        }
-        if (need1 && rank1 >= base && rank1 < base + JOBS) {
-            const float* mine = s_u + (rank1 - base) * W;
-#pragma unroll
-            for (int d = 0; d < NX; ++d) x[d].y += fmaf(tb->init_span[d], mine[d], tb->init_lo[d]);
-        }
-    }
-}
-constexpr int kCoop2Floats = 128 + 64 * 4;
-
-template <int SYS, uint32_t FT>
-__global__ __launch_bounds__(kBlock) void scg_step2_kernel(const KParams p, const scg_step_io io,
-                                                           const KTables* __restrict__ tb,
-                                                           const ConTable* __restrict__ ct,
-                                                           const float* __restrict__ ref, const uint32_t n) {
-    constexpr int NX = Dim<SYS>::NX, NU = Dim<SYS>::NU, NV = NX + NU;
-    constexpr bool tracking = (FT & FT_TRACK) != 0;
-    constexpr bool has_con = (FT & FT_CON) != 0;
-    extern __shared__ __align__(16) float s_ref[];
-    float* coop_scratch = s_ref + (threadIdx.x >> 6) * kCoop2Floats;      // the packed kernel never stages X_GOAL
-    const int64_t ld = io.ld;
-    const uint32_t npairs = (n + 1u) >> 1;
-
-    // Software pipeline: a wave owns several pairs (grid-stride) and requests the NEXT pair's inputs before it
-    // starts the ~1400 VALU instructions of the current one, so that after the first iteration no HBM latency
-    // is exposed.  Without it the resident waves of a SIMD run in lock step (all load, then all compute) and
-    // every round of waves pays the full load latency (measured: 35 us vs 31 us for the unpacked kernel).
-    struct In2 {
-        f2 x[NX], u[NU], epr;
-        i2 t, epl;
-    };
-    auto load_in = [&](In2& L, uint32_t pair) {
-        const uint32_t b4 = pair * 8u;
-#pragma unroll
-        for (int j = 0; j < NX; ++j) L.x[j] = ldp2<f2>(PL(io.state, j), b4);
-#pragma unroll
-        for (int j = 0; j < NU; ++j) L.u[j] = ldp2<f2>(PL(io.action, j), b4);
-        L.t = ldp2<i2>(io.step_count, b4);
-        L.epr = (f2){0.f, 0.f};
-        L.epl = (i2){0, 0};
-        if (io.ep_return) L.epr = ldp2<f2>(io.ep_return, b4);
-        L.epl = io.ep_length ? ldp2<i2>(io.ep_length, b4) : L.t;
-    };
-    const uint32_t stride = gridDim.x * kBlock;
-    uint32_t pr = blockIdx.x * kBlock + threadIdx.x;
-    In2 cur;
-    if (pr < npairs) load_in(cur, pr);
-    for (; pr < npairs; pr += stride) {
-        const uint32_t i = pr * 2u;                  // first env of this lane; the second is i + 1
-        const uint32_t i4 = i * 4u;                  // byte offset of the pair in every fp32 / int32 plane
-        const bool valid1 = (i + 1u) < n;            // false only for the last lane of an odd batch
-        In2 nxt;
-        const uint32_t prn = pr + stride;
-        if (SCG_PREFETCH2 && prn < npairs) load_in(nxt, prn);
-        f2 x[NX], u[NU];
-#pragma unroll
-        for (int j = 0; j < NX; ++j) x[j] = cur.x[j];
-#pragma unroll
-        for (int j = 0; j < NU; ++j) u[j] = cur.u[j];
-        const i2 t = cur.t;
-        f2 epr = cur.epr;
-        i2 epl = cur.epl;
-
-        // ---- _preprocess_control (quadrotor.py:815-842) + motor map (quadrotor_utils.py:38-50,66); the
-        //      action term of the cost is formed here so the clipped action need not stay in registers
-        f2 l_act = (f2){0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < NU; ++j) {
-            const float lo = tb->act_low[j], hi = tb->act_high[j];
-            const f2 a = (f2){clampf(u[j].x, lo, hi), clampf(u[j].y, lo, hi)};
-            const f2 ea = a - tb->u_goal[j];
-            l_act = fma2(ea * tb->w_act[j], ea, l_act);
-            f2 th = a;
-            if (SYS != SCG_CARTPOLE && (p.flags & F_MOTOR_MAP)) {
-                const f2 arg = (f2){fmaxf(th.x, 0.0f), fmaxf(th.y, 0.0f)} * p.ph.inv_nmotor_kf;
-                f2 pwm = ((f2){sqrt_f(arg.x), sqrt_f(arg.y)} - p.ph.pwm_const) * p.ph.inv_pwm_scale;
-                pwm = (f2){clampf(pwm.x, p.ph.pwm_min, p.ph.pwm_max), clampf(pwm.y, p.ph.pwm_min, p.ph.pwm_max)};
-                const f2 rpm = fma2(pwm, p.ph.pwm_scale, p.ph.pwm_const);
-                th = (rpm * p.ph.nmotor_kf) * rpm;
-            }
-            u[j] = th;
-        }
-
-        // ---- fixed-step integration of the prior model (controllers/mpc/mpc_utils.py:79-101)
-        {
-            Inputs2<SYS> in;
-            make_inputs2<SYS>(p, u, in);
-            for (int s = 0; s < p.substeps; ++s) integrate2<SYS>(p, in, x);
-        }
-
-        // ---- state term of the cost on the error to this step's goal; done flags (quadrotor.py:886-993)
-        f2 l = l_act, d2 = (f2){0.f, 0.f};
-        if (tracking) {
-            float g0[NX], g1[NX];
-            load_goal<NX>(p, ref, t.x, g0);
-            load_goal<NX>(p, ref, t.y, g1);
-#pragma unroll
-            for (int j = 0; j < NX; ++j) {
-                const f2 e = x[j] - (f2){g0[j], g1[j]};
-                l = fma2(e * tb->w_state[j], e, l);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NX; ++j) {
-                const f2 e = x[j] - tb->x_goal[j];
-                l = fma2(e * tb->w_state[j], e, l);
-                d2 = fma2(e, e, d2);
-            }
-        }
-        bool done0 = false, done1 = false;
-        if (!tracking && (p.flags & F_QUADRATIC)) {
-            done0 = d2.x < p.goal_tol2;
-            done1 = d2.y < p.goal_tol2;
-        }
-        if (p.flags & F_DONE_OOB) {
-            bool in0 = true, in1 = true;
-#pragma unroll
-            for (int j = 0; j < NX; ++j) {
-                const float lo = tb->oob_low[j], hi = tb->oob_high[j];
-                in0 &= (x[j].x >= lo) & (x[j].x <= hi);
-                in1 &= (x[j].y >= lo) & (x[j].y <= hi);
-            }
-            done0 |= !in0;
-            done1 |= !in1;
-        }
-        f2 rew = l * p.cost_scale;
-        if (!(p.flags & F_QUADRATIC) && (p.flags & F_REW_EXP)) rew = (f2){expf(rew.x), expf(rew.y)};
-
-        // ---- after_step (benchmark_env.py:422-463)
-        if (has_con) {
-            float v0[NV], v1[NV];
-#pragma unroll
-            for (int j = 0; j < NX; ++j) { v0[j] = x[j].x; v1[j] = x[j].y; }
-#pragma unroll
-            for (int j = 0; j < NU; ++j) {                                   // RAW action again (an L2 hit)
-                const f2 a = ldp2<f2>(PL(io.action, j), i4);
-                v0[NX + j] = a.x; v1[NX + j] = a.y;
-            }
-            const ConFlags c0 = eval_constraints<NV, false>(ct, v0, io.constraint_values, ld, i);
-            ConFlags c1{false, false};
-            if (valid1) c1 = eval_constraints<NV, false>(ct, v1, io.constraint_values, ld, i + 1u);
-            if (p.flags & F_DONE_VIOL) { done0 |= c0.violated; done1 |= c1.violated; }
-            if (!(p.flags & F_QUADRATIC) && (p.flags & F_PENALTY)) {
-                if (c0.almost) rew.x += p.constraint_penalty;
-                if (c1.almost) rew.y += p.constraint_penalty;
-            }
-            if (io.constraint_violation) {
-                stp(io.constraint_violation, i, (uint8_t)(c0.violated ? 1 : 0));
-                if (valid1) stp(io.constraint_violation, i + 1u, (uint8_t)(c1.violated ? 1 : 0));
-            }
-        }
-        i2 t_out = t + 1;
-        done0 |= t_out.x >= p.ctrl_steps;
-        done1 |= t_out.y >= p.ctrl_steps;
-        epr = epr + rew;
-        epl = epl + 1;
-
-        // ---- auto-reset (dummy_vec_env.py:41-47): one wave-cooperative Philox pass for both components
-        const bool need0 = done0 && (p.flags & F_AUTO_RESET);
-        const bool need1 = done1 && valid1 && (p.flags & F_AUTO_RESET);
-        if (__ballot(need0 | need1)) {
-            reset_state_coop2<NX>(p, tb, io.reset_state, ld, i, io.reset_serial, need0, need1, coop_scratch, x);
-            if (need0) { t_out.x = 0; epr.x = 0.f; epl.x = 0; }
-            if (need1) { t_out.y = 0; epr.y = 0.f; epl.y = 0; }
-        }
-
-        // ---- stores (8 bytes per lane per plane; the odd tail lane stores its one valid env)
-        if (valid1) {
-#pragma unroll
-            for (int j = 0; j < NX; ++j) stp(reinterpret_cast<f2*>(PLS(io.state, j)), i4, x[j]);
-            stp(reinterpret_cast<i2*>(io.step_count), i4, t_out);
-            stp(reinterpret_cast<f2*>(io.reward), i4, rew);
-            stp(reinterpret_cast<uint16_t*>(io.done), i, (uint16_t)((done0 ? 1u : 0u) | (done1 ? 0x100u : 0u)));
-            if (io.ep_return) stp(reinterpret_cast<f2*>(io.ep_return), i4, epr);
-            if (io.ep_length) stp(reinterpret_cast<i2*>(io.ep_length), i4, epl);
-        } else {
-#pragma unroll
-            for (int j = 0; j < NX; ++j) stp(PLS(io.state, j), i4, x[j].x);
-            stp(io.step_count, i4, t_out.x);
-            stp(io.reward, i4, rew.x);
-            stp(io.done, i, (uint8_t)(done0 ? 1 : 0));
-            if (io.ep_return) stp(io.ep_return, i4, epr.x);
-            if (io.ep_length) stp(io.ep_length, i4, epl.x);
-        }
-        if (SCG_PREFETCH2) cur = nxt;
-        else if (prn < npairs) load_in(cur, prn);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // reset kernel  (quadrotor.py:356-504 minus PyBullet; record_episode_statistics.py:132-140)
 // ------------------------------------------------------------------------------------------
 template <int SYS>
@@ -1692,10 +1251,9 @@ LaunchGeom step_geometry(const KParams& p, int system, int64_t n, int num_cus) {
     int64_t blocks = (n + kBlock - 1) / kBlock;
     g.lds_bytes = 0;
     if ((p.flags & F_AUTO_RESET) && (p.flags & F_RAND_INIT))
-        g.lds_bytes += (kBlock / 64) * (kCoop2Floats > kCoopFloats ? kCoop2Floats : kCoopFloats) * (int)sizeof(float);   // cooperative-reset scratch
-    // SCG_GRID_CAP_PER_CU (tuning knob): cap the grid at that many workgroups per CU and grid-stride the rest.
-    static const int cap_env = [] { const char* e = getenv("SCG_GRID_CAP_PER_CU"); return e ? atoi(e) : 0; }();
-    int cap_per_cu = cap_env;
+        g.lds_bytes += (kBlock / 64) * kCoopFloats * (int)sizeof(float);   // cooperative-reset scratch
+    // scg_config.grid_cap_per_cu (tuning knob): cap the grid at that many workgroups per CU and grid-stride the rest.
+    int cap_per_cu = p.grid_cap_per_cu;
     if ((p.flags & F_TRACKING) && (p.flags & F_REF_IN_LDS)) {
         int table = p.ref_rows * nx_of(system) * (int)sizeof(float);
         g.lds_bytes += (table + 15) & ~15;
@@ -1747,49 +1305,10 @@ static void launch_step_ft(uint32_t ft, const LaunchGeom& g, const KParams& p, c
 #undef SCG_LAUNCH
 }
 
-// The packed two-envs-per-lane kernel needs 8-byte aligned pairs in every plane it touches.
-static bool packed_ok(const KParams& p, const scg_step_io& io, uint32_t ft) {
-    // Opt-in (SCG_PACKED=1): on MI355X the packed kernel issues 29 % fewer VALU instructions per env but its
-    // 155 VGPRs (3 waves/SIMD) and 8-byte streams lose more to exposed latency than that saves
-    // (31.4 us vs 29.9 us at 2^20 envs).
-    static const bool disabled = [] { const char* e = getenv("SCG_PACKED"); return !(e && e[0] == '1'); }();
-    if (disabled || io.action_rows || (ft & (FT_EXTRA | FT_INFO)) || io.state_lo || (p.flags & F_REF_IN_LDS) || (io.ld & 1)) return false;
-    auto al = [](const void* q, uintptr_t a) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) % a) == 0; };
-    return al(io.state, 8) && al(io.action, 8) && al(io.step_count, 8) && al(io.reward, 8) && al(io.done, 2) &&
-           al(io.ep_return, 8) && al(io.ep_length, 8) && al(io.reset_state, 4);
-}
-
-template <int SYS>
-static void launch_step2_ft(uint32_t ft, const LaunchGeom& g, const KParams& p, const scg_step_io& io,
-                            const KTables* tb, const ConTable* ct, const float* ref, uint32_t n, hipStream_t s) {
-#define SCG_LAUNCH2(FTV)                                                                                  \
-    hipLaunchKernelGGL((scg_step2_kernel<SYS, (FTV)>), dim3(g.grid), dim3(g.block), g.lds_bytes, s, p, io, tb, ct, ref, n)
-    switch (ft) {
-        case 0: SCG_LAUNCH2(0u); break;
-        case FT_TRACK: SCG_LAUNCH2(FT_TRACK); break;
-        case FT_CON: SCG_LAUNCH2(FT_CON); break;
-        default: SCG_LAUNCH2(FT_TRACK | FT_CON); break;
-    }
-#undef SCG_LAUNCH2
-}
-
 template <int SYS>
 static void launch_step_sys(LaunchGeom g, const KParams& p, const scg_step_io& io, const KTables* tb,
                             const ConTable* ct, const float* ref, uint32_t n, int num_cus, hipStream_t s) {
     const uint32_t ft = features_needed(p, io);
-    if (packed_ok(p, io, ft)) {
-        const int64_t pairs = ((int64_t)n + 1) / 2;
-        int64_t blocks = (pairs + kBlock - 1) / kBlock;
-        static const int per_cu = [] {
-            const char* e = getenv("SCG_PACKED_BLOCKS_PER_CU");   // tuning knob
-            const int v = e ? atoi(e) : 0;
-            return v > 0 ? v : SCG_PACKED_BLOCKS_PER_CU;
-        }();
-        if (SCG_PREFETCH2 && blocks > (int64_t)num_cus * per_cu) blocks = (int64_t)num_cus * per_cu;
-        g.grid = (int)blocks;
-        launch_step2_ft<SYS>(ft, g, p, io, tb, ct, ref, n, s);
-        return;
-    }
     if (io.state_lo) launch_step_ft<SYS, true>(ft, g, p, io, tb, ct, ref, n, s);
     else launch_step_ft<SYS, false>(ft, g, p, io, tb, ct, ref, n, s);
 }

@@ -379,7 +379,7 @@ hipError_t launch_linearize(int system, const PhysT<float>& ph, const float* sta
                             const float* inertial, float* dfdx, float* dfdu, float disc_dt, int64_t ld, int64_t n,
                             hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    static const bool direct = getenv("SCG_LIN_DIRECT") && atoi(getenv("SCG_LIN_DIRECT")) != 0;   // tuning: no LDS staging
+    const bool direct = false;     // true = every lane streams its own record without LDS staging (16x slower)
     switch (system) {
         case SCG_QUAD_1D: return launch_lin_sys<SCG_QUAD_1D>(ph, state, input, inertial, dfdx, dfdu, disc_dt, ld, (uint32_t)n, direct, s);
         case SCG_QUAD_2D: return launch_lin_sys<SCG_QUAD_2D>(ph, state, input, inertial, dfdx, dfdu, disc_dt, ld, (uint32_t)n, direct, s);

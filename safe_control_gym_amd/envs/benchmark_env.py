@@ -112,7 +112,8 @@ class BenchmarkEnv:
                  # ---- batched-engine arguments (new) ----
                  num_envs=1, device='cuda', physics='rk4', integration_substeps=1, motor_map=True,
                  auto_reset=True, info_level='full', compensated_state=False, track_episode_stats=True,
-                 env_index_base=0,
+                 env_index_base=0, rollout_queues=None, rollout_split_min=None, ref_in_lds=None, grid_cap_per_cu=None,
+                 plane_pad=None,
                  **kwargs):
         self.id = self.__class__._count
         self.__class__._count += 1
@@ -154,6 +155,15 @@ class BenchmarkEnv:
         self.COMPENSATED_STATE = bool(compensated_state)
         self.TRACK_EPISODE_STATS = bool(track_episode_stats)
         self.ENV_INDEX_BASE = int(env_index_base)
+        # launch policy of this env's handle (scg_config fields; the SCG_* environment variables are only the defaults
+        # of these keyword arguments, read here -- the library itself reads no environment variable)
+        def _knob(value, env_name, default):
+            return int(os.environ.get(env_name, default)) if value is None else int(value)
+        self.ROLLOUT_QUEUES = _knob(rollout_queues, 'SCG_ROLLOUT_QUEUES', 0)        # 0 = library default (2)
+        self.ROLLOUT_SPLIT_MIN = _knob(rollout_split_min, 'SCG_ROLLOUT_SPLIT_MIN', 0)
+        self.REF_IN_LDS = _knob(ref_in_lds, 'SCG_REF_IN_LDS', 0)
+        self.GRID_CAP_PER_CU = _knob(grid_cap_per_cu, 'SCG_GRID_CAP_PER_CU', 0)
+        self.PLANE_PAD = _knob(plane_pad, 'SCG_LD_PAD', 17)                         # units of 64 lanes (256 B)
         # initial state / randomisation
         self.INIT_STATE = init_state
         self.RANDOMIZED_INIT = randomized_init
@@ -362,6 +372,10 @@ class BenchmarkEnv:
                 cfg.inertial_rand_low[q], cfg.inertial_rand_high[q] = lo, hi
         cfg.seed = self._seed & 0xFFFFFFFFFFFFFFFF
         cfg.env_index_base = self.ENV_INDEX_BASE
+        cfg.rollout_queues = self.ROLLOUT_QUEUES
+        cfg.rollout_split_min = self.ROLLOUT_SPLIT_MIN
+        cfg.ref_in_lds = self.REF_IN_LDS
+        cfg.grid_cap_per_cu = self.GRID_CAP_PER_CU
         self._fill_system_config(cfg)
         return Engine(cfg, x_goal_table=self._x_goal_table(), constraint_list=constraint_list, device=self.device,
                       disturbances=[e for mode, dl in self.disturbances.items() for e in dl.compile(mode)])
@@ -382,9 +396,9 @@ class BenchmarkEnv:
         # Plane-stride skew: with a power-of-two stride the j-th plane of every array maps to the same HBM
         # channel for a given env index and the 12 + 4 + ... streams of a wave collide there.  17 x 256 B of
         # padding per plane measured best (-10 % kernel time at 2^20 envs; 64 x 256 B is as bad as none) --
-        # DESIGN.md section 6.  SCG_LD_PAD (units of 64 lanes) overrides it for tuning.
+        # DESIGN.md section 6.  make(..., plane_pad=k) (units of 64 lanes) overrides it for tuning.
         if n >= 4096:
-            ld += 64 * int(os.environ.get('SCG_LD_PAD', '17'))
+            ld += 64 * self.PLANE_PAD
         self._ld = ld
         dev, f32 = self.device, torch.float32
         nx, nu = self.state_dim, self.action_dim

@@ -45,11 +45,12 @@ def make_sharded(make_fn, total_envs, rank=0, world_size=1, **kwargs):
     return make_fn(num_envs=hi - lo, env_index_base=lo, **kwargs)
 
 
-def all_gather_episode_returns(local_returns, total_envs=None):
+def all_gather_episode_returns(local_returns, total_envs=None, force_collective=False):
     """[n_local] -> [total] on every rank (rank order = global env order).
 
-    Uneven shards are padded to the largest one so that a single all_gather_into_tensor suffices."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    Uneven shards are padded to the largest one so that a single all_gather_into_tensor suffices.  A world of one rank
+    returns a copy without touching the backend, unless ``force_collective`` (tests: the RCCL call on a one-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force_collective):
         return local_returns.clone()
     world, rank = dist.get_world_size(), dist.get_rank()
     n_local = local_returns.shape[0]

@@ -64,3 +64,81 @@ def test_single_process_passthrough():
     from safe_control_gym_amd import parallel
     x = torch.arange(5, dtype=torch.float32)
     assert torch.equal(parallel.all_gather_episode_returns(x), x)
+
+
+# ---- the launcher of bench.py: `python bench.py --gpus N` starts its own N ranks (no GPU call in the parent) -----------
+import json
+import subprocess
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, 'bench.py')
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(extra)
+    return env
+
+
+def test_bench_dispatch_decision():
+    """Spawn exactly when N > 1 ranks are asked for and no launcher made them (the driver calls `python bench.py --gpus N`;
+    under torch.distributed.run WORLD_SIZE is set and every rank runs the body)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse_args(['--gpus', '8'])
+    assert bench.must_spawn(a, {}) and not bench.must_spawn(a, {'WORLD_SIZE': '8'})
+    assert not bench.must_spawn(bench.parse_args(['--gpus', '1']), {})
+    # the parent's path (module top level -> parse_args -> must_spawn -> spawn_ranks) never imports torch and never execs:
+    # nothing of it can initialise HIP
+    import ast
+    tree = ast.parse(open(BENCH).read())
+    parent_path = [n for n in tree.body if not isinstance(n, (ast.FunctionDef, ast.ClassDef))]
+    parent_path += [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ('parse_args', '_free_port', 'must_spawn', 'spawn_ranks')]
+    assert any(isinstance(n, ast.FunctionDef) and n.name == 'spawn_ranks' for n in parent_path)
+    for top in parent_path:
+        for node in ast.walk(top):
+            if isinstance(node, (ast.Import, ast.ImportFrom)):
+                names = [a.name for a in node.names] + [getattr(node, 'module', '') or '']
+                assert not any(nm.split('.')[0] in ('torch', 'safe_control_gym_amd') for nm in names), names
+            if isinstance(node, ast.Attribute):
+                assert not (node.attr.startswith('exec') and node.attr != 'executable'), 'the launcher must start children, never exec'
+
+
+@pytest.mark.parametrize('world', [2, 8])
+def test_bench_spawns_its_own_ranks_and_relays_rank0_line(world):
+    """Stand-in workers (--dry-run: gloo rendezvous + the timed region's collectives on host tensors, no GPU): the parent
+    prints exactly rank 0's JSON line, which proves the backend saw `world` ranks."""
+    run = subprocess.run([sys.executable, BENCH, '--gpus', str(world), '--steps', '20', '--warmup', '5', '--dry-run'],
+                         env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, run.stdout
+    j = json.loads(lines[0])
+    assert j['dry_run'] is True and j['n_gpus'] == world and j['ranks_seen'] == world and j['backend'] == 'gloo'
+    assert j['gather_ok'] is True and j['steps'] == 20 and j['warmup'] == 5
+
+
+def test_bench_launcher_propagates_a_failing_rank():
+    """One rank dies after the rendezvous: the parent stops the others (they would wait in a collective forever), prints
+    no JSON line and exits with the failing rank's code."""
+    t0 = time.time()
+    run = subprocess.run([sys.executable, BENCH, '--gpus', '4', '--dry-run'],
+                         env=_clean_env(SCG_BENCH_DRYRUN_FAIL_RANK='2'), capture_output=True, text=True, timeout=600)
+    assert run.returncode == 3, (run.returncode, run.stderr[-2000:])
+    assert not any(ln.startswith('{') for ln in run.stdout.splitlines())
+    assert 'rank 2 exited with 3' in run.stderr
+    assert time.time() - t0 < 300
+
+
+def test_bench_rejects_a_world_size_mismatch():
+    """--gpus N under a launcher that made a different number of ranks is an error, not silently ignored."""
+    run = subprocess.run([sys.executable, BENCH, '--gpus', '4', '--dry-run'], env=_clean_env(WORLD_SIZE='1', RANK='0'),
+                         capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0          # the dry run only rendezvous: world 1 is fine for it ...
+    run = subprocess.run([sys.executable, BENCH, '--gpus', '4', '--steps', '2', '--warmup', '1'],
+                         env=_clean_env(WORLD_SIZE='1', RANK='0'), capture_output=True, text=True, timeout=300)
+    assert run.returncode != 0 and 'WORLD_SIZE is 1' in run.stderr     # ... the real body refuses

@@ -42,21 +42,13 @@ LEAN = CONFIGS + [
 ]
 
 
-@pytest.mark.parametrize('n', [96, 1, 2, 127, 130])
-@pytest.mark.parametrize('name,system,kw', LEAN, ids=[c[0] for c in LEAN])
-@pytest.mark.parametrize('packed', ['0', '1'])
-def test_lean_tier_parity_teacher_forced(gpu, monkeypatch, name, system, kw, n, packed):
-    """info_level='minimal' selects the lean feature tiers (no FT_EXTRA).  packed=1 runs them on the opt-in
-    two-envs-per-lane kernel (scg_step2_kernel; SCG_PACKED is read once per process, so the packed arm only
-    takes effect when the whole session runs with SCG_PACKED=1 -- tools/run_gpu_tests.sh does both).
-    Odd n exercises the one-env tail lane."""
-    import os
-    if packed == '1' and os.environ.get('SCG_PACKED') != '1':
-        pytest.skip('packed arm runs in a session started with SCG_PACKED=1')
-    if packed == '0' and os.environ.get('SCG_PACKED') == '1':
-        pytest.skip('unpacked arm runs in a session without SCG_PACKED=1')
-    if n != 96 and name not in ('q3_track_quadratic', 'q2_stab_rl', 'q3_competition_constraints'):
-        pytest.skip('batch-size sweep on three representative configs only')
+_LEAN_SWEEP = ('q3_track_quadratic', 'q2_stab_rl', 'q3_competition_constraints')     # batch-size sweep on three configs
+_LEAN_CASES = [(c[0], c[1], c[2], n) for c in LEAN for n in (96, 1, 2, 127, 130) if n == 96 or c[0] in _LEAN_SWEEP]
+
+
+@pytest.mark.parametrize('name,system,kw,n', _LEAN_CASES, ids=['%s-n%d' % (c[0], c[3]) for c in _LEAN_CASES])
+def test_lean_tier_parity_teacher_forced(gpu, name, system, kw, n):
+    """info_level='minimal' selects the lean feature tiers (no FT_EXTRA).  Ragged n exercises the partial last wave."""
     env, ref, sampler = make_pair(system, n, randomized_init=True, engine_kwargs=dict(info_level='minimal'), **kw)
     obs_e, obs_r = sync_reset(env, ref, sampler)
     assert rel_err(obs_e.cpu().numpy(), obs_r) <= RTOL
@@ -288,12 +280,11 @@ def test_no_auto_reset_and_masked_reset(gpu):
     assert torch.equal(env.state[1::2], before[1::2]) and not torch.equal(env.state[::2], before[::2])
 
 
-def test_lds_staged_reference_table(gpu, monkeypatch):
-    """The optional LDS-staged X_GOAL path (SCG_REF_IN_LDS=1) gives the same numbers."""
-    monkeypatch.setenv('SCG_REF_IN_LDS', '1')
+def test_lds_staged_reference_table(gpu):
+    """The optional LDS-staged X_GOAL path (make(..., ref_in_lds=1) -> scg_config.ref_in_lds) gives the same numbers."""
     n = 300
     kw = dict(task='traj_tracking', cost='rl_reward', ctrl_freq=60, pyb_freq=240, obs_goal_horizon=2)
-    env, ref, sampler = make_pair(3, n, randomized_init=True, **kw)
+    env, ref, sampler = make_pair(3, n, randomized_init=True, engine_kwargs=dict(ref_in_lds=1), **kw)
     sync_reset(env, ref, sampler)
     assert env._engine.kernel_info(n)['lds_bytes'] >= 300 * 12 * 4
     rng = np.random.default_rng(1)
