@@ -38,7 +38,7 @@ def main():
                 act = actor(obs) + 0.1 * torch.randn(n, nu, device='cuda')          # [N, nu] rows: read in place by the kernel
                 v = critic(obs)
                 next_obs, rew, done, info = env.step(act)
-                next_obs = obs_norm(next_obs).clone()
+                next_obs = obs_norm(next_obs)               # a fresh tensor per call: `obs` of this step stays intact
                 rew = rew_norm(rew, done)
                 terminal_v = torch.where(info['TimeLimit.truncated'][:, None], critic(info['terminal_observation']), zeros)
                 buf.push({'obs': obs, 'act': act, 'rew': rew, 'mask': 1.0 - done.float(), 'v': v, 'terminal_v': terminal_v})
@@ -47,7 +47,7 @@ def main():
                                                       use_gae=True, gae_lambda=0.95)
         return obs, ret, adv
 
-    obs = obs_norm(env.reset()).clone()
+    obs = obs_norm(env.reset())
     obs, _, _ = rollout(obs)                                                        # warm-up
     torch.cuda.synchronize()
     t0 = time.perf_counter()

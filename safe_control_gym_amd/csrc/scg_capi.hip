@@ -109,6 +109,14 @@ static void derive_params(scg_handle* h) {
     if (c.task == SCG_STABILIZATION && k.obs_goal_horizon > 1) k.obs_goal_horizon = 1;
     k.n_con_rows = 0;
     k.grid_cap_per_cu = c.grid_cap_per_cu > 0 ? c.grid_cap_per_cu : 0;
+    // dims whose out-of-bound box is binding: the reference bounds the velocities / rates with +-f32max
+    // (quadrotor.py:742-791), which no finite float violates -- the kernel skips those compares.  A non-finite
+    // velocity still ends the episode: it reaches the position (a bounded dim) within the same RK4 step.
+    k.oob_dims = 0;
+    for (int j = 0; j < nx; ++j) {
+        const double m = (double)std::numeric_limits<float>::max();
+        if (c.oob_low[j] > -m || c.oob_high[j] < m) k.oob_dims |= 1u << j;
+    }
     k.seed_lo = (uint32_t)(c.seed & 0xffffffffull);
     k.seed_hi = (uint32_t)(c.seed >> 32);
     k.env_base = c.env_index_base;

@@ -59,7 +59,7 @@ struct KParams {
     int32_t obs_goal_horizon;
     int32_t n_con_rows;         // total constraint rows (c_val planes)
     int32_t grid_cap_per_cu;    // host-side launch policy (scg_config.grid_cap_per_cu); not read on the device
-    int32_t pad0;
+    uint32_t oob_dims;          // bit j: state dim j has a binding out-of-bound limit (|bound| < f32max); the others are skipped
     uint32_t seed_lo, seed_hi;
     int64_t env_base;
     PhysT<float> ph;            // physical constants (fp32 copy, SGPRs)

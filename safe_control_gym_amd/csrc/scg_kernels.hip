@@ -35,11 +35,22 @@ namespace scg {
 #ifndef SCG_PREFETCH
 #define SCG_PREFETCH 0         // load the next grid-stride iteration's lane inputs before computing this one
 #endif
+#ifndef SCG_OOB_MASK
+#define SCG_OOB_MASK 1         // skip the out-of-bound compares of dims whose limits are +-f32max (wave-uniform branch per dim)
+#endif
+#ifndef SCG_NUM_SGPR
+#define SCG_NUM_SGPR 0         // > 0: cap the step kernel's SGPR allocation (amdgpu_num_sgpr); <= 80 admits 8 workgroups per CU
+#endif
 constexpr int kBlock = SCG_BLOCK;
-#if SCG_MIN_WAVES > 0
-#define SCG_BOUNDS __launch_bounds__(kBlock, SCG_MIN_WAVES)
+#if SCG_NUM_SGPR > 0
+#define SCG_SGPR_CAP __attribute__((amdgpu_num_sgpr(SCG_NUM_SGPR)))
 #else
-#define SCG_BOUNDS __launch_bounds__(kBlock)
+#define SCG_SGPR_CAP
+#endif
+#if SCG_MIN_WAVES > 0
+#define SCG_BOUNDS __launch_bounds__(kBlock, SCG_MIN_WAVES) SCG_SGPR_CAP
+#else
+#define SCG_BOUNDS __launch_bounds__(kBlock) SCG_SGPR_CAP
 #endif
 
 // Philox4x32-10 (Salmon et al., SC'11).  Counter layout shared with oracle/philox.py.
@@ -223,6 +234,74 @@ __device__ __forceinline__ void reset_state_coop(const KParams& p, const KTables
         __builtin_amdgcn_wave_barrier();
         if (need && rank >= base && rank < base + JOBS) {
             const float* mine = s_u + (rank - base) * W;
+#pragma unroll
+            for (int d = 0; d < NX; ++d) x[d] += fmaf(tb->init_span[d], mine[d], tb->init_lo[d]);
+        }
+    }
+}
+
+// Workgroup-pooled form of the same job (SCG_WG_RESET, default on).  With a few percent of the lanes finishing per step
+// nearly every wave has at least one resetting lane, so the per-wave form above runs its ~100-instruction Philox
+// evaluation in ~9 of 10 waves for a handful of useful lanes each.  Here the resetting lanes of the WHOLE workgroup
+// (kBlock lanes) publish their env indices in one LDS list (slots handed out by one LDS atomic per wave), and the
+// (env, block) jobs are dealt to the workgroup's threads in order: at the usual 2-10 resetting envs per workgroup only
+// the first wave has jobs and the other three skip the evaluation.  Same counters, same draws, bit for bit.
+// Two workgroup barriers per step; taken only by workgroups whose lanes are ALL in range (block-uniform), so every
+// wave of the workgroup reaches every barrier; a ragged last workgroup uses the per-wave form.
+//   s_tot[2]: list length, double-buffered by `parity` (the other one is zeroed here for the next iteration / step)
+//   s_idx[kBlock]: env indices of the resetting lanes;  s_u[(kBlock / NB) * W]: uniforms of one pass
+constexpr int kWgResetFloats = 4 + kBlock + ((kBlock * 4 + 3) & ~3);
+#ifndef SCG_WG_RESET
+#define SCG_WG_RESET 1
+#endif
+
+template <int NX>
+__device__ __forceinline__ void reset_state_wg(const KParams& p, const KTables* __restrict__ tb,
+                                               const float* __restrict__ reset_state, int64_t ld, uint32_t i,
+                                               uint32_t serial, bool need, float* scratch, int parity, float (&x)[NX]) {
+    constexpr int NB = (NX + 3) / 4;          // Philox blocks per env
+    constexpr int W = 4 * NB;                 // uniforms per env (>= NX)
+    constexpr int CAP = kBlock / NB;          // envs served per pass of the workgroup
+    uint32_t* s_tot = reinterpret_cast<uint32_t*>(scratch);
+    uint32_t* s_idx = s_tot + 4;
+    float* s_u = scratch + 4 + kBlock;
+    if (need) {
+        if (reset_state) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) x[j] = ldp(uptr(reset_state + j * opaque_s(ld)), i * 4u);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) x[j] = tb->init_state[j];
+        }
+    }
+    const unsigned long long m = __ballot(need);
+    int rank = 0;
+    if (m) {                                                          // wave-uniform
+        const int cnt = __popcll(m);
+        uint32_t base = 0;
+        if (__lane_id() == 0) base = atomicAdd(&s_tot[parity], (uint32_t)cnt);
+        base = __builtin_amdgcn_readfirstlane(base);
+        rank = (int)base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (need) s_idx[rank] = i;
+    }
+    __syncthreads();                                                  // the list is complete
+    const int total = (int)__builtin_amdgcn_readfirstlane(s_tot[parity]);   // plain LDS read behind the barrier
+    if (threadIdx.x == 0) s_tot[parity ^ 1] = 0u;                     // nobody touches the other counter before the next step
+    const int job = (int)threadIdx.x;
+    const int k = job / NB, blk = job - k * NB;
+    for (int pb = 0; pb < total; pb += CAP) {                         // block-uniform trip count (1 unless > CAP envs reset)
+        if (pb > 0) __syncthreads();                                  // the previous pass's uniforms have been consumed
+        const int slot = pb + k;
+        if (k < CAP && slot < total) {
+            const uint64_t g = (uint64_t)(p.env_base + (int64_t)s_idx[slot]);
+            uint32_t w[4];
+            philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), serial, (uint32_t)blk, p.seed_lo, p.seed_hi, w);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s_u[k * W + 4 * blk + q] = (float)(w[q] >> 8) * 5.9604644775390625e-8f;
+        }
+        __syncthreads();                                              // the uniforms of this pass are in LDS
+        if (need && rank >= pb && rank < pb + CAP) {
+            const float* mine = s_u + (rank - pb) * W;
 #pragma unroll
             for (int d = 0; d < NX; ++d) x[d] += fmaf(tb->init_span[d], mine[d], tb->init_lo[d]);
         }
@@ -648,8 +727,15 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
     const bool has_con = EXTRA ? (p.n_con_rows > 0) : ((FT & FT_CON) != 0);
 
     // per-wave LDS scratch of the cooperative reset, placed after the (16-B padded) reference table
-    float* coop_scratch = s_ref + ((tracking && (p.flags & F_REF_IN_LDS)) ? (((p.ref_rows * NX + 3) >> 2) << 2) : 0) +
-                          (threadIdx.x >> 6) * kCoopFloats;
+    float* wg_scratch = s_ref + ((tracking && (p.flags & F_REF_IN_LDS)) ? (((p.ref_rows * NX + 3) >> 2) << 2) : 0);
+    float* coop_scratch = wg_scratch + (threadIdx.x >> 6) * kCoopFloats;      // per-wave form: aliases the pooled form's scratch
+    const bool pooled_reset = SCG_WG_RESET && (p.flags & F_AUTO_RESET) && (p.flags & F_RAND_INIT);
+    if (pooled_reset) {
+        // list counters of the workgroup-pooled reset; visible to every wave after the first barrier each of them takes
+        // (the table-staging barrier below, or the first barrier inside reset_state_wg -- so zero BOTH before any of them)
+        if (threadIdx.x < 2) reinterpret_cast<uint32_t*>(wg_scratch)[threadIdx.x] = 0u;
+        __syncthreads();
+    }
 
     const int64_t ld = io.ld;
     float st_rew = 0.f, st_done = 0.f, st_viol = 0.f, st_fret = 0.f, st_flen = 0.f, st_trunc = 0.f;
@@ -894,7 +980,8 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         if (p.flags & F_DONE_OOB) {
             bool inb = true;                                                // NaN compares false -> out of bounds
 #pragma unroll
-            for (int j = 0; j < NX; ++j) inb &= (x[j] >= tb->oob_low[j]) & (x[j] <= tb->oob_high[j]);
+            for (int j = 0; j < NX; ++j)
+                if (!SCG_OOB_MASK || (p.oob_dims & (1u << j))) inb &= (x[j] >= tb->oob_low[j]) & (x[j] <= tb->oob_high[j]);   // wave-uniform skip
             done |= !inb;
         }
         if (INFO && io.goal_reached) stp(io.goal_reached, i, (uint8_t)(goal_reached ? 1 : 0));
@@ -1005,9 +1092,16 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
             }
         }
         const bool need_reset = done && (p.flags & F_AUTO_RESET);
-        if (__ballot(need_reset)) {                                         // wave-uniform
+        // every lane of this workgroup in range (block-uniform): all its waves reach the barriers of the pooled form
+        const bool wg_full = pooled_reset && ((i - threadIdx.x) + kBlock <= n);
+        if (wg_full || __ballot(need_reset)) {                              // wave-uniform
             float xr[NX];
-            reset_state_coop<NX>(p, tb, io.reset_state, ld, i, serial, need_reset, coop_scratch, xr);
+            if (wg_full) reset_state_wg<NX>(p, tb, io.reset_state, ld, i, serial, need_reset, wg_scratch, kstep & 1, xr);
+#if SCG_WG_RESET
+            else if (need_reset) reset_state_of<NX>(p, tb, io.reset_state, ld, i, serial, xr);     // ragged last workgroup / no randomisation
+#else
+            else reset_state_coop<NX>(p, tb, io.reset_state, ld, i, serial, need_reset, coop_scratch, xr);
+#endif
             if (need_reset) {
 #pragma unroll
                 for (int j = 0; j < NX; ++j) x[j] = xr[j];
@@ -1251,7 +1345,8 @@ LaunchGeom step_geometry(const KParams& p, int system, int64_t n, int num_cus) {
     int64_t blocks = (n + kBlock - 1) / kBlock;
     g.lds_bytes = 0;
     if ((p.flags & F_AUTO_RESET) && (p.flags & F_RAND_INIT))
-        g.lds_bytes += (kBlock / 64) * kCoopFloats * (int)sizeof(float);   // cooperative-reset scratch
+        g.lds_bytes += ((kBlock / 64) * kCoopFloats > kWgResetFloats ? (kBlock / 64) * kCoopFloats : kWgResetFloats) *
+                       (int)sizeof(float);                                  // reset scratch (pooled form / per-wave form)
     // scg_config.grid_cap_per_cu (tuning knob): cap the grid at that many workgroups per CU and grid-stride the rest.
     int cap_per_cu = p.grid_cap_per_cu;
     if ((p.flags & F_TRACKING) && (p.flags & F_REF_IN_LDS)) {

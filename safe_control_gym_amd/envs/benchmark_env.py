@@ -113,7 +113,7 @@ class BenchmarkEnv:
                  num_envs=1, device='cuda', physics='rk4', integration_substeps=1, motor_map=True,
                  auto_reset=True, info_level='full', compensated_state=False, track_episode_stats=True,
                  env_index_base=0, rollout_queues=None, rollout_split_min=None, ref_in_lds=None, grid_cap_per_cu=None,
-                 plane_pad=None,
+                 plane_pad=None, copy_outputs=None,
                  **kwargs):
         self.id = self.__class__._count
         self.__class__._count += 1
@@ -151,6 +151,10 @@ class BenchmarkEnv:
         if info_level not in ('full', 'minimal'):
             raise ValueError("[ERROR] info_level must be 'full' or 'minimal'.")
         self.INFO_LEVEL = info_level
+        # step() outputs: fresh tensors (the reference returns new arrays, quadrotor.py:878 deepcopy) or zero-copy views of
+        # the engine's planes that the NEXT step() overwrites.  Default: fresh with the drop-in API (info_level='full'),
+        # views with the lean one.  See step().
+        self.COPY_OUTPUTS = (info_level == 'full') if copy_outputs is None else bool(copy_outputs)
         # precise mode: state kept as hi + lo float32 planes and integrated in float64
         self.COMPENSATED_STATE = bool(compensated_state)
         self.TRACK_EPISODE_STATS = bool(track_episode_stats)
@@ -203,7 +207,6 @@ class BenchmarkEnv:
         self.RND_SEED = seed
         self.RESEED_ON_RESET = kwargs.get('reseed_on_reset', False)
         self._bufs = None
-        self._serial = 0
         self._raw_action, self._raw_action_rows = None, False
 
     # ------------------------------------------------------------------ seeding
@@ -211,17 +214,24 @@ class BenchmarkEnv:
         """benchmark_env.py:220-235.  The device stream is Philox keyed by this seed; ``None`` draws one."""
         if seed is None:
             seed = int(np.random.SeedSequence().entropy % (2 ** 63))
+        # the Philox key is part of the handle's constants: a new handle only when the key really changes
+        if getattr(self, '_seed', None) != int(seed):
+            self._engine_dirty = True
         self._seed = int(seed)
         self.np_random = np.random.RandomState(self._seed % (2 ** 32))
         self.action_space.seed(self._seed % (2 ** 32))
         for disturbs in getattr(self, 'disturbances', {}).values():
             disturbs.seed(self)
-        self._engine_dirty = True
+        # re-seeding rewinds the stream: the draws that follow repeat those that followed the previous seed() with this value
+        # (counter = (global env index, serial); the reference re-creates np_random, benchmark_env.py:231)
+        self._serial = 0
         return [seed]
 
     # -- checkpoint / resume of the simulation state (the reference checkpoints only the policy side and the envs' RNG
     #    states, controllers/ppo/ppo.py:115-155 + dummy_vec_env.py:88-100; here the env state is a handful of tensors) ----
-    _CHECKPOINT_PLANES = ('state', 'state_lo', 'step_count', 'ep_return', 'ep_length', 'inertial', 'episode_id')
+    # 'obs' is persistent too when it is a buffer of its own (goal horizon / observation noise): the observation an env
+    # exposes between two steps must survive a resume
+    _CHECKPOINT_PLANES = ('state', 'state_lo', 'step_count', 'ep_return', 'ep_length', 'inertial', 'episode_id', 'obs')
 
     def state_dict(self):
         """Everything a resumed run needs to continue bit for bit: the device planes that persist across steps, the
@@ -646,7 +656,11 @@ class BenchmarkEnv:
         return src[:, :self.num_envs].T
 
     def reset(self, mask=None):
-        """(Re-)initialise all envs (or those where ``mask`` is set).  Returns obs or (obs, info)."""
+        """(Re-)initialise all envs (or those where ``mask`` is set).  Returns obs or (obs, info).
+
+        ``reseed_on_reset=True`` (benchmark_env.py:356-362, ``before_reset``: ``self.seed(self.RND_SEED)`` ahead of every reset) makes
+        every reset draw the SAME initial states, inertial properties and disturbance streams: the Philox stream is rewound,
+        the handle (same key) is kept."""
         if self.RESEED_ON_RESET:
             self.seed(self.RND_SEED)
         self._ensure_engine()
@@ -664,6 +678,8 @@ class BenchmarkEnv:
         self._bound = False
         self._serial += 1
         obs = self._obs_view()
+        if self.COPY_OUTPUTS:
+            obs = obs.clone()
         if self.INFO_IN_RESET:
             return obs, self._get_reset_info()
         return obs
@@ -713,7 +729,14 @@ class BenchmarkEnv:
         return buf, False
 
     def step(self, action):
-        """Advance every env by one control step (quadrotor.py:507-558 + benchmark_env.py:422-463)."""
+        """Advance every env by one control step (quadrotor.py:507-558 + benchmark_env.py:422-463).
+
+        OWNERSHIP OF THE OUTPUTS.  With ``copy_outputs=True`` (the default of ``info_level='full'``, i.e. of a plain
+        ``make()``) ``obs``, ``rew`` and ``done`` are fresh tensors, as the reference's are: the usual RL loop keeps the
+        previous ``obs`` until after the next ``step()`` (controllers/ppo/ppo.py:259-276).  With ``copy_outputs=False``
+        (default of ``info_level='minimal'``) they are zero-copy VIEWS of the engine's planes -- valid until the next
+        ``step()`` / ``rollout()`` / ``reset()``, ``.clone()`` what must outlive it (saves ~100 B/env of copy traffic per
+        step).  The tensors inside ``info`` are always views of per-step buffers."""
         self._check_initial_reset()
         act, rows = self._load_action(action)
         self._raw_action, self._raw_action_rows = act, rows
@@ -736,6 +759,8 @@ class BenchmarkEnv:
             self._engine.step_bound(act, self.num_envs, self._serial, action_rows=rows)
         self._serial += 1
         obs, rew, done = self._out_views
+        if self.COPY_OUTPUTS:
+            obs, rew, done = obs.clone(), rew.clone(), done.clone()
         info = dict(self._info_views)
         if info.get('constraint_values', 0) is None:                 # folded constraints (|y| - bound): needs a max()
             info['constraint_values'] = self.constraints.fold(b['constraint_values'][:, :self.num_envs].T)

@@ -107,7 +107,6 @@ class MeanStdNormalizer(BaseNormalizer):
         self.clip = clip
         self.epsilon = epsilon
         self.device = self.rms.device
-        self._out = None
 
     def _planes(self, x):
         """(planes pointer tensor, ld, n): zero copy for an [N, d] view of SoA planes, else one transposing copy."""
@@ -125,23 +124,33 @@ class MeanStdNormalizer(BaseNormalizer):
         t = x.T.contiguous()
         return t.T, n, n
 
-    def __call__(self, x):
-        """Update the tracker with the batch (unless read_only), return the normalised, clipped batch [N, d]."""
+    def __call__(self, x, out=None):
+        """Update the tracker with the batch (unless read_only), return the normalised, clipped batch [N, d].
+
+        The result is a FRESH tensor on every call, as the reference's is (normalization.py:125-133 returns a new
+        array): callers keep the previous step's observation around while the next one is produced
+        (controllers/ppo/ppo.py:259-276 pushes ``obs`` after ``obs_normalizer(next_obs)`` has run).  ``out`` opts into
+        reuse: a float32 [d, ld] plane buffer (ld >= N, a multiple of 64) that receives the result and whose [N, d]
+        view is returned -- then the caller owns the aliasing."""
         xv, ld_x, n = self._planes(x)
         d = self.rms.d
         if n == 0:
             return xv
         ld_y = (n + 63) // 64 * 64
-        if self._out is None or self._out.shape[1] != ld_y:
-            self._out = torch.empty((d, ld_y), dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((d, ld_y), dtype=torch.float32, device=self.device)
+        elif not (isinstance(out, torch.Tensor) and out.dtype == torch.float32 and out.is_contiguous() and out.ndim == 2
+                  and out.shape[0] == d and out.shape[1] >= n and out.device == xv.device):
+            raise ValueError('[ERROR] out must be a contiguous float32 (%d, ld >= %d) device tensor' % (d, n))
+        ld_y = out.shape[1]
         state_in, state_out = self.rms._records(not self.read_only)
         with torch.cuda.device(self.device):
-            _capi.check(self.lib.scg_mean_std_normalize(xv.data_ptr(), self._out.data_ptr(), d, ld_x, ld_y, n,
+            _capi.check(self.lib.scg_mean_std_normalize(xv.data_ptr(), out.data_ptr(), d, ld_x, ld_y, n,
                                                         state_in.data_ptr(), _capi.ptr(state_out),
                                                         self.rms._moments.data_ptr(), float(self.clip),
                                                         float(self.epsilon), _stream(self.device)),
                         'scg_mean_std_normalize')
-        return self._out[:, :n].T
+        return out[:, :n].T
 
     def state_dict(self):
         return {'mean': self.rms.mean.cpu().numpy(), 'var': self.rms.var.cpu().numpy()}

@@ -1,0 +1,573 @@
+#!/usr/bin/env python
+"""Generate tests/golden/reference_numpy.npz by EXECUTING the reference's own NumPy-only code for the hot path.
+
+The reference's modules cannot be imported in the build container (casadi / pybullet / gym are absent: ordinary
+ModuleNotFoundError), but many of the functions the path consists of need nothing but NumPy.  This script
+parses the cited reference files with ``ast``, takes exactly the function / method / class definitions (or, where a method
+mixes NumPy with PyBullet calls, a leading run of its statements) named in the ``SOURCES +=`` lines below, compiles them UNCHANGED
+under their own file name and line numbers, and executes them with NumPy and plain attribute holders.  No module is
+stubbed: nothing that needs casadi, pybullet or gym is executed (those functions stay "parity unpinned", DESIGN.md
+section 2).  Two NumPy-1.x spellings the reference uses were removed in NumPy 2 and are aliased to their documented
+equivalents in the namespace the code runs in: ``np.round_`` (= ``np.round``) and ``np.long`` (= ``int``).
+
+Groups written (inputs and the reference's outputs, float64):
+  motor_map      cmd2pwm / pwm2rpm                       envs/gym_pybullet_drones/quadrotor_utils.py:21-67
+  trajectory     _generate_trajectory / _get_coordinates / _figure8 / _circle / _square   envs/benchmark_env.py:465-674
+  transform      unit_vector / projection_matrix / transform_trajectory                   math_and_models/transformations.py:10-123
+  x_goal         the X_GOAL / U_GOAL statements of Quadrotor.__init__                     envs/gym_pybullet_drones/quadrotor.py:261-329
+  constraints    Constraint family, ConstraintList, create_constraint_list                envs/constraints.py:21-612
+  step_glue      before_step / _preprocess_control / extend_obs / _get_done / _get_reward (rl) / the mse statements of
+                 _get_info / after_step                   envs/benchmark_env.py:394-463, quadrotor.py:815-842,886-913,956-993,1011-1025
+  gae            compute_returns_and_advantages          controllers/ppo/ppo_utils.py:428-456
+  normalization  RunningMeanStd, MeanStdNormalizer, RewardStdNormalizer                   math_and_models/normalization.py:17-190
+
+Run in the build container only (the reference never travels to the GPU box):
+    python tests/golden/make_golden_reference_numpy.py
+tests/test_reference_pins.py replays the oracle (CPU) and the HIP path (GPU) against the file.
+"""
+import ast
+import json
+import math
+import os
+import sys
+import types
+from copy import deepcopy
+from enum import Enum, IntEnum
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference/safe_control_gym'
+
+
+class NumpyCompat:
+    """numpy, plus the two aliases of NumPy 1.x that NumPy 2 dropped and the reference still spells."""
+    round_ = staticmethod(np.round)      # np.round_ was an alias of np.round (removed in NumPy 2.0)
+    long = int                           # np.long was an alias of int (removed in NumPy 1.24)
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+
+NP = NumpyCompat()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# AST extraction
+# ---------------------------------------------------------------------------------------------------------------------
+_TREES = {}
+
+
+def _tree(rel):
+    if rel not in _TREES:
+        path = os.path.join(REF, rel)
+        with open(path) as f:
+            _TREES[rel] = (ast.parse(f.read(), filename=path), path)
+    return _TREES[rel]
+
+
+def _find(body, name):
+    for node in body:
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)) and node.name == name:
+            return node
+    raise KeyError(name)
+
+
+def _exec_nodes(nodes, path, ns):
+    mod = ast.Module(body=list(nodes), type_ignores=[])
+    exec(compile(mod, path, 'exec'), ns)
+
+
+def top_level(rel, names, ns):
+    """Execute the top-level definitions `names` of a reference file (unchanged) in namespace `ns`."""
+    tree, path = _tree(rel)
+    _exec_nodes([_find(tree.body, n) for n in names], path, ns)
+    return [(rel, n, _find(tree.body, n).lineno, _find(tree.body, n).end_lineno) for n in names]
+
+
+def methods(rel, cls, names, ns):
+    """The methods `names` of class `cls`, compiled unchanged as plain functions into `ns` (to be bound to a holder)."""
+    tree, path = _tree(rel)
+    c = _find(tree.body, cls)
+    _exec_nodes([_find(c.body, n) for n in names], path, ns)
+    return [(rel, '%s.%s' % (cls, n), _find(c.body, n).lineno, _find(c.body, n).end_lineno) for n in names]
+
+
+def method_statements(rel, cls, name, pick, fn_name, ns, returns=None):
+    """A run of statements of method `cls.name` selected by `pick(stmt) -> bool`, wrapped unchanged into a function
+    ``fn_name(self)`` (for __init__ blocks, and for methods whose tail calls PyBullet); `returns` names a local of those
+    statements that the wrapper hands back (a method cut before its own ``return``)."""
+    tree, path = _tree(rel)
+    m = _find(_find(tree.body, cls).body, name)
+    chosen = [s for s in m.body if pick(s)]
+    assert chosen, (rel, cls, name)
+    first, last = chosen[0].lineno, chosen[-1].end_lineno
+    if returns:
+        chosen = chosen + [ast.Return(value=ast.Name(id=returns, ctx=ast.Load()))]
+    fn = ast.FunctionDef(name=fn_name, args=ast.arguments(posonlyargs=[], args=[ast.arg(arg='self')], kwonlyargs=[],
+                                                           kw_defaults=[], defaults=[]),
+                         body=chosen, decorator_list=[], lineno=first, col_offset=0)
+    ast.fix_missing_locations(fn)
+    _exec_nodes([fn], path, ns)
+    return [(rel, '%s.%s statements' % (cls, name), first, last)]
+
+
+class Holder:
+    """Plain attribute holder standing where the reference has `self` / `env`."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def bind(holder, ns, names):
+    for n in names:
+        setattr(holder, n, types.MethodType(ns[n], holder))
+
+
+def _assigns_self(stmt, attr):
+    return isinstance(stmt, ast.Assign) and any(isinstance(t, ast.Attribute) and t.attr == attr for t in stmt.targets)
+
+
+def _tests_task(stmt):
+    return isinstance(stmt, ast.If) and 'self.TASK' in ast.unparse(stmt.test) and 'X_GOAL' in ast.unparse(stmt)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the namespace every extracted piece runs in
+# ---------------------------------------------------------------------------------------------------------------------
+NS = {'np': NP, 'math': math, 'deepcopy': deepcopy, 'Enum': Enum, 'IntEnum': IntEnum, 'str': str}
+SOURCES = []
+SOURCES += top_level('envs/gym_pybullet_drones/quadrotor_utils.py', ['QuadType', 'cmd2pwm', 'pwm2rpm'], NS)
+SOURCES += top_level('envs/benchmark_env.py', ['Cost', 'Task'], NS)
+SOURCES += top_level('math_and_models/transformations.py', ['unit_vector', 'projection_matrix', 'transform_trajectory'], NS)
+SOURCES += top_level('envs/constraints.py', ['ConstrainedVariableType', 'Constraint', 'QuadraticContstraint', 'LinearConstraint',
+                                             'BoundedConstraint', 'DefaultConstraint', 'SymmetricStateConstraint',
+                                             'get_symbolic_constraint_models', 'ConstraintList', 'create_constraint_list'], NS)
+SOURCES += top_level('controllers/ppo/ppo_utils.py', ['compute_returns_and_advantages'], NS)
+SOURCES += top_level('math_and_models/normalization.py', ['RunningMeanStd', 'BaseNormalizer', 'MeanStdNormalizer',
+                                                          'RewardStdNormalizer'], NS)
+SOURCES += methods('envs/benchmark_env.py', 'BenchmarkEnv', ['_generate_trajectory', '_get_coordinates', '_figure8', '_circle',
+                                                             '_square', 'before_step', 'extend_obs', 'after_step',
+                                                             '_check_initial_reset'], NS)
+SOURCES += methods('envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor', ['_preprocess_control', '_get_reward', '_get_done'], NS)
+SOURCES += method_statements('envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor', '__init__',
+                             lambda s: _assigns_self(s, 'U_GOAL') or _tests_task(s), 'build_goals', NS)
+# _get_info: everything up to and including  info["mse"] = ...  (the rest of the method queries PyBullet contacts)
+_seen_mse = []
+
+
+def _until_mse(stmt):
+    if _seen_mse:
+        return False
+    if isinstance(stmt, ast.Expr) and isinstance(stmt.value, ast.Constant):
+        return False                                           # the docstring
+    if '"mse"' in ast.unparse(stmt) or "'mse'" in ast.unparse(stmt):
+        _seen_mse.append(1)
+    return True
+
+
+SOURCES += method_statements('envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor', '_get_info', _until_mse, 'info_mse_part', NS,
+                             returns='info')
+
+
+def GENERAL_CONSTRAINTS():
+    return {'linear_constraint': NS['LinearConstraint'], 'quadratic_constraint': NS['QuadraticContstraint'],
+            'bounded_constraint': NS['BoundedConstraint'], 'default_constraint': NS['DefaultConstraint'],
+            'symmetric_state_constraint': NS['SymmetricStateConstraint']}
+
+
+# constants of the reference's vehicle (assets/cf2x.urdf:5,12-13; base_aviary.py:90,100-147)
+CF = dict(MASS=0.03454, GRAVITY_ACC=9.8, KF=3.16e-10, KM=7.94e-12, PWM2RPM_SCALE=0.2685, PWM2RPM_CONST=4070.3, MIN_PWM=20000,
+          MAX_PWM=65535)
+F32MAX = float(np.finfo(np.float32).max)
+OUT = {}
+MANIFEST = {'generator': 'tests/golden/make_golden_reference_numpy.py', 'numpy': np.__version__,
+            'sources': [dict(file='safe_control_gym/' + f, symbol=s, lines=[a, b]) for f, s, a, b in SOURCES], 'groups': {}}
+
+
+def put(key, value):
+    OUT[key] = np.asarray(value, dtype=np.float64)
+
+
+def spaces(quad_type):
+    """Bounds as gym.spaces.Box(dtype=float32) would hold them (quadrotor.py:742-791): float32 arrays."""
+    r85, r180 = 85 * math.pi / 180, math.pi
+    if quad_type == 1:
+        low, high = [0, -F32MAX], [2.5, F32MAX]
+    elif quad_type == 2:
+        low, high = [-5, -F32MAX, 0, -F32MAX, -r85, -F32MAX], [5, F32MAX, 2.5, F32MAX, r85, F32MAX]
+    else:
+        low = [-5, -F32MAX, -5, -F32MAX, 0, -F32MAX, -r85, -r85, -r180, -F32MAX, -F32MAX, -F32MAX]
+        high = [5, F32MAX, 5, F32MAX, 2.5, F32MAX, r85, r85, r180, F32MAX, F32MAX, F32MAX]
+    return Holder(low=np.array(low, dtype=np.float32), high=np.array(high, dtype=np.float32), shape=(len(low),))
+
+
+def action_space(quad_type, normalized=False):
+    """quadrotor.py:720-733."""
+    nu = {1: 1, 2: 2, 3: 4}[quad_type]
+    if normalized:
+        return Holder(low=-np.ones(nu, dtype=np.float32), high=np.ones(nu, dtype=np.float32), shape=(nu,))
+    n_motor = 4 / nu
+    a_low = CF['KF'] * n_motor * (CF['PWM2RPM_SCALE'] * CF['MIN_PWM'] + CF['PWM2RPM_CONST']) ** 2
+    a_high = CF['KF'] * n_motor * (CF['PWM2RPM_SCALE'] * CF['MAX_PWM'] + CF['PWM2RPM_CONST']) ** 2
+    return Holder(low=np.full(nu, np.float32(a_low)), high=np.full(nu, np.float32(a_high)), shape=(nu,))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def gen_motor_map(rng):
+    cases = []
+    for nu in (1, 2, 4):
+        n_motor = 4 // nu
+        lo = CF['KF'] * n_motor * (CF['PWM2RPM_SCALE'] * CF['MIN_PWM'] + CF['PWM2RPM_CONST']) ** 2
+        hi = CF['KF'] * n_motor * (CF['PWM2RPM_SCALE'] * CF['MAX_PWM'] + CF['PWM2RPM_CONST']) ** 2
+        thrusts = np.concatenate([rng.uniform(lo, hi, size=(12, nu)), rng.uniform(-0.1 * hi, 1.6 * hi, size=(8, nu)),
+                                  np.zeros((1, nu)), np.full((1, nu), lo), np.full((1, nu), hi)])
+        pwm = np.array([NS['cmd2pwm'](t.copy(), CF['PWM2RPM_SCALE'], CF['PWM2RPM_CONST'], CF['KF'], CF['MIN_PWM'], CF['MAX_PWM'])
+                        for t in thrusts])
+        rpm = np.array([NS['pwm2rpm'](p, CF['PWM2RPM_SCALE'], CF['PWM2RPM_CONST']) for p in pwm])
+        put('motor_map/nu%d/thrust' % nu, thrusts)
+        put('motor_map/nu%d/pwm' % nu, pwm)
+        put('motor_map/nu%d/rpm' % nu, rpm)
+        cases.append('nu%d' % nu)
+    MANIFEST['groups']['motor_map'] = dict(cases=cases, constants=CF,
+                                           note='pwm = cmd2pwm(thrust, ...) (4 motors), rpm = pwm2rpm(pwm, ...); the force of motor i '
+                                                'is KF rpm_i^2 (base_aviary.py:420)')
+
+
+TRAJ_CASES = [
+    dict(traj_type='circle', traj_length=5.0, num_cycles=1, traj_plane='zx', position_offset=[0.5, 0.0], scaling=-0.5, sample_time=1 / 60),
+    dict(traj_type='figure8', traj_length=5.0, num_cycles=1, traj_plane='xy', position_offset=[0.0, 0.0], scaling=1.0, sample_time=1 / 50),
+    dict(traj_type='square', traj_length=6.0, num_cycles=2, traj_plane='xz', position_offset=[0.2, 1.0], scaling=0.8, sample_time=1 / 30),
+    dict(traj_type='figure8', traj_length=4.0, num_cycles=2, traj_plane='yz', position_offset=[-0.3, 0.7], scaling=0.35, sample_time=1 / 60),
+    dict(traj_type='circle', traj_length=3.0, num_cycles=3, traj_plane='yx', position_offset=[0.0, 0.1], scaling=1.5, sample_time=0.01),
+    dict(traj_type='square', traj_length=5.0, num_cycles=1, traj_plane='zy', position_offset=[1.0, 0.0], scaling=-0.4, sample_time=1 / 60),
+]
+
+
+def gen_trajectory():
+    h = Holder()
+    bind(h, NS, ['_generate_trajectory', '_get_coordinates', '_figure8', '_circle', '_square'])
+    for k, c in enumerate(TRAJ_CASES):
+        kw = dict(c, position_offset=np.array(c['position_offset'], dtype=float))
+        pos, vel, speed = h._generate_trajectory(**kw)
+        put('trajectory/%d/pos' % k, pos)
+        put('trajectory/%d/vel' % k, vel)
+        put('trajectory/%d/speed' % k, speed)
+    MANIFEST['groups']['trajectory'] = dict(cases=TRAJ_CASES)
+
+
+TRANSFORM_CASES = [dict(point=[0.0, 0.0, 0.5], normal=[0.0, 1.0, 1.0]), dict(point=[0.3, -0.2, 1.0], normal=[1.0, 0.0, 0.0]),
+                   dict(point=[0.0, 0.0, 0.0], normal=[0.2, -0.7, 0.4]), dict(point=[1.0, 2.0, 3.0], normal=[0.0, 0.0, -2.0])]
+
+
+def gen_transform(rng):
+    for k, c in enumerate(TRANSFORM_CASES):
+        # ndarray arguments: projection_matrix says np.array(point[:3], dtype=float64, copy=False), which NumPy 2 refuses for a
+        # list (a copy is unavoidable) but accepts for a float64 array, the same values either way
+        point, normal = np.array(c['point'], dtype=np.float64), np.array(c['normal'], dtype=np.float64)
+        put('transform/%d/unit_normal' % k, NS['unit_vector'](normal))
+        put('transform/%d/M' % k, NS['projection_matrix'](point, normal))
+        pos, vel = rng.normal(size=(7, 3)), rng.normal(size=(7, 3))
+        tp, tv = NS['transform_trajectory'](pos, vel, trans_info={'point': point, 'normal': normal})
+        put('transform/%d/pos' % k, pos)
+        put('transform/%d/vel' % k, vel)
+        put('transform/%d/trans_pos' % k, tp)
+        put('transform/%d/trans_vel' % k, tv)
+    MANIFEST['groups']['transform'] = dict(cases=TRANSFORM_CASES,
+                                           note='transform_trajectory augments the VELOCITY rows with ones as well '
+                                                '(transformations.py:121): the plane offset M[:3, 3] is added to the velocities')
+
+
+DEFAULT_TASK_INFO = {'stabilization_goal': [0, 1], 'stabilization_goal_tolerance': 0.05, 'trajectory_type': 'circle', 'num_cycles': 1,
+                     'trajectory_plane': 'zx', 'trajectory_position_offset': [0.5, 0], 'trajectory_scale': -0.5,
+                     'proj_point': [0, 0, 0.5], 'proj_normal': [0, 1, 1]}           # quadrotor.py:136-146
+X_GOAL_CASES = [
+    dict(quad_type=3, task='traj_tracking', ctrl_freq=60, episode_len_sec=5, task_info={}),
+    dict(quad_type=3, task='traj_tracking', ctrl_freq=50, episode_len_sec=4,
+         task_info={'trajectory_type': 'figure8', 'trajectory_plane': 'xy', 'trajectory_scale': 0.75, 'num_cycles': 2,
+                    'trajectory_position_offset': [0.1, -0.2], 'proj_point': [0, 0, 1.0], 'proj_normal': [0, 0, 1]}),
+    dict(quad_type=3, task='stabilization', ctrl_freq=60, episode_len_sec=5, task_info={'stabilization_goal': [0.5, -0.5, 1.2]}),
+    dict(quad_type=2, task='traj_tracking', ctrl_freq=60, episode_len_sec=5, task_info={}),
+    dict(quad_type=2, task='traj_tracking', ctrl_freq=30, episode_len_sec=6,
+         task_info={'trajectory_type': 'square', 'trajectory_plane': 'xz', 'trajectory_scale': 0.6, 'num_cycles': 2}),
+    dict(quad_type=2, task='stabilization', ctrl_freq=60, episode_len_sec=5, task_info={}),
+    dict(quad_type=1, task='traj_tracking', ctrl_freq=60, episode_len_sec=5, task_info={'trajectory_type': 'figure8'}),
+    dict(quad_type=1, task='stabilization', ctrl_freq=60, episode_len_sec=5, task_info={}),
+]
+
+
+def goal_holder(case):
+    """`self` for the X_GOAL / U_GOAL statements of Quadrotor.__init__ (quadrotor.py:261-329)."""
+    ti = dict(DEFAULT_TASK_INFO)
+    ti.update(case['task_info'])
+    ti['proj_point'] = np.array(ti['proj_point'], dtype=np.float64)        # see gen_transform: ndarray for NumPy 2
+    ti['proj_normal'] = np.array(ti['proj_normal'], dtype=np.float64)
+    ti['trajectory_position_offset'] = np.array(ti['trajectory_position_offset'], dtype=float)
+    nx, nu = {1: (2, 1), 2: (6, 2), 3: (12, 4)}[case['quad_type']]
+    h = Holder(QUAD_TYPE=NS['QuadType'](case['quad_type']), TASK=NS['Task'](case['task']), TASK_INFO=ti, MASS=CF['MASS'],
+               GRAVITY_ACC=CF['GRAVITY_ACC'], action_dim=nu, state_dim=nx, EPISODE_LEN_SEC=case['episode_len_sec'],
+               CTRL_TIMESTEP=1.0 / case['ctrl_freq'])
+    bind(h, NS, ['_generate_trajectory', '_get_coordinates', '_figure8', '_circle', '_square', 'build_goals'])
+    h.build_goals()
+    return h
+
+
+def gen_x_goal():
+    for k, c in enumerate(X_GOAL_CASES):
+        h = goal_holder(c)
+        put('x_goal/%d/X_GOAL' % k, h.X_GOAL)
+        put('x_goal/%d/U_GOAL' % k, h.U_GOAL)
+    MANIFEST['groups']['x_goal'] = dict(cases=X_GOAL_CASES, default_task_info=DEFAULT_TASK_INFO)
+
+
+# ---- constraints -----------------------------------------------------------------------------------------------------
+CONSTRAINT_CASES = [
+    dict(name='competition_3d', quad_type=3, specs=[
+        {'constraint_form': 'default_constraint', 'constrained_variable': 'input'},
+        {'constraint_form': 'bounded_constraint', 'constrained_variable': 'state', 'active_dims': [0, 2, 4],
+         'upper_bounds': [3, 3, 2], 'lower_bounds': [-3, -3, -0.1]}]),                        # competition/getting_started.yaml:123-156
+    dict(name='bench_c3', quad_type=2, specs=[
+        {'constraint_form': 'bounded_constraint', 'constrained_variable': 'state', 'active_dims': [0, 2, 4],
+         'lower_bounds': [-2, 0, -0.5], 'upper_bounds': [2, 2, 0.5]}]),
+    dict(name='default_state_and_input_2d', quad_type=2, specs=[
+        {'constraint_form': 'default_constraint', 'constrained_variable': 'input'},
+        {'constraint_form': 'default_constraint', 'constrained_variable': 'state'}]),
+    dict(name='linear_general_strict_tol', quad_type=2, specs=[
+        {'constraint_form': 'linear_constraint', 'constrained_variable': 'state', 'strict': True, 'tolerance': [0.1, 0.2],
+         'A': [[1.0, 0, 0.5, 0, 0, 0], [0, 0, -1.0, 0, 2.0, 0]], 'b': [1.0, 0.3]},
+        {'constraint_form': 'linear_constraint', 'constrained_variable': 'input', 'A': [[1.0, -1.0]], 'b': [0.05]}]),
+    dict(name='quadratic_ball', quad_type=3, specs=[
+        {'constraint_form': 'quadratic_constraint', 'constrained_variable': 'state', 'active_dims': [0, 2, 4],
+         'P': [[1.0, 0.1, 0], [0.1, 2.0, 0], [0, 0, 0.5]], 'b': 1.5, 'tolerance': [0.25]},
+        {'constraint_form': 'bounded_constraint', 'constrained_variable': 'input', 'lower_bounds': [0.03, 0.03, 0.03, 0.03],
+         'upper_bounds': [0.14, 0.14, 0.14, 0.14], 'tolerance': [0.01] * 8}]),
+    dict(name='bounded_1d_tol', quad_type=1, specs=[
+        {'constraint_form': 'bounded_constraint', 'constrained_variable': 'state', 'lower_bounds': [0.2, -1.0],
+         'upper_bounds': [1.8, 1.0], 'tolerance': [0.05, 0.05, 0.05, 0.05], 'strict': True}]),
+    dict(name='cartpole_symmetric', quad_type='cartpole', specs=[
+        {'constraint_form': 'symmetric_state_constraint', 'constrained_variable': 'state', 'active_dims': [0, 2], 'bound': [1.0, 0.2],
+         'tolerance': [0.1, 0.02]}]),
+]
+
+
+def constraint_env(case):
+    qt = case['quad_type']
+    if qt == 'cartpole':
+        nx, nu = 4, 1
+        ss = Holder(low=np.array([-4.8, -F32MAX, -math.pi, -F32MAX], dtype=np.float32),
+                    high=np.array([4.8, F32MAX, math.pi, F32MAX], dtype=np.float32), shape=(4,))
+        asp = Holder(low=np.array([-10.0], dtype=np.float32), high=np.array([10.0], dtype=np.float32), shape=(1,))
+        name = 'cartpole'
+    else:
+        nx, nu = {1: (2, 1), 2: (6, 2), 3: (12, 4)}[qt]
+        ss, asp, name = spaces(qt), action_space(qt), 'quadrotor'
+    return Holder(state_dim=nx, action_dim=nu, state_space=ss, observation_space=ss, action_space=asp, NAME=name, COST='rl_reward',
+                  state=np.zeros(nx), current_raw_input_action=np.zeros(nu))
+
+
+def sample_states(rng, env, count):
+    nx, nu = env.state_dim, env.action_dim
+    lo = np.where(env.state_space.low < -1e30, -3.0, env.state_space.low).astype(float)
+    hi = np.where(env.state_space.high > 1e30, 3.0, env.state_space.high).astype(float)
+    xs = rng.uniform(lo - 0.4 * (hi - lo), hi + 0.4 * (hi - lo), size=(count, nx))
+    xs[0] = 0.0
+    al, ah = env.action_space.low.astype(float), env.action_space.high.astype(float)
+    us = rng.uniform(al - 0.3 * (ah - al), ah + 0.3 * (ah - al), size=(count, nu))
+    return xs, us
+
+
+def gen_constraints(rng):
+    for c in CONSTRAINT_CASES:
+        env = constraint_env(c)
+        specs = deepcopy(c['specs'])
+        for s in specs:                                   # the yaml loader hands lists; the classes take them as they are
+            if s['constraint_form'] == 'symmetric_state_constraint':
+                s['bound'] = np.array(s['bound'], dtype=float)     # `-bound` in the constructor needs an array (constraints.py:393)
+        cl = NS['create_constraint_list'](specs, GENERAL_CONSTRAINTS(), env)
+        xs, us = sample_states(rng, env, 24)
+        vals, vals_state, viol, almost, per_viol = [], [], [], [], []
+        for x, u in zip(xs, us):
+            env.state, env.current_raw_input_action = x.copy(), u.copy()
+            v = cl.get_values(env)
+            vals.append(v)
+            viol.append(cl.is_violated(env, c_value=v))
+            almost.append(cl.is_almost_active(env, c_value=v))
+            per_viol.append(cl.get_violations(env))
+            if cl.state_constraints:
+                vals_state.append(cl.get_values(env, only_state=True))
+        key = 'constraints/%s/' % c['name']
+        put(key + 'state', xs)
+        put(key + 'action', us)
+        put(key + 'values', vals)
+        put(key + 'violated', viol)
+        put(key + 'almost_active', almost)
+        put(key + 'violations_per_constraint', per_viol)
+        if vals_state:
+            put(key + 'values_only_state', vals_state)
+        put(key + 'num_constraints', [cl.num_constraints])
+    MANIFEST['groups']['constraints'] = dict(cases=CONSTRAINT_CASES,
+                                             note='values = ConstraintList.get_values(env) (rounded to 8 decimals by the reference, '
+                                                  'constraints.py:119); violated / almost_active evaluated on those values')
+
+
+# ---- step glue -------------------------------------------------------------------------------------------------------
+GLUE_CASES = [
+    dict(name='q3_track_rl', quad_type=3, task='traj_tracking', cost='rl_reward', obs_goal_horizon=2),
+    dict(name='q3_stab_rl_con_penalty', quad_type=3, task='stabilization', cost='rl_reward', obs_goal_horizon=1,
+         task_info={'stabilization_goal': [0.2, -0.1, 1.0]}, constraints='competition_3d', use_constraint_penalty=True,
+         constraint_penalty=-2.5, rew_exponential=False, rew_state_weight=[1, 0.1, 1, 0.1, 2, 0.1, 0.5, 0.5, 0.5, 0.01, 0.01, 0.01],
+         rew_act_weight=0.3),
+    dict(name='q2_stab_quadratic_done', quad_type=2, task='stabilization', cost='quadratic'),
+    dict(name='q2_track_rl_norm_act_done_on_violation', quad_type=2, task='traj_tracking', cost='rl_reward',
+         normalized_rl_action_space=True, constraints='bench_c3', done_on_violation=True, obs_goal_horizon=0),
+    dict(name='q1_stab_rl', quad_type=1, task='stabilization', cost='rl_reward', obs_goal_horizon=1, done_on_out_of_bound=False),
+    dict(name='q1_track_rl_bounded_tol', quad_type=1, task='traj_tracking', cost='rl_reward', constraints='bounded_1d_tol',
+         use_constraint_penalty=True, constraint_penalty=-1.0),
+]
+
+
+def glue_env(c):
+    qt = c['quad_type']
+    gh = goal_holder(dict(quad_type=qt, task=c['task'], ctrl_freq=60, episode_len_sec=5, task_info=c.get('task_info', {})))
+    nx, nu = gh.state_dim, gh.action_dim
+    norm = c.get('normalized_rl_action_space', False)
+    mse_w = {1: [1, 0], 2: [1, 0, 1, 0, 0, 0], 3: [1, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0]}[qt]
+    h = Holder(QUAD_TYPE=gh.QUAD_TYPE, TASK=gh.TASK, COST=NS['Cost'](c['cost']), TASK_INFO=gh.TASK_INFO, X_GOAL=gh.X_GOAL, U_GOAL=gh.U_GOAL,
+               state_dim=nx, action_dim=nu, state_space=spaces(qt), observation_space=spaces(qt), action_space=action_space(qt, norm),
+               NAME='quadrotor', NORMALIZED_RL_ACTION_SPACE=norm, norm_act_scale=0.1, hover_thrust=CF['GRAVITY_ACC'] * CF['MASS'] / nu,
+               VERBOSE=False, disturbances={}, adversary_disturbance=None, initial_reset=True,
+               obs_goal_horizon=c.get('obs_goal_horizon', 0),
+               rew_state_weight=np.array(c.get('rew_state_weight', 1.0), ndmin=1, dtype=float),
+               rew_act_weight=np.array(c.get('rew_act_weight', 0.0001), ndmin=1, dtype=float),
+               rew_exponential=c.get('rew_exponential', True), done_on_out_of_bound=c.get('done_on_out_of_bound', True),
+               info_mse_metric_state_weight=np.array(mse_w, ndmin=1, dtype=float),
+               DONE_ON_COLLISION=False, DONE_ON_COMPLETION=False, currently_collided=False, task_completed=False,
+               DONE_ON_VIOLATION=c.get('done_on_violation', False), use_constraint_penalty=c.get('use_constraint_penalty', False),
+               constraint_penalty=c.get('constraint_penalty', -1), PYB_STEPS_PER_CTRL=4, CTRL_STEPS=300, CTRL_FREQ=60,
+               constraints=None, goal_reached=False, **{k: CF[k] for k in ('PWM2RPM_SCALE', 'PWM2RPM_CONST', 'KF', 'MIN_PWM', 'MAX_PWM')})
+    bind(h, NS, ['before_step', '_check_initial_reset', '_preprocess_control', 'extend_obs', 'after_step', '_get_reward', '_get_done',
+                 'info_mse_part'])
+    if c.get('constraints'):
+        spec = [cc for cc in CONSTRAINT_CASES if cc['name'] == c['constraints']][0]
+        h.constraints = NS['create_constraint_list'](deepcopy(spec['specs']), GENERAL_CONSTRAINTS(), h)
+    return h
+
+
+def gen_step_glue(rng):
+    for c in GLUE_CASES:
+        h = glue_env(c)
+        nx, nu = h.state_dim, h.action_dim
+        rec = {k: [] for k in ('state', 'action', 'counter', 'rpm', 'clipped', 'obs', 'mse', 'done_raw', 'goal_reached', 'rew_raw', 'rew',
+                               'done', 'violation', 'truncated', 'cvals')}
+        tracking = h.TASK == NS['Task'].TRAJ_TRACKING
+        for k in range(40):
+            counter = int(rng.choice([0, 1, 7, 150, 298, 299])) if k % 4 else int(rng.integers(0, 299))
+            goal = h.X_GOAL[min(counter, h.X_GOAL.shape[0] - 1)] if tracking else h.X_GOAL
+            spread = [0.02, 0.3, 2.0, 6.0][k % 4]                  # near the goal ... far out of bounds
+            x = goal + spread * rng.normal(size=nx)
+            al, ah = h.action_space.low.astype(float), h.action_space.high.astype(float)
+            a = rng.uniform(al - 0.4 * (ah - al), ah + 0.4 * (ah - al))
+            # ---- the reference's step() order (quadrotor.py:507-558) with the state advance replaced by "state := x"
+            h.ctrl_step_counter, h.pyb_step_counter = counter, 4 * counter
+            rpm = h.before_step(a.copy())                          # -> _preprocess_control
+            h.state = x.copy()                                     # stands for _advance_simulation + _get_observation's self.state
+            obs = h.extend_obs(deepcopy(h.state), h.ctrl_step_counter + 1)          # quadrotor.py:883
+            info = h.info_mse_part()                               # the statements of _get_info up to info["mse"]
+            done = h._get_done()
+            goal_reached = bool(getattr(h, 'goal_reached', False))
+            rew = h._get_reward() if h.COST == NS['Cost'].RL_REWARD else float('nan')     # quadratic cost: CasADi (unpinned)
+            rew_in = rew if rew == rew else 0.0
+            obs2, rew2, done2, info2 = h.after_step(obs, rew_in, done, dict(info))
+            rec['state'].append(x); rec['action'].append(a); rec['counter'].append(counter); rec['rpm'].append(rpm)
+            rec['clipped'].append(np.asarray(h.current_preprocessed_action, dtype=float)); rec['obs'].append(obs2)
+            rec['mse'].append(info['mse']); rec['done_raw'].append(done); rec['goal_reached'].append(goal_reached)
+            rec['rew_raw'].append(rew); rec['rew'].append(rew2 if rew == rew else float('nan')); rec['done'].append(done2)
+            rec['violation'].append(info2.get('constraint_violation', -1))
+            rec['truncated'].append({True: 1, False: 0}.get(info2.get('TimeLimit.truncated'), -1))
+            rec['cvals'].append(info2.get('constraint_values', np.zeros(0)))
+        for k, v in rec.items():
+            put('step_glue/%s/%s' % (c['name'], k), v)
+    MANIFEST['groups']['step_glue'] = dict(
+        cases=GLUE_CASES,
+        note='per sample: before_step(action) -> rpm and current_preprocessed_action (clipped); state := the given state (standing for '
+             'the PyBullet advance); obs = extend_obs(state, counter + 1); mse = the statements of _get_info up to info["mse"]; '
+             'done_raw = _get_done(); rew_raw = _get_reward() (rl_reward only: the quadratic cost calls CasADi, NaN here); then '
+             'after_step(obs, rew, done, info) -> rew, done, constraint_values / violation (-1: no constraints), '
+             'TimeLimit.truncated (-1: key absent).  counter = ctrl_step_counter before after_step increments it.')
+
+
+# ---- GAE and normalisers ---------------------------------------------------------------------------------------------
+def gen_gae(rng):
+    cases = []
+    for k, (T, N, use_gae, with_term) in enumerate([(8, 5, True, True), (8, 5, False, True), (16, 3, True, False), (1, 4, True, True),
+                                                    (33, 7, True, True)]):
+        rews = rng.normal(size=(T, N, 1))
+        vals = rng.normal(size=(T, N, 1))
+        masks = (rng.uniform(size=(T, N, 1)) > 0.2).astype(float)
+        last_val = rng.normal(size=(N, 1))
+        term = (rng.normal(size=(T, N, 1)) * (masks == 0)) if with_term else 0
+        gamma, lam = 0.97 + 0.005 * k, 0.9 + 0.01 * k
+        rews_in = rews.copy()
+        rets, advs = NS['compute_returns_and_advantages'](rews_in, vals.copy(), masks.copy(), deepcopy(term), last_val.copy(), gamma=gamma,
+                                                           use_gae=use_gae, gae_lambda=lam)
+        key = 'gae/%d/' % k
+        put(key + 'rews', rews); put(key + 'vals', vals); put(key + 'masks', masks); put(key + 'last_val', last_val)
+        put(key + 'terminal_vals', term if with_term else np.zeros((T, N, 1)))
+        put(key + 'rews_after', rews_in)                      # the reference updates rews in place (:443)
+        put(key + 'rets', rets); put(key + 'advs', advs)
+        cases.append(dict(T=T, N=N, use_gae=use_gae, with_terminal_vals=with_term, gamma=gamma, gae_lambda=lam))
+    MANIFEST['groups']['gae'] = dict(cases=cases)
+
+
+def gen_normalization(rng):
+    rms = NS['RunningMeanStd'](shape=(5,))
+    batches, means, variances, counts = [], [], [], []
+    for k, n in enumerate([7, 1, 64, 1000, 3]):
+        arr = rng.normal(loc=rng.normal(size=5) * 3, scale=rng.uniform(0.1, 4.0, size=5), size=(n, 5))
+        rms.update(arr)
+        put('normalization/rms/batch%d' % k, arr)
+        means.append(rms.mean.copy()); variances.append(rms.var.copy()); counts.append(rms.count)
+    put('normalization/rms/mean', means); put('normalization/rms/var', variances); put('normalization/rms/count', counts)
+    # MeanStdNormalizer.__call__ (:125-133): update + normalise + clip, then read_only
+    msn = NS['MeanStdNormalizer'](shape=(4,), clip=2.5)
+    outs = []
+    for k in range(4):
+        x = rng.normal(size=(50, 4)) * [1.0, 10.0, 0.1, 3.0] + [0.0, 5.0, -2.0, 1.0]
+        if k == 3:
+            msn.set_read_only()
+        put('normalization/msn/x%d' % k, x)
+        put('normalization/msn/y%d' % k, msn(x.copy()))
+    put('normalization/msn/mean', msn.rms.mean); put('normalization/msn/var', msn.rms.var)
+    # RewardStdNormalizer.__call__ (:172-189) incl. its literal  self.ret[dones.astype(np.long)] = 0
+    rsn = NS['RewardStdNormalizer'](gamma=0.95, clip=5.0)
+    for k in range(6):
+        r = rng.normal(size=12) * 2.0
+        d = rng.uniform(size=12) < 0.25
+        put('normalization/rsn/r%d' % k, r); put('normalization/rsn/d%d' % k, d)
+        put('normalization/rsn/out%d' % k, rsn(r.copy(), d.copy()))
+        put('normalization/rsn/ret%d' % k, rsn.ret.copy())
+    put('normalization/rsn/var', [rsn.rms.var])
+    MANIFEST['groups']['normalization'] = dict(note='rms: RunningMeanStd.update over 5 batches (state after each); msn: '
+                                                    'MeanStdNormalizer(shape=(4,), clip=2.5), 4 calls, read_only on the last; rsn: '
+                                                    'RewardStdNormalizer(gamma=0.95, clip=5.0), 6 calls (legacy index reset semantics)')
+
+
+def main():
+    rng = np.random.default_rng(20241004)
+    gen_motor_map(rng)
+    gen_trajectory()
+    gen_transform(rng)
+    gen_x_goal()
+    gen_constraints(rng)
+    gen_step_glue(rng)
+    gen_gae(rng)
+    gen_normalization(rng)
+    OUT['manifest'] = np.array(json.dumps(MANIFEST))
+    np.savez_compressed(os.path.join(HERE, 'reference_numpy.npz'), **OUT)
+    print('wrote %d arrays, %d reference symbols executed' % (len(OUT) - 1, len(SOURCES)))
+    for f, s, a, b in SOURCES:
+        print('  safe_control_gym/%s:%d-%d  %s' % (f, a, b, s))
+
+
+if __name__ == '__main__':
+    main()

@@ -114,7 +114,7 @@ def test_normalizers_on_the_env_buffers_zero_copy_and_at_scale(gpu):
     from safe_control_gym_amd.math_and_models.normalization import MeanStdNormalizer, RewardStdNormalizer
     n = 1 << 20
     env = scg.make('quadrotor', quad_type=3, num_envs=n, device='cuda', seed=5, randomized_init=True,
-                   task='traj_tracking', cost='quadratic')
+                   task='traj_tracking', cost='quadratic', copy_outputs=False)      # views of the engine's planes
     obs_norm, rew_norm = MeanStdNormalizer(shape=(12,)), RewardStdNormalizer(gamma=0.99)
     obs = env.reset()
     assert obs.stride(0) == 1                                     # SoA view: taken without a copy

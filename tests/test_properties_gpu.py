@@ -383,3 +383,142 @@ def test_two_queue_rollout_is_bit_identical_to_the_step_loop(gpu, tier):
         assert torch.equal(x, y), (tier, key)
     assert int(a.ctrl_step_counter.max()) < 15           # episodes of 15 steps: every env was reset at least once
     a.close(), b.close()
+
+
+def test_reference_push_after_step_protocol_keeps_the_previous_observation(gpu):
+    """The reference's rollout loop (controllers/ppo/ppo.py:259-276) steps the env and runs the observation normaliser
+    BEFORE it pushes the previous ``obs`` into the buffer.  With a plain ``make()`` env (copy_outputs defaults to True
+    with info_level='full') and the normaliser's fresh-tensor default that order stores obs[t] under obs[t], not
+    obs[t+1]; the zero-copy views of copy_outputs=False / ``out=`` are an opt-in that really alias."""
+    from safe_control_gym_amd.math_and_models.normalization import MeanStdNormalizer
+    n, T = 4096, 6
+    env = scg.make('quadrotor', quad_type=2, num_envs=n, device='cuda', seed=3, randomized_init=True)
+    norm = MeanStdNormalizer(shape=(env.obs_dim,))
+    g = torch.Generator(device='cuda'); g.manual_seed(0)
+    lo, hi = float(env.action_space.low[0]), float(env.action_space.high[0])
+    stored, truth = [], []
+    raw = env.reset()
+    obs = norm(raw)
+    for t in range(T):
+        truth.append(obs.clone())                                   # what obs[t] really is, copied at time t
+        act = torch.rand((n, 2), generator=g, device='cuda') * (hi - lo) + lo
+        next_raw, rew, done, info = env.step(act)
+        next_obs = norm(next_raw)
+        stored.append(obs)                                          # push AFTER step + normaliser, as ppo.py does (no clone)
+        obs = next_obs
+    torch.cuda.synchronize()
+    for t in range(T):
+        assert torch.equal(stored[t], truth[t]), t
+        if t + 1 < T:
+            assert not torch.equal(stored[t], stored[t + 1])
+    assert raw.data_ptr() != env._bufs['state'].data_ptr()          # reset() handed out a fresh tensor as well
+    env.close()
+    # the opt-ins alias, as documented
+    env = scg.make('quadrotor', quad_type=2, num_envs=n, device='cuda', seed=3, randomized_init=True, copy_outputs=False)
+    o0 = env.reset()
+    act = torch.rand((n, 2), generator=g, device='cuda') * (hi - lo) + lo
+    o1 = env.step(act)[0]
+    assert o0.data_ptr() == o1.data_ptr() == env._bufs['state'].data_ptr() and torch.equal(o0, o1)
+    out = torch.empty((env.obs_dim, (n + 63) // 64 * 64), dtype=torch.float32, device='cuda')
+    y0 = norm(o1, out=out)
+    y1 = norm(env.step(act)[0], out=out)
+    assert y0.data_ptr() == y1.data_ptr() == out.data_ptr()
+    assert scg.make('quadrotor', quad_type=2, num_envs=8, device='cuda', info_level='minimal').COPY_OUTPUTS is False
+    env.close()
+
+
+def test_reseed_on_reset_repeats_the_draws_and_keeps_the_handle(gpu):
+    """benchmark_env.py:356-362: with reseed_on_reset every reset() re-seeds first, so consecutive resets return the SAME
+    randomised initial states (and the disturbance streams restart); without it they differ.  The Philox key is unchanged,
+    so the scg_handle is kept (no hipFree / hipMalloc of the tables per reset)."""
+    n = 3000
+    kw = dict(quad_type=3, num_envs=n, device='cuda', seed=11, randomized_init=True, randomized_inertial_prop=True,
+              task='traj_tracking', disturbances={'observation': [{'disturbance_func': 'white_noise', 'std': 0.01}]})
+    env = scg.make('quadrotor', reseed_on_reset=True, **kw)
+    a = env.reset().clone()
+    pa = env.inertial_properties.clone()
+    handle = env._engine
+    act = torch.zeros((n, 4), device='cuda') + float(env.action_space.low[0])
+    s1 = [tuple(t.clone() for t in env.step(act)[:3]) for _ in range(3)]
+    b = env.reset().clone()
+    assert env._engine is handle and env._engine.handle
+    assert torch.equal(a, b) and torch.equal(pa, env.inertial_properties)
+    s2 = [tuple(t.clone() for t in env.step(act)[:3]) for _ in range(3)]
+    for (o1, r1, d1), (o2, r2, d2) in zip(s1, s2):                  # the in-kernel noise streams restart with the reset
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+    env.close()
+    env = scg.make('quadrotor', **kw)
+    a = env.reset().clone()
+    b = env.reset().clone()
+    assert not torch.equal(a, b)
+    env.seed(11)                                                    # an explicit re-seed rewinds the stream too
+    assert torch.equal(env.reset(), a)
+    env.close()
+
+
+def test_checkpoint_carries_the_separate_observation_buffer(gpu):
+    """An env whose observation is a buffer of its own (goal horizon + observation noise) exposes the SAME observation
+    after load_state_dict as the env the snapshot was taken from, before any further step."""
+    n = 777
+    kw = dict(quad_type=2, num_envs=n, device='cuda', seed=2, task='traj_tracking', cost='rl_reward', obs_goal_horizon=2,
+              randomized_init=True, disturbances={'observation': [{'disturbance_func': 'white_noise', 'std': 0.05}]})
+    a = scg.make('quadrotor', **kw)
+    a.reset()
+    act = torch.zeros((n, 2), device='cuda') + float(a.action_space.high[0])
+    for _ in range(7):
+        obs_a = a.step(act)[0]
+    b = scg.make('quadrotor', **kw)
+    b.load_state_dict(a.state_dict())
+    assert 'obs' in a.state_dict()['planes']
+    assert torch.equal(b._obs_view(), obs_a) and not torch.equal(b._obs_view()[:, :6], b.state)   # noise is in obs only
+    oa, ob = a.step(act)[0], b.step(act)[0]
+    assert torch.equal(oa, ob)
+    a.close(), b.close()
+
+
+def test_two_handles_in_one_process_may_differ_in_launch_policy(gpu):
+    """The launch policy is per handle (scg_config.rollout_queues / ref_in_lds / grid_cap_per_cu), not per process: three
+    envs with different policies coexist and produce bit-identical buffers."""
+    n = 300001
+    kw = dict(quad_type=3, num_envs=n, device='cuda', seed=5, randomized_init=True, task='traj_tracking', cost='quadratic',
+              episode_len_sec=0.25, info_level='minimal')
+    envs = [scg.make('quadrotor', **kw), scg.make('quadrotor', rollout_queues=1, **kw),
+            scg.make('quadrotor', rollout_queues=2, rollout_split_min=1024, ref_in_lds=1, **kw),
+            scg.make('quadrotor', rollout_queues=1, grid_cap_per_cu=2, **kw)]
+    g = torch.Generator(device='cuda'); g.manual_seed(8)
+    lo, hi = float(envs[0].action_space.low[0]), float(envs[0].action_space.high[0])
+    acts = torch.rand((5, 4, envs[0].plane_stride), generator=g, device='cuda') * (hi - lo) + lo
+    for e in envs:
+        e.reset()
+        e.rollout(acts, steps=17)
+    torch.cuda.synchronize()
+    assert envs[2]._engine.kernel_info(n)['lds_bytes'] > envs[0]._engine.kernel_info(n)['lds_bytes']
+    assert envs[3]._engine.kernel_info(n)['grid'] < envs[0]._engine.kernel_info(n)['grid']
+    for e in envs[1:]:
+        for key in ('state', 'step_count', 'reward', 'done', 'ep_return'):
+            assert torch.equal(envs[0]._bufs[key], e._bufs[key]), key
+    for e in envs:
+        e.close()
+
+
+def test_all_gather_of_episode_returns_through_rccl(gpu):
+    """The nccl (= RCCL) branch of parallel.all_gather_episode_returns on this one-GPU box: a world of one rank, the
+    collective forced (a one-rank world otherwise returns a copy without touching the backend)."""
+    import torch.distributed as dist
+    from safe_control_gym_amd import parallel
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    import tempfile
+    with tempfile.NamedTemporaryFile() as f:
+        dist.init_process_group(backend='nccl', init_method='file://' + f.name + '.store', rank=0, world_size=1)
+        try:
+            assert dist.get_backend() == 'nccl'
+            x = torch.arange(1000, dtype=torch.float32, device='cuda') * 0.25
+            y = parallel.all_gather_episode_returns(x, total_envs=1000, force_collective=True)
+            z = parallel.all_gather_episode_returns(x, force_collective=True)      # sizes discovered by a collective
+            ones = torch.ones(1, device='cuda')
+            dist.all_reduce(ones)
+            torch.cuda.synchronize()
+            assert torch.equal(x, y) and torch.equal(x, z) and y.data_ptr() != x.data_ptr() and int(ones.item()) == 1
+        finally:
+            dist.destroy_process_group()

@@ -1,0 +1,374 @@
+"""Pins to the reference's own output.
+
+``tests/golden/reference_numpy.npz`` was produced by EXECUTING the reference's NumPy-only code for the hot path (the functions,
+classes and statement runs listed in its manifest, extracted from /root/reference with ``ast`` and compiled unchanged:
+tests/golden/make_golden_reference_numpy.py).  CPU tests replay ``oracle/`` and the package's host logic against it; the
+``gpu`` tests replay the HIP path.  Nothing here reads /root/reference.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import rel_err
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = np.load(os.path.join(HERE, 'golden', 'reference_numpy.npz'))
+MANIFEST = json.loads(str(G['manifest']))
+GROUPS = MANIFEST['groups']
+CF = GROUPS['motor_map']['constants']
+TIGHT = 1e-12            # float64 restatement vs float64 reference output
+RTOL = 1e-5              # float32 device path vs float64 reference output (the north-star's tolerance)
+
+
+def test_manifest_lists_the_executed_reference_symbols():
+    syms = {(s['file'], s['symbol']) for s in MANIFEST['sources']}
+    for want in (('safe_control_gym/envs/gym_pybullet_drones/quadrotor_utils.py', 'cmd2pwm'),
+                 ('safe_control_gym/envs/benchmark_env.py', 'BenchmarkEnv._generate_trajectory'),
+                 ('safe_control_gym/math_and_models/transformations.py', 'transform_trajectory'),
+                 ('safe_control_gym/envs/constraints.py', 'ConstraintList'),
+                 ('safe_control_gym/controllers/ppo/ppo_utils.py', 'compute_returns_and_advantages'),
+                 ('safe_control_gym/math_and_models/normalization.py', 'RunningMeanStd'),
+                 ('safe_control_gym/envs/benchmark_env.py', 'BenchmarkEnv.after_step'),
+                 ('safe_control_gym/envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor._get_done')):
+        assert want in syms
+    assert all(s['lines'][0] <= s['lines'][1] for s in MANIFEST['sources'])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU: the oracle (and the package's host-side tables) against the reference's output
+# ---------------------------------------------------------------------------------------------------------------------
+def _effective_thrust(rpm, nu):
+    """Per-actuator thrust from the reference's 4 motor speeds: KF rpm^2 per motor (base_aviary.py:420); 1-D: all four
+    motors, 2-D: T1 = motors 1 & 4, T2 = motors 2 & 3 (quadrotor_utils.py:24-25,43-44), 3-D: one motor each."""
+    f = CF['KF'] * rpm ** 2
+    if nu == 1:
+        return f.sum(axis=-1, keepdims=True)
+    if nu == 2:
+        return np.stack([f[..., 0] + f[..., 3], f[..., 1] + f[..., 2]], axis=-1)
+    return f
+
+
+@pytest.mark.parametrize('nu', [1, 2, 4])
+def test_oracle_motor_map_matches_reference_cmd2pwm_pwm2rpm(nu):
+    from oracle import ref_model as rm
+    thrust, rpm = G['motor_map/nu%d/thrust' % nu], G['motor_map/nu%d/rpm' % nu]
+    want = _effective_thrust(rpm, nu)
+    got = np.array([rm.motor_map(list(t), rm.QuadParams()) for t in thrust])
+    assert rel_err(got, want) <= TIGHT
+    # the action bounds of quadrotor.py:726-733 are this map's fixed points at PWM_min / PWM_max
+    lo, hi = rm.action_bounds(nu)
+    n_motor = 4 // nu
+    assert abs(lo - n_motor * CF['KF'] * (CF['PWM2RPM_SCALE'] * CF['MIN_PWM'] + CF['PWM2RPM_CONST']) ** 2) <= 1e-7 * lo
+    assert abs(hi - n_motor * CF['KF'] * (CF['PWM2RPM_SCALE'] * CF['MAX_PWM'] + CF['PWM2RPM_CONST']) ** 2) <= 1e-7 * hi
+
+
+@pytest.mark.parametrize('k', range(len(GROUPS['trajectory']['cases'])))
+def test_trajectory_generators_match_reference(k):
+    from oracle.ref_trajectory import generate_trajectory
+    from safe_control_gym_amd.envs.benchmark_env import BenchmarkEnv
+    c = GROUPS['trajectory']['cases'][k]
+    for gen in (generate_trajectory, lambda **kw: BenchmarkEnv._generate_trajectory(None, **kw)):
+        pos, vel, speed = gen(**dict(c, position_offset=np.array(c['position_offset'], dtype=float)))
+        for got, name in ((pos, 'pos'), (vel, 'vel'), (speed, 'speed')):
+            want = G['trajectory/%d/%s' % (k, name)]
+            assert got.shape == want.shape
+            assert np.max(np.abs(got - want)) <= 1e-13 * max(1.0, np.max(np.abs(want))), (k, name)
+
+
+@pytest.mark.parametrize('k', range(len(GROUPS['transform']['cases'])))
+def test_projection_and_trajectory_transform_match_reference(k):
+    from oracle import ref_trajectory as rt
+    from safe_control_gym_amd.math_and_models import transformations as tf
+    c = GROUPS['transform']['cases'][k]
+    pos, vel = G['transform/%d/pos' % k], G['transform/%d/vel' % k]
+    assert np.max(np.abs(rt.projection_matrix(c['point'], c['normal']) - G['transform/%d/M' % k])) <= 1e-14
+    tp, tv = rt.transform_trajectory(pos, vel, c['point'], c['normal'])
+    assert np.max(np.abs(tp - G['transform/%d/trans_pos' % k])) <= 1e-13
+    assert np.max(np.abs(tv - G['transform/%d/trans_vel' % k])) <= 1e-13
+    assert np.max(np.abs(tf.projection_matrix(c['point'], c['normal']) - G['transform/%d/M' % k])) <= 1e-14
+    tp2, tv2 = tf.transform_trajectory(pos, vel, trans_info={'point': c['point'], 'normal': c['normal']})
+    assert np.max(np.abs(tp2 - G['transform/%d/trans_pos' % k])) <= 1e-13
+    assert np.max(np.abs(tv2 - G['transform/%d/trans_vel' % k])) <= 1e-13       # incl. the plane offset added to velocities
+
+
+@pytest.mark.parametrize('k', range(len(GROUPS['x_goal']['cases'])))
+def test_x_goal_tables_match_reference(k):
+    """The X_GOAL / U_GOAL statements of Quadrotor.__init__ (quadrotor.py:261-325) run on the reference's own trajectory
+    code: the oracle's table and the table the package uploads to the device both reproduce them."""
+    import safe_control_gym_amd as scg
+    from oracle.ref_env import RefEnv
+    c = GROUPS['x_goal']['cases'][k]
+    ti = dict(GROUPS['x_goal']['default_task_info'])
+    ti.update(c['task_info'])
+    kw = dict(task=c['task'], task_info=ti, ctrl_freq=c['ctrl_freq'], pyb_freq=c['ctrl_freq'], episode_len_sec=c['episode_len_sec'])
+    want, u_want = G['x_goal/%d/X_GOAL' % k], G['x_goal/%d/U_GOAL' % k]
+    ref = RefEnv(system=c['quad_type'], **kw)
+    env = scg.make('quadrotor', quad_type=c['quad_type'], num_envs=1, **kw)
+    for got_x, got_u in ((ref.X_GOAL, ref.U_GOAL), (np.asarray(env.X_GOAL), np.asarray(env.U_GOAL))):
+        assert got_x.shape == want.shape
+        assert np.max(np.abs(got_x - want)) <= 1e-13 and np.max(np.abs(got_u - u_want)) <= 1e-15
+
+
+def _constraint_case(name):
+    return [c for c in GROUPS['constraints']['cases'] if c['name'] == name][0]
+
+
+@pytest.mark.parametrize('name', [c['name'] for c in GROUPS['constraints']['cases']])
+def test_oracle_constraints_match_reference_classes(name):
+    """get_values / is_violated / is_almost_active / only_state values of the reference's own Constraint classes
+    (constraints.py:21-612, executed) on 24 (state, raw action) samples per specification."""
+    from oracle.ref_constraints import create_ref_constraint_list
+    from oracle.ref_env import RefEnv
+    c = _constraint_case(name)
+    system = c['quad_type']
+    env = RefEnv(system=system, cost='rl_reward', task='traj_tracking')     # (3-D stabilisation needs a 3-element goal)
+    cl = create_ref_constraint_list(c['specs'], env)
+    key = 'constraints/%s/' % name
+    assert cl.num_constraints == int(G[key + 'num_constraints'][0])
+    for i, (x, u) in enumerate(zip(G[key + 'state'], G[key + 'action'])):
+        env.state, env.current_raw_input_action = x.copy(), u.copy()
+        v = cl.get_values(env)
+        assert np.max(np.abs(v - G[key + 'values'][i])) <= 1e-8, (name, i)      # the reference rounds to 8 decimals (:119)
+        assert bool(cl.is_violated(env, c_value=v)) == bool(G[key + 'violated'][i])
+        assert bool(cl.is_almost_active(env, c_value=v)) == bool(G[key + 'almost_active'][i])
+        if key + 'values_only_state' in G.files:
+            assert np.max(np.abs(cl.get_values(env, only_state=True) - G[key + 'values_only_state'][i])) <= 1e-8
+
+
+def _glue_ref_env(c):
+    from oracle.ref_env import RefEnv
+    kw = dict(task=c['task'], cost=c['cost'], ctrl_freq=60, pyb_freq=240, episode_len_sec=5,
+              obs_goal_horizon=c.get('obs_goal_horizon', 0), normalized_rl_action_space=c.get('normalized_rl_action_space', False),
+              rew_state_weight=c.get('rew_state_weight', 1.0), rew_act_weight=c.get('rew_act_weight', 0.0001),
+              rew_exponential=c.get('rew_exponential', True), done_on_out_of_bound=c.get('done_on_out_of_bound', True),
+              done_on_violation=c.get('done_on_violation', False), use_constraint_penalty=c.get('use_constraint_penalty', False),
+              constraint_penalty=c.get('constraint_penalty', -1))
+    ti = dict(GROUPS['x_goal']['default_task_info'])
+    ti.update(c.get('task_info', {}))
+    kw['task_info'] = ti
+    if c.get('constraints'):
+        kw['constraints'] = _constraint_case(c['constraints'])['specs']
+    return RefEnv(system=c['quad_type'], **kw), kw
+
+
+@pytest.mark.parametrize('name', [c['name'] for c in GROUPS['step_glue']['cases']])
+def test_oracle_step_glue_matches_reference_methods(name):
+    """Everything step() does around the state advance, executed from the reference's own methods (before_step,
+    _preprocess_control + cmd2pwm / pwm2rpm, extend_obs, the mse statements of _get_info, _get_done, _get_reward (rl),
+    after_step with its ConstraintList): the oracle's methods of the same names reproduce every recorded value."""
+    c = [g for g in GROUPS['step_glue']['cases'] if g['name'] == name][0]
+    ref, _ = _glue_ref_env(c)
+    ref.reset_sampler = lambda i, e: np.zeros(ref.nx)
+    ref.reset()
+    key = 'step_glue/%s/' % name
+    nu = ref.nu
+    for i in range(G[key + 'state'].shape[0]):
+        x, a, counter = G[key + 'state'][i], G[key + 'action'][i], int(G[key + 'counter'][i])
+        ref.ctrl_step_counter, ref.pyb_step_counter = counter, 4 * counter
+        thrust = np.array(ref.before_step(a.copy()))
+        assert rel_err(thrust, _effective_thrust(G[key + 'rpm'][i], nu)) <= TIGHT, i
+        assert rel_err(ref.current_preprocessed_action, G[key + 'clipped'][i]) <= TIGHT
+        ref.state = x.copy()
+        obs = ref._get_observation()
+        info = ref._get_info()
+        done = ref._get_done()
+        assert rel_err(info['mse'], G[key + 'mse'][i]) <= TIGHT
+        assert bool(done) == bool(G[key + 'done_raw'][i]), i
+        if c['cost'] == 'quadratic' and c['task'] == 'stabilization':
+            assert bool(ref.goal_reached) == bool(G[key + 'goal_reached'][i])
+        rew = ref._get_reward() if c['cost'] == 'rl_reward' else 0.0
+        if c['cost'] == 'rl_reward':
+            assert rel_err(rew, G[key + 'rew_raw'][i]) <= TIGHT, i
+        obs2, rew2, done2, info2 = ref.after_step(obs, rew, done, dict(info))
+        assert rel_err(obs2, G[key + 'obs'][i]) <= TIGHT
+        assert bool(done2) == bool(G[key + 'done'][i]), i
+        if c['cost'] == 'rl_reward':
+            assert rel_err(rew2, G[key + 'rew'][i]) <= TIGHT
+        assert info2.get('constraint_violation', -1) == int(G[key + 'violation'][i])
+        assert {True: 1, False: 0}.get(info2.get('TimeLimit.truncated'), -1) == int(G[key + 'truncated'][i])
+        if ref.constraints is not None:
+            assert np.max(np.abs(info2['constraint_values'] - G[key + 'cvals'][i])) <= 1e-8
+
+
+@pytest.mark.parametrize('k', range(len(GROUPS['gae']['cases'])))
+def test_oracle_gae_matches_reference_function(k):
+    from oracle.ref_ppo import compute_returns_and_advantages
+    c = GROUPS['gae']['cases'][k]
+    key = 'gae/%d/' % k
+    rews = G[key + 'rews'].copy()
+    term = G[key + 'terminal_vals'].copy() if c['with_terminal_vals'] else 0
+    rets, advs, rews_after = compute_returns_and_advantages(rews, G[key + 'vals'].copy(), G[key + 'masks'].copy(), term,
+                                                            G[key + 'last_val'].copy(), gamma=c['gamma'], use_gae=c['use_gae'],
+                                                            gae_lambda=c['gae_lambda'])
+    assert rel_err(rets, G[key + 'rets']) <= TIGHT and rel_err(advs, G[key + 'advs']) <= TIGHT
+    assert rel_err(rews_after, G[key + 'rews_after']) <= TIGHT                 # the reference's in-place  rews += gamma * terminal_vals
+
+
+def test_oracle_normalisers_match_reference_classes():
+    from oracle.ref_normalization import RunningMeanStd, MeanStdNormalizer, RewardStdNormalizer
+    rms = RunningMeanStd(shape=(5,))
+    for k in range(5):
+        rms.update(G['normalization/rms/batch%d' % k])
+        assert rel_err(rms.mean, G['normalization/rms/mean'][k]) <= TIGHT
+        assert rel_err(rms.var, G['normalization/rms/var'][k]) <= TIGHT
+        assert rel_err(rms.count, G['normalization/rms/count'][k]) <= TIGHT
+    msn = MeanStdNormalizer(shape=(4,), clip=2.5)
+    for k in range(4):
+        if k == 3:
+            msn.read_only = True
+        assert rel_err(msn(G['normalization/msn/x%d' % k].copy()), G['normalization/msn/y%d' % k]) <= TIGHT
+    rsn = RewardStdNormalizer(gamma=0.95, clip=5.0, legacy=True)               # the reference's literal index reset (:188)
+    for k in range(6):
+        out = rsn(G['normalization/rsn/r%d' % k].copy(), G['normalization/rsn/d%d' % k].astype(bool))
+        assert rel_err(out, G['normalization/rsn/out%d' % k]) <= TIGHT
+        assert rel_err(rsn.ret, G['normalization/rsn/ret%d' % k]) <= TIGHT
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GPU: the HIP path against the reference's output
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_device_motor_map_matches_reference(gpu):
+    """cmd2pwm -> pwm2rpm -> KF rpm^2 inside the step kernel: a 1-D quadrotor at rest accelerates with T_eff / m - g, and RK4
+    is exact for a constant acceleration, so the effective thrust can be read off one step: T_eff = m (dz_dot / dt + g)."""
+    import torch
+    import safe_control_gym_amd as scg
+    thrust, rpm = G['motor_map/nu1/thrust'], G['motor_map/nu1/rpm']
+    want = _effective_thrust(rpm, 1)[:, 0]
+    n = thrust.shape[0]
+    env = scg.make('quadrotor', quad_type=1, num_envs=n, device='cuda', randomized_init=False, done_on_out_of_bound=False,
+                   init_state=np.array([1.0, 0.0]), ctrl_freq=60, pyb_freq=240)
+    env.reset()
+    env.step(torch.as_tensor(thrust.astype(np.float32), device='cuda'))
+    zdot = env.state[:, 1].double().cpu().numpy()
+    t_eff = CF['MASS'] * (zdot * 60.0 + CF['GRAVITY_ACC'])
+    # the raw action is clipped to the action space before the map (quadrotor.py:830): compare on the clipped thrusts
+    lo, hi = float(env.action_space.low[0]), float(env.action_space.high[0])
+    clipped = np.clip(thrust[:, 0], lo, hi)
+    inside = (thrust[:, 0] >= lo) & (thrust[:, 0] <= hi)
+    assert inside.sum() >= 12
+    assert rel_err(t_eff[inside] / CF['MASS'], want[inside] / CF['MASS']) <= 3e-5      # accelerations (~10 m/s^2), fp32 velocity
+    assert rel_err(t_eff[~inside] / CF['MASS'], np.where(clipped[~inside] <= lo, lo, hi) / CF['MASS']) <= 3e-5
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('k', [0, 1, 3, 4])
+def test_device_goal_table_rows_match_reference(gpu, k):
+    """The table the kernel gathers from is the reference's X_GOAL: the goal-horizon part of the observation holds rows
+    min(t + 1 + i, T - 1) of it (benchmark_env.py:406-413), in float32."""
+    import torch
+    import safe_control_gym_amd as scg
+    c = GROUPS['x_goal']['cases'][k]
+    ti = dict(GROUPS['x_goal']['default_task_info'])
+    ti.update(c['task_info'])
+    want = G['x_goal/%d/X_GOAL' % k]
+    nx, h, n = want.shape[1], 3, 64
+    env = scg.make('quadrotor', quad_type=c['quad_type'], num_envs=n, device='cuda', task='traj_tracking', task_info=ti,
+                   cost='rl_reward', obs_goal_horizon=h, ctrl_freq=c['ctrl_freq'], pyb_freq=c['ctrl_freq'],
+                   episode_len_sec=c['episode_len_sec'], randomized_init=False, done_on_out_of_bound=False)
+    obs = env.reset()
+    T = want.shape[0]
+    hover = torch.as_tensor(np.tile(env.U_GOAL, (n, 1)).astype(np.float32), device='cuda')
+
+    def check(pre):          # an observation computed with ctrl_step_counter = pre holds rows min(pre + 1 + i, T - 1) (quadrotor.py:883)
+        rows = [min(pre + 1 + i, T - 1) for i in range(h)]
+        got = obs[0, nx:].double().cpu().numpy().reshape(h, nx)
+        assert np.array_equal(got, want[rows].astype(np.float32).astype(np.float64)), pre
+
+    check(0)                                         # reset(): counter 0
+    for pre in range(0, 15):
+        obs = env.step(hover)[0]
+        check(pre)                                   # step(): evaluated before after_step increments the counter
+    env.ctrl_step_counter.fill_(T - 7)               # jump near the end of the table: the lookup only reads the counter
+    for pre in range(T - 7, T):
+        obs = env.step(hover)[0]
+        check(pre if pre < T - 1 else 0)             # the step from T - 1 hits the time limit: the reset observation comes back
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', [c['name'] for c in GROUPS['constraints']['cases']])
+def test_device_constraint_rows_match_reference_classes(gpu, name):
+    """scg_eval_constraints (and the Python Constraint API over it) on the recorded (state, raw action) samples: values within
+    the float32 tolerance of the reference's, violated / almost-active flags equal wherever the value is not within
+    rounding of its threshold."""
+    import torch
+    import safe_control_gym_amd as scg
+    c = _constraint_case(name)
+    key = 'constraints/%s/' % name
+    xs, us = G[key + 'state'], G[key + 'action']
+    n = xs.shape[0]
+    if c['quad_type'] == 'cartpole':
+        env = scg.make('cartpole', num_envs=n, device='cuda', constraints=c['specs'], randomized_init=False)
+    else:
+        env = scg.make('quadrotor', quad_type=c['quad_type'], num_envs=n, device='cuda', constraints=c['specs'], randomized_init=False,
+                       task='traj_tracking')
+    env.reset()
+    env.state_soa.copy_(torch.as_tensor(xs.astype(np.float32).T, device='cuda'))
+    env._raw_action, env._raw_action_rows = torch.as_tensor(us.astype(np.float32), device='cuda').contiguous(), True
+    vals = env.constraints.get_values(env)
+    want = G[key + 'values']
+    got = vals.double().cpu().numpy()
+    # float32 inputs: compare with the reference evaluated on the float32-rounded samples' neighbourhood
+    scale = np.maximum(np.abs(want), 1.0) + np.abs(xs).max() + np.abs(us).max()
+    assert np.max(np.abs(got - want) / scale) <= RTOL, name
+    viol = env.constraints.is_violated(env, c_value=vals).cpu().numpy()
+    almost = env.constraints.is_almost_active(env, c_value=vals).cpu().numpy()
+    margin = np.min(np.abs(want), axis=1) > 1e-4          # samples whose flags cannot flip under fp32 rounding
+    assert np.array_equal(viol[margin], G[key + 'violated'][margin].astype(bool))
+    tol_margin = margin.copy()
+    for s in c['specs']:
+        if 'tolerance' in s:
+            tol_margin &= np.min(np.abs(want + np.max(np.abs(np.asarray(s['tolerance'], dtype=float)))), axis=1) > 1e-4
+    assert np.array_equal(almost[tol_margin], G[key + 'almost_active'][tol_margin].astype(bool))
+    if key + 'values_only_state' in G.files:
+        vs = env.constraints.get_values(env, only_state=True).double().cpu().numpy()
+        ws = G[key + 'values_only_state']
+        assert np.max(np.abs(vs - ws) / (np.maximum(np.abs(ws), 1.0) + np.abs(xs).max())) <= RTOL
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('k', range(len(GROUPS['gae']['cases'])))
+def test_device_gae_matches_reference_function(gpu, k):
+    import torch
+    from safe_control_gym_amd.controllers.ppo.ppo_utils import compute_returns_and_advantages
+    c = GROUPS['gae']['cases'][k]
+    key = 'gae/%d/' % k
+    dev = lambda a: torch.as_tensor(a.astype(np.float32), device='cuda')
+    rews = dev(G[key + 'rews'])
+    term = dev(G[key + 'terminal_vals']) if c['with_terminal_vals'] else 0
+    rets, advs = compute_returns_and_advantages(rews, dev(G[key + 'vals']), dev(G[key + 'masks']), term, dev(G[key + 'last_val']),
+                                                gamma=c['gamma'], use_gae=c['use_gae'], gae_lambda=c['gae_lambda'])
+    assert rel_err(rets.cpu().numpy(), G[key + 'rets']) <= RTOL and rel_err(advs.cpu().numpy(), G[key + 'advs']) <= RTOL
+    assert rel_err(rews.cpu().numpy(), G[key + 'rews_after']) <= RTOL
+
+
+@pytest.mark.gpu
+def test_device_normalisers_match_reference_classes(gpu):
+    import torch
+    from safe_control_gym_amd.math_and_models.normalization import MeanStdNormalizer, RewardStdNormalizer
+    msn = MeanStdNormalizer(shape=(4,), clip=2.5)
+    for k in range(4):
+        if k == 3:
+            msn.set_read_only()
+        y = msn(torch.as_tensor(G['normalization/msn/x%d' % k].astype(np.float32), device='cuda'))
+        assert rel_err(y.cpu().numpy(), G['normalization/msn/y%d' % k]) <= 4 * RTOL        # |y| <= 2.5, fp32 inputs
+    assert rel_err(msn.rms.mean.cpu().numpy(), G['normalization/msn/mean']) <= RTOL
+    assert rel_err(msn.rms.var.cpu().numpy(), G['normalization/msn/var']) <= RTOL
+    rsn = RewardStdNormalizer(gamma=0.95, clip=5.0, legacy_index_reset=True)
+    for k in range(6):
+        out = rsn(torch.as_tensor(G['normalization/rsn/r%d' % k].astype(np.float32), device='cuda'),
+                  torch.as_tensor(G['normalization/rsn/d%d' % k].astype(bool), device='cuda'))
+        assert rel_err(out.cpu().numpy(), G['normalization/rsn/out%d' % k]) <= 4 * RTOL
+        assert rel_err(rsn.ret.cpu().numpy(), G['normalization/rsn/ret%d' % k]) <= 4 * RTOL
+    # RunningMeanStd.update alone: 5 batches through the tracker of a wide normaliser
+    m5 = MeanStdNormalizer(shape=(5,), clip=1e9)
+    for k in range(5):
+        m5(torch.as_tensor(G['normalization/rms/batch%d' % k].astype(np.float32), device='cuda'))
+        assert rel_err(m5.rms.mean.cpu().numpy(), G['normalization/rms/mean'][k]) <= RTOL
+        assert rel_err(m5.rms.var.cpu().numpy(), G['normalization/rms/var'][k]) <= 4 * RTOL
+        assert abs(float(m5.rms.count) - G['normalization/rms/count'][k]) <= 1e-9 * G['normalization/rms/count'][k]

@@ -1,5 +1,4 @@
 #!/bin/bash
-# Full GPU suite, then the lean-tier parity tests again on the opt-in packed kernel.
+# Full GPU suite (one process).
 set -u
 python -m pytest tests -m gpu -q "$@" 2>&1 | tail -5
-SCG_PACKED=1 python -m pytest tests/test_parity_gpu.py -m gpu -q -k "lean_tier" 2>&1 | tail -3

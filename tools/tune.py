@@ -19,7 +19,7 @@ def run(lib, env_extra, steps, extra_args):
         env['SCG_ROLLOUT_LIB'] = lib
     env.update(env_extra)
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', str(steps), '--warmup', '100',
-                          '--no-cpu-baseline'] + extra_args, env=env, capture_output=True, text=True)
+                          '--no-cpu-baseline', '--no-sub-records'] + extra_args, env=env, capture_output=True, text=True)
     for line in out.stdout.splitlines():
         if line.startswith('{'):
             return json.loads(line)
