@@ -1,0 +1,261 @@
+// Driver of the CPU sanitizer build of the C-ABI validation layer (scg_capi.hip compiled as host C++ against the
+// stand-in HIP runtime of this directory, -fsanitize=address,undefined).  Exercises every argument check, the table
+// compilers (reference / constraints / disturbances) at their limits, and the two-queue rollout's error paths.
+// Exit code 0 = every expectation held and the sanitizers reported nothing.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "../../include/scg_rollout.h"
+#include "hip_host_shim.h"
+
+static int g_fail = 0;
+#define EXPECT(cond)                                                                                        \
+    do {                                                                                                    \
+        if (!(cond)) { std::fprintf(stderr, "EXPECT failed at %s:%d: %s   [%s]\n", __FILE__, __LINE__, #cond, scg_last_error()); ++g_fail; } \
+    } while (0)
+
+static scg_config base_config(int system) {
+    scg_config c;
+    std::memset(&c, 0, sizeof(c));
+    c.struct_size = sizeof(c);
+    c.abi_version = SCG_ABI_VERSION;
+    c.system = system;
+    c.integrator = SCG_RK4;
+    c.substeps = 1;
+    c.task = SCG_STABILIZATION;
+    c.cost = SCG_RL_REWARD;
+    c.ctrl_steps = 300;
+    c.dt = 1.0 / 60;
+    c.mass = 0.03454; c.gravity = 9.8; c.arm = 0.0397; c.ixx = 1.4e-5; c.iyy = 1.4e-5; c.izz = 2.17e-5; c.kf = 3.16e-10; c.km = 7.94e-12;
+    c.pwm2rpm_scale = 0.2685; c.pwm2rpm_const = 4070.3; c.pwm_min = 20000; c.pwm_max = 65535;
+    c.pole_length = 0.5; c.pole_mass = 0.1; c.cart_mass = 1.0;
+    c.motor_map = 1;
+    for (int j = 0; j < SCG_MAX_NU; ++j) { c.act_low[j] = 0.028; c.act_high[j] = 0.148; c.u_goal[j] = 0.0846; c.rew_act_weight[j] = 1e-4; }
+    for (int j = 0; j < SCG_MAX_NX; ++j) { c.rew_state_weight[j] = 1.0; c.oob_low[j] = (j & 1) ? -3.5e38 : -5.0; c.oob_high[j] = (j & 1) ? 3.5e38 : 5.0; c.init_rand_low[j] = -0.1; c.init_rand_high[j] = 0.1; }
+    for (int j = 0; j < SCG_MAX_NX; ++j) c.Q[j * SCG_MAX_NX + j] = 1.0;
+    for (int j = 0; j < SCG_MAX_NU; ++j) c.R[j * SCG_MAX_NU + j] = 1.0;
+    c.goal_tolerance = 0.05;
+    c.done_on_out_of_bound = 1;
+    c.randomized_init = 1;
+    c.auto_reset = 1;
+    c.seed = 1337;
+    return c;
+}
+
+static int dims_nx(int s) { return s == 1 ? 2 : s == 2 ? 6 : s == 3 ? 12 : 4; }
+static int dims_nu(int s) { return s == 1 ? 1 : s == 2 ? 2 : s == 3 ? 4 : 1; }
+
+// a step_io whose pointers are non-null host buffers (never dereferenced by the layer: it only validates and forwards)
+struct Buffers {
+    std::vector<float> f;
+    std::vector<int32_t> i;
+    std::vector<uint8_t> b;
+    scg_step_io io;
+    explicit Buffers(int64_t ld) : f(64), i(64), b(64) {
+        std::memset(&io, 0, sizeof(io));
+        io.struct_size = sizeof(io);
+        io.ld = ld;
+        io.action = f.data(); io.state = f.data(); io.step_count = i.data(); io.reward = f.data(); io.done = b.data();
+    }
+};
+
+static void check_create_validation() {
+    scg_handle* h = nullptr;
+    scg_config c = base_config(SCG_QUAD_3D);
+    EXPECT(scg_create(nullptr, &h) == SCG_ERR_INVALID);
+    EXPECT(scg_create(&c, nullptr) == SCG_ERR_INVALID);
+    { scg_config d = c; d.struct_size = 8; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = c; d.abi_version = SCG_ABI_VERSION - 1; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = c; d.system = 9; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = c; d.integrator = 5; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = c; d.task = 2; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = c; d.cost = 2; EXPECT(scg_create(&d, &h) == SCG_ERR_UNSUPPORTED); }
+    { scg_config d = c; d.substeps = 0; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = c; d.substeps = 65; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = c; d.dt = 0.0; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = c; d.ctrl_steps = 0; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = c; d.obs_goal_horizon = SCG_MAX_GOAL_HORIZON + 1; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = c; d.mass = 0.0; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = base_config(SCG_CARTPOLE); d.pole_mass = -1.0; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = c; d.rollout_queues = 3; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = c; d.rollout_split_min = -1; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = c; d.grid_cap_per_cu = -2; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = c; d.init_rand_kind[3] = 99; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = c; d.inertial_rand_kind[1] = -1; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = c; d.randomized_inertial = 1; d.inertial_rand_low[0] = -1.0; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    EXPECT(g_shim.live_allocations == 0);             // no failed create leaks its tables
+    EXPECT(scg_destroy(nullptr) == SCG_OK);
+    EXPECT(scg_version() == SCG_ABI_VERSION && scg_sizeof_config() == (int)sizeof(scg_config) && scg_sizeof_step_io() == (int)sizeof(scg_step_io));
+}
+
+static void check_tables(int system) {
+    const int nx = dims_nx(system), nu = dims_nu(system), nv = nx + nu;
+    scg_config c = base_config(system);
+    c.task = SCG_TRAJ_TRACKING;
+    c.cost = SCG_QUADRATIC;
+    c.Q[1] = 0.25;                                    // non-diagonal Q: the full-matrix path of the table builder
+    scg_handle* h = nullptr;
+    EXPECT(scg_create(&c, &h) == SCG_OK && h != nullptr);
+    if (!h) return;
+    EXPECT(scg_obs_dim(h) == nx);
+    // reference table: too short for the quadratic cost, then exact sizes incl. one whose byte count is not a multiple of 16
+    std::vector<double> table((size_t)301 * nx, 0.5);
+    EXPECT(scg_set_reference(h, nullptr, 300) == SCG_ERR_INVALID);
+    EXPECT(scg_set_reference(h, table.data(), 0) == SCG_ERR_INVALID);
+    EXPECT(scg_set_reference(h, table.data(), 299) == SCG_ERR_INVALID);
+    EXPECT(scg_set_reference(h, table.data(), 301) == SCG_OK);
+    EXPECT(scg_set_reference(h, table.data(), 300) == SCG_OK);
+    // constraints: the maximum number of rows of every kind the tables can hold
+    std::vector<scg_constraint_row> rows(SCG_MAX_CONSTRAINT_ROWS + 1);
+    std::vector<double> pm((size_t)SCG_MAX_QUADRATIC * SCG_MAX_NV * SCG_MAX_NV, 0.0);
+    for (int q = 0; q < SCG_MAX_QUADRATIC; ++q) for (int a = 0; a < nv; ++a) pm[(size_t)q * SCG_MAX_NV * SCG_MAX_NV + a * SCG_MAX_NV + a] = 1.0 + q;
+    for (size_t r = 0; r < rows.size(); ++r) {
+        std::memset(&rows[r], 0, sizeof(rows[r]));
+        rows[r].b = 1.0 + 0.01 * (double)r;
+        if (r % 3 == 0) { rows[r].coef[r % nv] = (r & 1) ? 1.0 : -1.0; rows[r].strict = 1; }            // bound row
+        else { rows[r].coef[r % nv] = 0.5; rows[r].coef[(r + 1) % nv] = -2.0; rows[r].has_tolerance = 1; rows[r].tolerance = 0.1; }   // dense row
+    }
+    for (int q = 0; q < SCG_MAX_QUADRATIC; ++q) { rows[1 + 3 * q].kind = 1; rows[1 + 3 * q].p_index = q; }
+    EXPECT(scg_set_constraints(h, rows.data(), SCG_MAX_CONSTRAINT_ROWS + 1, pm.data(), SCG_MAX_QUADRATIC) == SCG_ERR_INVALID);
+    EXPECT(scg_set_constraints(h, nullptr, 3, pm.data(), 0) == SCG_ERR_INVALID);
+    EXPECT(scg_set_constraints(h, rows.data(), SCG_MAX_CONSTRAINT_ROWS, pm.data(), SCG_MAX_QUADRATIC + 1) == SCG_ERR_INVALID);
+    EXPECT(scg_set_constraints(h, rows.data(), SCG_MAX_CONSTRAINT_ROWS, pm.data(), SCG_MAX_QUADRATIC) == SCG_OK);
+    EXPECT(scg_num_constraints(h) == SCG_MAX_CONSTRAINT_ROWS);
+    { auto bad = rows; bad[1].p_index = SCG_MAX_QUADRATIC; EXPECT(scg_set_constraints(h, bad.data(), 8, pm.data(), SCG_MAX_QUADRATIC) == SCG_ERR_INVALID); }
+    { auto bad = rows; bad[1].kind = 7; EXPECT(scg_set_constraints(h, bad.data(), 8, pm.data(), SCG_MAX_QUADRATIC) == SCG_ERR_INVALID); }
+    if (nv < SCG_MAX_NV) { auto bad = rows; bad[0].coef[SCG_MAX_NV - 1] = 1.0; EXPECT(scg_set_constraints(h, bad.data(), 8, pm.data(), SCG_MAX_QUADRATIC) == SCG_ERR_INVALID); }
+    EXPECT(scg_set_constraints(h, rows.data(), 0, nullptr, 0) == SCG_OK);        // clearing
+    // disturbances: SCG_MAX_DISTURBANCES per mode, one too many, malformed impulse / random offset
+    std::vector<scg_disturbance> ds;
+    for (int mode = 0; mode < 3; ++mode)
+        for (int e = 0; e < SCG_MAX_DISTURBANCES; ++e) {
+            scg_disturbance d;
+            std::memset(&d, 0, sizeof(d));
+            d.mode = mode; d.kind = (mode + e) % 5;
+            d.step_offset = e == 0 ? -1 : 3; d.max_step = 300; d.duration = 2; d.decay_rate = 0.5; d.magnitude = 0.1; d.scale = 0.2; d.frequency = 1.5;
+            d.has_mask = e & 1;
+            for (int j = 0; j < SCG_MAX_NX; ++j) { d.low[j] = -0.1; d.high[j] = 0.1; d.mask[j] = j & 1; }
+            ds.push_back(d);
+        }
+    EXPECT(scg_set_disturbances(h, ds.data(), (int32_t)ds.size()) == SCG_OK);
+    { auto more = ds; more.push_back(ds[0]); EXPECT(scg_set_disturbances(h, more.data(), (int32_t)more.size()) == SCG_ERR_INVALID); }
+    { auto bad = ds; bad[0].mode = 3; EXPECT(scg_set_disturbances(h, bad.data(), 1) == SCG_ERR_INVALID); }
+    { auto bad = ds; bad[0].kind = 9; EXPECT(scg_set_disturbances(h, bad.data(), 1) == SCG_ERR_INVALID); }
+    { auto bad = ds; bad[0].kind = SCG_DIST_IMPULSE; bad[0].duration = 0; EXPECT(scg_set_disturbances(h, bad.data(), 1) == SCG_ERR_INVALID); }
+    { auto bad = ds; bad[0].kind = SCG_DIST_STEP; bad[0].step_offset = -1; bad[0].max_step = 0; EXPECT(scg_set_disturbances(h, bad.data(), 1) == SCG_ERR_INVALID); }
+    EXPECT(scg_set_disturbances(h, nullptr, 2) == SCG_ERR_INVALID);
+    // with a per-episode offset and an observation entry attached, step() asks for the planes they need
+    { Buffers b(128); EXPECT(scg_step(h, &b.io, 100, nullptr) == SCG_ERR_INVALID); }
+    EXPECT(scg_set_disturbances(h, nullptr, 0) == SCG_OK);
+    EXPECT(scg_destroy(h) == SCG_OK);
+    EXPECT(g_shim.live_allocations == 0);
+}
+
+static void check_step_and_rollout() {
+    scg_config c = base_config(SCG_QUAD_3D);
+    scg_handle* h = nullptr;
+    EXPECT(scg_create(&c, &h) == SCG_OK);
+    Buffers b(1 << 20);
+    EXPECT(scg_step(nullptr, &b.io, 1, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_step(h, nullptr, 1, nullptr) == SCG_ERR_INVALID);
+    { Buffers x(64); x.io.struct_size = 12; EXPECT(scg_step(h, &x.io, 1, nullptr) == SCG_ERR_INVALID); }
+    { Buffers x(64); EXPECT(scg_step(h, &x.io, 65, nullptr) == SCG_ERR_INVALID); EXPECT(scg_step(h, &x.io, -1, nullptr) == SCG_ERR_INVALID); }
+    { Buffers x(64); x.io.reward = nullptr; EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_ERR_INVALID); }
+    { Buffers x(64); x.io.obs_noise = x.f.data(); EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_ERR_INVALID); }
+    { Buffers x(64); x.io.terminal_record = x.f.data(); x.io.terminal_stride = 13; EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_ERR_INVALID); }
+    { Buffers x(64); x.io.terminal_record = x.f.data(); x.io.terminal_stride = 16; EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_OK); }
+    { Buffers x(64); x.io.action_rows = 2; EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_ERR_INVALID); }
+    { Buffers x(64); x.io.action_rows = 1; x.io.action = x.f.data() + 1; EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_ERR_INVALID); }
+    { Buffers x((int64_t)1 << 31); EXPECT(scg_step(h, &x.io, ((int64_t)1 << 30) + 1, nullptr) == SCG_ERR_INVALID); }
+    const int64_t before = g_shim.launches;
+    EXPECT(scg_step(h, &b.io, 0, nullptr) == SCG_OK && g_shim.launches == before);      // n = 0 launches nothing
+    EXPECT(scg_step(h, &b.io, 1000, nullptr) == SCG_OK && g_shim.launches == before + 1);
+    // rollout argument checks
+    EXPECT(scg_rollout(h, &b.io, 1000, -1, 0, 1, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_rollout(h, &b.io, 1000, 3, 0, 0, nullptr) == SCG_ERR_INVALID);
+    { Buffers x(64); x.io.action_rows = 1; EXPECT(scg_rollout(h, &x.io, 8, 3, 0, 1, nullptr) == SCG_ERR_INVALID); }
+    EXPECT(scg_rollout(h, &b.io, 1000, 0, 0, 1, nullptr) == SCG_OK);
+    // small batch: one queue
+    shim_reset();
+    EXPECT(scg_rollout(h, &b.io, 1000, 5, 16, 2, nullptr) == SCG_OK);
+    EXPECT(g_shim.step_launches_main == 5 && g_shim.step_launches_aux == 0);
+    // large batch: two queues, forked and joined by events, second half keyed by its global env index
+    shim_reset();
+    const int64_t n = 700001, half = (n / 2) / 256 * 256;
+    EXPECT(scg_rollout(h, &b.io, n, 7, 16, 2, nullptr) == SCG_OK);
+    EXPECT(g_shim.step_launches_main == 7 && g_shim.step_launches_aux == 7);
+    EXPECT(g_shim.aux_streams_open == 0 && g_shim.event_records == 2 && g_shim.stream_waits == 2);
+    EXPECT(g_shim.last_n == n - half && g_shim.last_env_base == half);
+    // a launch failing anywhere between the fork and the join: the error comes back AND the second queue is joined
+    for (int k = 0; k < 9; ++k) {
+        shim_reset();
+        g_shim.fail_launch_after = k;
+        EXPECT(scg_rollout(h, &b.io, n, 7, 16, 2, nullptr) == SCG_ERR_HIP);
+        EXPECT(g_shim.aux_streams_open == 0);
+        EXPECT(g_shim.step_launches_main + g_shim.step_launches_aux == k);
+    }
+    // the fork event cannot be recorded: nothing was queued on the second stream, plain error
+    shim_reset();
+    g_shim.fail_event_record_after = 0;
+    EXPECT(scg_rollout(h, &b.io, n, 7, 16, 2, nullptr) == SCG_ERR_HIP && g_shim.aux_streams_open == 0 && g_shim.launches == 0);
+    // the join event cannot be recorded: the layer falls back to a host-side join of the second queue
+    shim_reset();
+    g_shim.fail_event_record_after = 1;
+    EXPECT(scg_rollout(h, &b.io, n, 7, 16, 2, nullptr) == SCG_ERR_HIP && g_shim.aux_streams_open == 0 && g_shim.stream_syncs == 1);
+    shim_reset();
+    EXPECT(scg_rollout_fused(h, &b.io, 1000, 4, 16, 2, nullptr) == SCG_OK && g_shim.launches == 1);
+    EXPECT(scg_destroy(h) == SCG_OK);
+    // per-handle launch policy: one queue only / a lower split threshold
+    c.rollout_queues = 1;
+    EXPECT(scg_create(&c, &h) == SCG_OK);
+    shim_reset();
+    EXPECT(scg_rollout(h, &b.io, n, 3, 16, 2, nullptr) == SCG_OK && g_shim.step_launches_aux == 0 && g_shim.step_launches_main == 3);
+    EXPECT(scg_destroy(h) == SCG_OK);
+    c.rollout_queues = 2; c.rollout_split_min = 256; c.grid_cap_per_cu = 2;
+    EXPECT(scg_create(&c, &h) == SCG_OK);
+    shim_reset();
+    EXPECT(scg_rollout(h, &b.io, 1000, 3, 16, 2, nullptr) == SCG_OK && g_shim.step_launches_aux == 3 && g_shim.aux_streams_open == 0);
+    int32_t blk = 0, grid = 0, lds = 0;
+    EXPECT(scg_kernel_info(h, &blk, &grid, &lds, (int64_t)1 << 20) == SCG_OK && grid == 512);
+    EXPECT(scg_destroy(h) == SCG_OK);
+}
+
+static void check_next_row_entry_points() {
+    std::vector<float> f(64);
+    std::vector<double> d(64);
+    std::vector<uint8_t> u(64);
+    scg_config c = base_config(SCG_QUAD_2D);
+    scg_handle* h = nullptr;
+    EXPECT(scg_create(&c, &h) == SCG_OK);
+    EXPECT(scg_reset(nullptr, f.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 8, 8, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_reset(h, f.data(), nullptr, (int32_t*)f.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 4, 8, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_reset(h, f.data(), nullptr, (int32_t*)f.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 8, 8, nullptr) == SCG_OK);
+    EXPECT(scg_eval_constraints(h, nullptr, nullptr, f.data(), nullptr, 8, 8, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_eval_constraints(h, f.data(), nullptr, f.data(), nullptr, 4, 8, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_model_eval(h, f.data(), f.data(), nullptr, nullptr, nullptr, 8, 8, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_model_eval(h, f.data(), f.data(), nullptr, f.data(), nullptr, 8, 8, nullptr) == SCG_OK);
+    EXPECT(scg_linearize(h, f.data(), f.data(), nullptr, f.data(), f.data(), -1.0, 8, 8, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_linearize(h, f.data(), f.data(), nullptr, f.data(), f.data(), 0.02, 8, 8, nullptr) == SCG_OK);
+    EXPECT(scg_quadratic_loss(h, d.data(), d.data(), f.data(), f.data(), f.data(), 4, f.data(), 0, f.data(), nullptr, nullptr, 8, 8, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_quadratic_loss(h, d.data(), d.data(), f.data(), f.data(), f.data(), 0, f.data(), 0, f.data(), nullptr, nullptr, 8, 8, nullptr) == SCG_OK);
+    EXPECT(scg_gae(f.data(), f.data(), f.data(), nullptr, f.data(), f.data(), f.data(), nullptr, nullptr, 0, 8, 8, 0.99f, 0.95f, 1, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_gae(f.data(), f.data(), f.data(), nullptr, f.data(), f.data(), f.data(), f.data(), nullptr, 4, 8, 8, 0.99f, 0.95f, 1, nullptr) == SCG_OK);
+    EXPECT(scg_normalize_advantages(f.data(), nullptr, 4, 8, 8, 1e-6f, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_mean_std_normalize(f.data(), f.data(), 0, 8, 8, 8, d.data(), d.data() + 32, d.data(), 10.f, 1e-8, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_mean_std_normalize(f.data(), f.data(), 3, 8, 8, 8, d.data(), d.data(), d.data(), 10.f, 1e-8, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_mean_std_normalize(f.data(), f.data(), 3, 8, 8, 8, d.data(), d.data() + 32, d.data(), 10.f, 1e-8, nullptr) == SCG_OK);
+    EXPECT(scg_reward_normalize(f.data(), nullptr, nullptr, f.data(), 8, d.data(), d.data() + 8, d.data(), 0.99f, 10.f, 1e-8, 0, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_reward_normalize(f.data(), u.data(), f.data(), f.data(), 8, d.data(), d.data() + 8, d.data(), 0.99f, 10.f, 1e-8, 0, nullptr) == SCG_OK);
+    EXPECT(scg_destroy(h) == SCG_OK);
+}
+
+int main() {
+    shim_reset();
+    check_create_validation();
+    for (int system = SCG_QUAD_1D; system <= SCG_CARTPOLE; ++system) check_tables(system);
+    check_step_and_rollout();
+    check_next_row_entry_points();
+    EXPECT(g_shim.live_allocations == 0);
+    std::printf(g_fail ? "capi sanitize driver: %d expectation(s) FAILED\n" : "capi sanitize driver: ok\n", g_fail);
+    return g_fail ? 1 : 0;
+}

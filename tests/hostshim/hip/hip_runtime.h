@@ -1,0 +1,46 @@
+// HOST-ONLY stand-in for <hip/hip_runtime.h>, used by ONE thing: the CPU sanitizer build of the C-ABI validation layer
+// (tests/hostshim/build.sh compiles safe_control_gym_amd/csrc/scg_capi.hip as plain C++ with -fsanitize=address,undefined).
+// "Device" memory is host heap memory, so AddressSanitizer checks every table the layer builds and copies; streams and
+// events are counters, so the driver can assert that scg_rollout joins its second launch queue on every error path.
+// The kernels themselves are NOT here (GPU sanitizers are unavailable on this pool): launches are recorded by
+// tests/hostshim/hip_host_shim.cc and may be told to fail.  Never part of the product build.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+
+#define __host__
+#define __device__
+#define __global__
+#define __forceinline__ inline
+
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorLaunchFailure = 719 };
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2 };
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+
+struct ihipStream_t { int id; int pending; };
+struct ihipEvent_t { int id; ihipStream_t* recorded_on; };
+typedef ihipStream_t* hipStream_t;
+typedef ihipEvent_t* hipEvent_t;
+
+struct hipDeviceProp_t { int multiProcessorCount; size_t sharedMemPerBlock; };
+
+const char* hipGetErrorString(hipError_t e);
+hipError_t hipGetLastError(void);
+hipError_t hipGetDevice(int* dev);
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int dev);
+hipError_t hipMalloc(void** p, size_t bytes);
+hipError_t hipFree(void* p);
+hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+hipError_t hipMemset(void* dst, int value, size_t bytes);
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
+hipError_t hipStreamDestroy(hipStream_t s);
+hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
+hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
+
+template <class T> hipError_t hipMalloc(T** p, size_t bytes) { return hipMalloc(reinterpret_cast<void**>(p), bytes); }

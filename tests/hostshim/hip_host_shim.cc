@@ -1,0 +1,66 @@
+// Host-only HIP stand-in + recording kernel launchers (test infrastructure: CPU sanitizer build of scg_capi.hip).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include "../../safe_control_gym_amd/csrc/scg_device.h"
+#include "hip_host_shim.h"
+
+ShimState g_shim;
+void shim_reset(void) {          // everything but the allocation balance, which spans the life of a handle
+    const int64_t live = g_shim.live_allocations;
+    std::memset(&g_shim, 0, sizeof(g_shim));
+    g_shim.live_allocations = live; g_shim.fail_launch_after = -1; g_shim.fail_event_record_after = -1;
+}
+
+static int g_next_id = 1;
+static hipError_t g_last = hipSuccess;
+
+const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : e == hipErrorLaunchFailure ? "launch failure (injected)" : "error"; }
+hipError_t hipGetLastError(void) { hipError_t e = g_last; g_last = hipSuccess; return e; }
+hipError_t hipGetDevice(int* dev) { *dev = 0; return hipSuccess; }
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 256; p->sharedMemPerBlock = 65536; return hipSuccess; }
+hipError_t hipMalloc(void** p, size_t bytes) { *p = std::malloc(bytes ? bytes : 1); if (!*p) return hipErrorOutOfMemory; ++g_shim.live_allocations; return hipSuccess; }
+hipError_t hipFree(void* p) { if (p) { std::free(p); --g_shim.live_allocations; } return hipSuccess; }
+hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind) { std::memcpy(dst, src, bytes); return hipSuccess; }
+hipError_t hipMemset(void* dst, int value, size_t bytes) { std::memset(dst, value, bytes); return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new ihipStream_t{g_next_id++, 0}; return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t s) { ++g_shim.stream_syncs; if (s && s->pending) { s->pending = 0; --g_shim.aux_streams_open; } return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new ihipEvent_t{g_next_id++, nullptr}; return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
+    if (g_shim.fail_event_record_after >= 0 && g_shim.event_records >= g_shim.fail_event_record_after) { ++g_shim.event_records; return hipErrorInvalidValue; }
+    ++g_shim.event_records;
+    e->recorded_on = s;
+    return hipSuccess;
+}
+hipError_t hipStreamWaitEvent(hipStream_t waiter, hipEvent_t e, unsigned) {
+    ++g_shim.stream_waits;
+    // the caller's stream (null here) waiting on an event recorded on an aux stream = that stream is joined
+    if (waiter == nullptr && e->recorded_on && e->recorded_on->pending) { e->recorded_on->pending = 0; --g_shim.aux_streams_open; }
+    return hipSuccess;
+}
+
+namespace scg {
+LaunchGeom step_geometry(const KParams& p, int, int64_t n, int num_cus) {
+    LaunchGeom g; g.block = 256; int64_t b = (n + 255) / 256;
+    if (p.grid_cap_per_cu > 0 && b > (int64_t)num_cus * p.grid_cap_per_cu) b = (int64_t)num_cus * p.grid_cap_per_cu;
+    g.grid = (int32_t)(b < 1 ? 1 : b); g.lds_bytes = 0; return g;
+}
+hipError_t launch_step(int, const KParams& p, const scg_step_io&, const KTables*, const ConTable*, const float*, int64_t n, int, hipStream_t s) {
+    if (g_shim.fail_launch_after >= 0 && g_shim.step_launches_main + g_shim.step_launches_aux >= g_shim.fail_launch_after) return hipErrorLaunchFailure;
+    ++g_shim.launches; g_shim.last_n = n; g_shim.last_env_base = p.env_base;
+    if (s) { ++g_shim.step_launches_aux; if (!s->pending) { s->pending = 1; ++g_shim.aux_streams_open; } } else ++g_shim.step_launches_main;
+    return hipSuccess;
+}
+bool fused_rollout_ok(const KParams&, const scg_step_io& io) { return !io.obs && !io.state_lo; }
+hipError_t launch_rollout_fused(int, const KParams&, const scg_step_io&, const KTables*, const ConTable*, const float*, int64_t, int32_t, int64_t, int32_t, int, hipStream_t) { ++g_shim.launches; return hipSuccess; }
+hipError_t launch_reset(int, const KParams&, const KTables*, float*, float*, int32_t*, float*, int32_t*, float*, const uint8_t*, const float*, float*, uint32_t*, const float*, uint32_t, int64_t, int64_t, hipStream_t) { ++g_shim.launches; return hipSuccess; }
+hipError_t launch_gae(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, double*, int, int64_t, int64_t, float, float, int, hipStream_t) { ++g_shim.launches; return hipSuccess; }
+hipError_t launch_normalize(float*, const double*, int, int64_t, int64_t, float, hipStream_t) { ++g_shim.launches; return hipSuccess; }
+hipError_t launch_model_eval(int, const KParams&, const KTables*, const float*, const float*, const float*, float*, float*, int64_t, int64_t, hipStream_t) { ++g_shim.launches; return hipSuccess; }
+hipError_t launch_linearize(int, const PhysT<float>&, const float*, const float*, const float*, float*, float*, float, int64_t, int64_t, hipStream_t) { ++g_shim.launches; return hipSuccess; }
+hipError_t launch_loss(int, const double*, const double*, const float*, const float*, const float*, int64_t, const float*, int64_t, float*, float*, float*, int64_t, int64_t, hipStream_t) { ++g_shim.launches; return hipSuccess; }
+hipError_t launch_mean_std_normalize(const float*, float*, int, int64_t, int64_t, int64_t, const double*, double*, double*, float, double, hipStream_t) { ++g_shim.launches; return hipSuccess; }
+hipError_t launch_reward_normalize(const float*, const uint8_t*, float*, float*, int64_t, const double*, double*, double*, float, float, double, int, hipStream_t) { ++g_shim.launches; return hipSuccess; }
+hipError_t launch_eval_constraints(int, const ConTable*, const float*, const float*, float*, uint8_t*, int64_t, int64_t, hipStream_t) { ++g_shim.launches; return hipSuccess; }
+}  // namespace scg

@@ -270,3 +270,23 @@ def test_bench_cli_contract_and_loud_failure_without_gpu():
         run = subprocess.run([sys.executable, bench, '--steps', '2', '--warmup', '1', '--envs-per-gpu', '64', '--no-cpu-baseline'],
                              capture_output=True, text=True, timeout=300)
         assert run.returncode != 0 and not run.stdout.strip().startswith('{')
+
+
+def test_sanitizer_builds_of_the_cpu_side_are_clean():
+    """SURVEY.md section 5 (build: -fsanitize=address host shim): GPU sanitizers are not available on this pool, so the
+    sanitizers run on the CPU builds -- (a) oracle/c, every system and the edge batch sizes, on exact-size heap buffers;
+    (b) the C-ABI validation layer (scg_capi.hip compiled as host C++ against tests/hostshim's stand-in HIP runtime):
+    every argument check, the reference / constraint / disturbance table compilers at their limits, and scg_rollout's error
+    paths (a launch failing at any point between fork and join still joins the second queue).  Both under
+    -fsanitize=address,undefined -fno-sanitize-recover=all: any report aborts with a non-zero exit code."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None or shutil.which('g++') is None:
+        pytest.skip('no host compiler on this box (the GPU box runs the prebuilt product only)')
+    env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=0', UBSAN_OPTIONS='print_stacktrace=1')
+    subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle', 'c'), '-s', 'asan'], stderr=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(ROOT, 'oracle', 'c', '_asan', 'scg_oracle_asan')], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0 and 'asan driver: ok' in out.stdout, out.stdout + out.stderr[-3000:]
+    subprocess.check_call(['bash', os.path.join(ROOT, 'tests', 'hostshim', 'build.sh')], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(ROOT, 'tests', 'hostshim', '_build', 'capi_sanitize')], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0 and 'capi sanitize driver: ok' in out.stdout, out.stdout + out.stderr[-3000:]
