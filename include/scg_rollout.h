@@ -317,7 +317,8 @@ int scg_normalize_advantages(float* adv, const double* stats, int32_t T, int64_t
  * clipped action, not the raw action.  inertial (nullable, [4][ld]) gives per-env (M, Ixx, Iyy, Izz) /
  * (pole_length, pole_mass, cart_mass, -); NULL uses the handle's nominal constants.  Outputs are row-major
  * batches dfdx [n][nx][nx], dfdu [n][nx][nu].  disc_dt > 0 applies discretize_linear_system(exact=False)
- * (controllers/mpc/mpc_utils.py:51-54, controllers/lqr/lqr_utils.py:39-60): Ad = I + A dt, Bd = B dt. */
+ * (controllers/mpc/mpc_utils.py:51-54, controllers/lqr/lqr_utils.py:39-60): Ad = I + A dt, Bd = B dt; the exact=True
+ * branch (:45-50) is scg_discretize_exact() below, applied to this function's outputs. */
 /* SymbolicModel.fc_func (symbolic_systems.py:68) and fd_func (:70-73) for n explicit (x, u) pairs: xdot = f(x, u) and/or
  * xnext = one control step of the handle's integrator (RK4 / Euler, its sub-steps) with zero-order-hold input -- the
  * engine's discretisation, where the reference's fd_func integrates with CVODES.  Same plane conventions as scg_linearize
@@ -326,6 +327,22 @@ int scg_model_eval(scg_handle* h, const float* state, const float* input, const 
                    float* xnext, int64_t ld, int64_t n, void* stream);
 int scg_linearize(scg_handle* h, const float* state, const float* input, const float* inertial, float* dfdx,
                   float* dfdu, double disc_dt, int64_t ld, int64_t n, void* stream);
+/* SymbolicModel.fc_linear_func (symbolic_systems.py:93-101): the model linearised about (state, input), evaluated at
+ * (x_eval, u_eval):  out = f(x, u) + dfdx(x, u) (x_eval - x) + dfdu(x, u) (u_eval - u).  All five arrays are SoA planes
+ * ([nx][ld] / [nu][ld]); x_eval == NULL evaluates at x_eval = 0, which gives the constant term c of the affine ODE
+ * z' = dfdx z + c that fd_linear_func (:102-107) integrates (see scg_discretize_exact).  g_linear_func (:108-112) is the
+ * identity map for these systems (y = x) and needs no kernel. */
+int scg_fc_linear(scg_handle* h, const float* x_eval, const float* u_eval, const float* state, const float* input,
+                  const float* inertial, float* out, int64_t ld, int64_t n, void* stream);
+/* discretize_linear_system(A, B, dt, exact=True) (controllers/mpc/mpc_utils.py:24-54) for n systems in one launch:
+ * [[Ad, Bd], [0, I]] = expm([[A, B], [0, 0]] dt), computed on the matrix cores (Taylor + scaling and squaring on
+ * v_mfma_f32_16x16x4_f32: exact f32 products).  A [n][nx][nx], B [n][nx][m] row-major device batches (the output format of
+ * scg_linearize), nx + m <= 16; Ad / Bd (each nullable) have the same shapes.  Optionally the one-step prediction of
+ * the discrete model: z1 [n][nx] = Ad z0 + Bd w with z0 [n][nx], w [n][m] (w == NULL: a vector of ones -- with B := the
+ * constant term of an affine ODE, m = 1, this is the exact flow that SymbolicModel.fd_linear_func integrates with CVODES,
+ * symbolic_systems.py:102-107).  Needs no handle: pure linear algebra. */
+int scg_discretize_exact(const float* A, const float* B, int32_t nx, int32_t m, double dt, float* Ad, float* Bd,
+                         const float* z0, const float* w, float* z1, int64_t n, void* stream);
 /* Quadratic stage cost and gradients (quadrotor.py:678-682, symbolic_systems.py:94-123):
  * l = 1/2 ex'Q ex + 1/2 eu'R eu, l_x = 1/2 (Q + Q') ex, l_u = 1/2 (R + R') eu with ex = x - xr, eu = u - ur.
  * Q [nx*nx] and R [nu*nu] are HOST row-major doubles.  xr is a device vector [nx] when xr_ld == 0, else planes

@@ -49,28 +49,61 @@ def uniform01(words):
     return (np.asarray(words, dtype=np.uint32) >> np.uint32(8)).astype(np.float64) * (2.0 ** -24)
 
 
-def reset_offsets(seed, env_index, reset_serial, low, high):
-    """Uniform reset offsets for one env: (nx,) float64, low/high are (nx,) arrays."""
+# scg_distribution (include/scg_rollout.h): the np.random.RandomState methods the reference may name in its yaml
+# (envs/benchmark_env.py:297-307), as transforms of the Philox uniforms -- shared with csrc/scg_kernels.hip::draw_distribution
+UNIFORM, NORMAL, EXPONENTIAL, LAPLACE, LOGISTIC, TRIANGULAR, RANDINT = range(7)
+
+
+def draw(kind, u, u2, p, low=0.0, high=1.0):
+    """One draw, float64.  u, u2 in [0, 1); p = (p0, p1, p2) as documented for scg_distribution."""
+    uo = u + 2.0 ** -25
+    if kind == NORMAL:
+        return p[0] + p[1] * np.sqrt(-2.0 * np.log(uo)) * np.cos(2.0 * np.pi * u2)
+    if kind == EXPONENTIAL:
+        return -p[0] * np.log(1.0 - u)
+    if kind == LAPLACE:
+        d = u - 0.5
+        return p[0] - np.copysign(p[1] * np.log(max(1.0 - 2.0 * abs(d), 2.0 ** -24)), d)
+    if kind == LOGISTIC:
+        return p[0] + p[1] * np.log(uo / (1.0 - uo))
+    if kind == TRIANGULAR:
+        base, ratio = p[2] - p[0], (p[1] - p[0]) / (p[2] - p[0])
+        return p[0] + np.sqrt(u * base * (p[1] - p[0])) if u <= ratio else p[2] - np.sqrt((1.0 - u) * base * (p[2] - p[1]))
+    if kind == RANDINT:
+        return np.floor(p[0] + (p[1] - p[0]) * u)
+    return low + (high - low) * u
+
+
+def _uniform_block(seed, env_index, reset_serial, word3):
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)
+    ctr = np.array([env_index & 0xFFFFFFFF, (env_index >> 32) & 0xFFFFFFFF, reset_serial & 0xFFFFFFFF, word3], dtype=np.uint32)
+    return uniform01(philox4x32_10(ctr, key))
+
+
+def reset_offsets(seed, env_index, reset_serial, low, high, kinds=None, params=None):
+    """Reset offsets for one env: (nx,) float64; low / high are (nx,) arrays (uniform dims).  ``kinds`` / ``params``
+    ((nx,) ints, (nx, 3) floats) select other distributions per dim; their second uniforms come from blocks 4 + j."""
     low = np.asarray(low, dtype=np.float64)
     high = np.asarray(high, dtype=np.float64)
     nx = low.shape[0]
-    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)
+    general = kinds is not None and any(int(k) != UNIFORM for k in kinds)
     out = np.zeros(nx)
     for j in range((nx + 3) // 4):
-        ctr = np.array([env_index & 0xFFFFFFFF, (env_index >> 32) & 0xFFFFFFFF,
-                        reset_serial & 0xFFFFFFFF, j], dtype=np.uint32)
-        u = uniform01(philox4x32_10(ctr, key))
+        u = _uniform_block(seed, env_index, reset_serial, j)
+        u2 = _uniform_block(seed, env_index, reset_serial, 4 + j) if general else np.zeros(4)
         for w in range(4):
             d = 4 * j + w
             if d < nx:
-                out[d] = low[d] + (high[d] - low[d]) * u[w]
+                out[d] = draw(int(kinds[d]), u[w], u2[w], params[d], low[d], high[d]) if general else low[d] + (high[d] - low[d]) * u[w]
     return out
 
 
-def inertial_offsets(seed, env_index, reset_serial, low, high):
-    """Uniform offsets for the 4 inertial properties: Philox block 15 of the same (env, serial) counter."""
-    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)
-    ctr = np.array([env_index & 0xFFFFFFFF, (env_index >> 32) & 0xFFFFFFFF, reset_serial & 0xFFFFFFFF, 15], dtype=np.uint32)
-    u = uniform01(philox4x32_10(ctr, key))
+def inertial_offsets(seed, env_index, reset_serial, low, high, kinds=None, params=None):
+    """Offsets for the 4 inertial properties: Philox block 15 of the same (env, serial) counter (block 14: the second
+    uniforms of non-uniform kinds)."""
+    u = _uniform_block(seed, env_index, reset_serial, 15)
     low, high = np.asarray(low, dtype=np.float64), np.asarray(high, dtype=np.float64)
-    return low + (high - low) * u
+    if kinds is None or all(int(k) == UNIFORM for k in kinds):
+        return low + (high - low) * u
+    u2 = _uniform_block(seed, env_index, reset_serial, 14)
+    return np.array([draw(int(kinds[q]), u[q], u2[q], params[q], low[q], high[q]) for q in range(4)])

@@ -62,3 +62,35 @@ def quadratic_loss(x, u, xr, ur, Q, R):
             'l_x': 0.5 * (Q + Q.T) @ ex, 'l_xx': 0.5 * (Q + Q.T),
             'l_u': 0.5 * (R + R.T) @ eu, 'l_uu': 0.5 * (R + R.T),
             'l_xu': np.zeros((ex.shape[0], eu.shape[0]))}
+
+
+def _f(system, x, u, p):
+    from oracle import ref_model as rm
+    return np.asarray(rm.F_BY_SYSTEM[system](list(x), list(u), p), dtype=np.float64)
+
+
+def fc_linear(system, x_eval, u_eval, x, u, p):
+    """SymbolicModel.fc_linear_func (math_and_models/symbolic_systems.py:93-101):
+    x_dot_linear = x_dot + dfdx (x_eval - x) + dfdu (u_eval - u), Jacobians by symbolic differentiation (``df``)."""
+    A, B = df(system, x, u, p)
+    return _f(system, x, u, p) + A @ (np.asarray(x_eval, dtype=np.float64) - np.asarray(x, dtype=np.float64)) \
+        + B @ (np.asarray(u_eval, dtype=np.float64) - np.asarray(u, dtype=np.float64))
+
+
+def fd_linear(system, x_eval, u_eval, x, u, p, dt, method='expm'):
+    """SymbolicModel.fd_linear_func (:102-107): the linearised ODE  z' = fc_linear(z, u_eval; x, u)  integrated over
+    [0, dt] from z(0) = x_eval.  The reference hands it to CVODES; the ODE is affine (z' = A z + c), so its flow is
+    ``expm([[A, c], [0, 0]] dt)`` -- ``method='ivp'`` integrates it numerically instead (DOP853, rtol 1e-12), the CVODES
+    stand-in the tests compare the closed form with."""
+    A, _ = df(system, x, u, p)
+    c = fc_linear(system, np.zeros(len(x)), u_eval, x, u, p)
+    z0 = np.asarray(x_eval, dtype=np.float64)
+    nx = len(z0)
+    if method == 'ivp':
+        from scipy.integrate import solve_ivp
+        sol = solve_ivp(lambda t, z: A @ z + c, (0.0, dt), z0, method='DOP853', rtol=1e-12, atol=1e-14)
+        return sol.y[:, -1]
+    M = np.zeros((nx + 1, nx + 1))
+    M[:nx, :nx], M[:nx, nx] = A, c
+    E = scipy.linalg.expm(M * dt)
+    return E[:nx, :nx] @ z0 + E[:nx, nx]

@@ -10,7 +10,7 @@ obj="$out/obj"
 mkdir -p "$out" "$obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 flags=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize "$@")
-units=(scg_kernels scg_gae scg_linearize scg_normalize scg_capi)
+units=(scg_kernels scg_gae scg_linearize scg_normalize scg_expm scg_capi)
 pids=()
 for u in "${units[@]}"; do
     "$HIPCC" "${flags[@]}" -c "$here/$u.hip" -o "$obj/$u.o" &

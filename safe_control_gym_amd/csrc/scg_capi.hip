@@ -101,6 +101,10 @@ static void derive_params(scg_handle* h) {
     if (c.drag && c.system != SCG_CARTPOLE) f |= F_DRAG;
     if (c.cost != SCG_QUADRATIC || (matrix_is_diag(c.Q, nx, SCG_MAX_NX) && matrix_is_diag(c.R, nu, SCG_MAX_NU)))
         f |= F_Q_DIAG;
+    if (c.randomized_init)
+        for (int j = 0; j < nx; ++j) if (c.init_rand_kind[j] != SCG_RAND_UNIFORM) f |= F_RAND_GENERAL;
+    if (c.randomized_inertial)
+        for (int q = 0; q < 4; ++q) if (c.inertial_rand_kind[q] != SCG_RAND_UNIFORM) f |= F_RAND_GENERAL;
     k.flags = f;
     k.substeps = c.substeps;
     k.ctrl_steps = c.ctrl_steps;
@@ -203,6 +207,14 @@ static void derive_tables(const scg_handle* h, KTables& t) {
         t.inertial_span[q] = (float)(c.inertial_rand_high[q] - c.inertial_rand_low[q]);
     }
     for (int j = 0; j < nu; ++j) { t.act_low_d[j] = c.act_low[j]; t.act_high_d[j] = c.act_high[j]; }
+    for (int j = 0; j < nx; ++j) {
+        t.init_kind[j] = c.init_rand_kind[j];
+        for (int r = 0; r < 3; ++r) t.init_p[j][r] = (float)c.init_rand_p[j][r];
+    }
+    for (int q = 0; q < 4; ++q) {
+        t.inertial_kind[q] = c.inertial_rand_kind[q];
+        for (int r = 0; r < 3; ++r) t.inertial_p[q][r] = (float)c.inertial_rand_p[q][r];
+    }
     for (int a = 0; a < SCG_MAX_NX * SCG_MAX_NX; ++a) t.Q[a] = (float)c.Q[a];
     for (int a = 0; a < SCG_MAX_NU * SCG_MAX_NU; ++a) t.R[a] = (float)c.R[a];
 }
@@ -260,9 +272,21 @@ int scg_create(const scg_config* cfg, scg_handle** out) {
                                    cfg->system == SCG_CARTPOLE ? cfg->pole_mass : cfg->ixx,
                                    cfg->system == SCG_CARTPOLE ? cfg->cart_mass : cfg->iyy,
                                    cfg->system == SCG_CARTPOLE ? 1.0 : cfg->izz};
-        for (int q = 0; q < 4; ++q)
-            if (!(nominal[q] + cfg->inertial_rand_low[q] > 0.0) || cfg->inertial_rand_high[q] < cfg->inertial_rand_low[q])
+        for (int q = 0; q < 4; ++q) {
+            // smallest draw of a bounded distribution (unbounded ones are floored by the kernel at 0.1 % of nominal)
+            const int kind = cfg->inertial_rand_kind[q];
+            double lowest = 0.0;
+            bool bounded = true;
+            if (kind == SCG_RAND_UNIFORM) {
+                lowest = cfg->inertial_rand_low[q];
+                if (cfg->inertial_rand_high[q] < cfg->inertial_rand_low[q])
+                    return fail(SCG_ERR_INVALID, "scg_create: randomised inertial property %d has high < low", q);
+            } else if (kind == SCG_RAND_TRIANGULAR || kind == SCG_RAND_RANDINT) lowest = cfg->inertial_rand_p[q][0];
+            else if (kind == SCG_RAND_EXPONENTIAL) lowest = 0.0;
+            else bounded = false;
+            if (bounded && !(nominal[q] + lowest > 0.0))
                 return fail(SCG_ERR_INVALID, "scg_create: randomised inertial property %d can become non-positive", q);
+        }
     }
 
     scg_handle* h = new (std::nothrow) scg_handle();
@@ -697,6 +721,34 @@ int scg_linearize(scg_handle* h, const float* state, const float* input, const f
     if (!(disc_dt >= 0.0)) return fail(SCG_ERR_INVALID, "scg_linearize: disc_dt must be >= 0");
     HIP_TRY(launch_linearize(h->system, h->kp.ph, state, input, inertial, dfdx, dfdu, (float)disc_dt, ld, n,
                              (hipStream_t)stream));
+    return SCG_OK;
+}
+
+int scg_fc_linear(scg_handle* h, const float* x_eval, const float* u_eval, const float* state, const float* input,
+                  const float* inertial, float* out, int64_t ld, int64_t n, void* stream) {
+    if (!h) return fail(SCG_ERR_INVALID, "scg_fc_linear: null handle");
+    if (!u_eval || !state || !input || !out) return fail(SCG_ERR_INVALID, "scg_fc_linear: null argument");
+    if (n < 0 || ld < n) return fail(SCG_ERR_INVALID, "scg_fc_linear: need 0 <= n <= ld");
+    if (n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_fc_linear: n > 2^30");
+    HIP_TRY(launch_fc_linear(h->system, h->kp.ph, x_eval, u_eval, state, input, inertial, out, ld, n, (hipStream_t)stream));
+    return SCG_OK;
+}
+
+int scg_discretize_exact(const float* A, const float* B, int32_t nx, int32_t m, double dt, float* Ad, float* Bd,
+                         const float* z0, const float* w, float* z1, int64_t n, void* stream) {
+    if (!A || !B) return fail(SCG_ERR_INVALID, "scg_discretize_exact: null argument");
+    if (nx < 1 || m < 1 || nx + m > 16) return fail(SCG_ERR_INVALID, "scg_discretize_exact: need nx >= 1, m >= 1, nx + m <= 16 (got %d + %d)", nx, m);
+    if (!Ad && !Bd && !z1) return fail(SCG_ERR_INVALID, "scg_discretize_exact: no output requested");
+    if (z1 && !z0) return fail(SCG_ERR_INVALID, "scg_discretize_exact: z1 needs z0");
+    if (!(dt > 0.0) || !std::isfinite(dt)) return fail(SCG_ERR_INVALID, "scg_discretize_exact: dt must be positive and finite");
+    if (n < 0 || n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_discretize_exact: need 0 <= n <= 2^30");
+    if (n == 0) return SCG_OK;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    }
+    HIP_TRY(launch_discretize_exact(A, B, nx, m, (float)dt, Ad, Bd, z0, w, z1, n, cus, (hipStream_t)stream));
     return SCG_OK;
 }
 

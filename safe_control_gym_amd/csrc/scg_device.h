@@ -25,6 +25,7 @@ enum Flags : uint32_t {
     F_RAND_INERTIAL = 1u << 13, // per-env inertial properties re-drawn at every reset
     F_GND = 1u << 14,           // ground effect (Physics.PYB_GND)
     F_DRAG = 1u << 15,          // drag (Physics.PYB_DRAG)
+    F_RAND_GENERAL = 1u << 16,  // some reset-time quantity is drawn from a non-uniform distribution (scg_distribution)
 };
 
 // Physical constants of the model, in the real type the integrator runs in: float in the kernarg block for
@@ -90,6 +91,9 @@ struct KTables {
     float inertial_nominal[4], inertial_lo[4], inertial_span[4];   // (M, Ixx, Iyy, Izz) | (pole_length, pole_mass, cart_mass, -)
     double arm, kmkf;           // l and KM/KF, to rebuild the per-env constants
     double act_low_d[SCG_MAX_NU], act_high_d[SCG_MAX_NU];
+    // distribution of every randomised quantity (only read when F_RAND_GENERAL is set; uniform dims keep lo / span above)
+    int32_t init_kind[SCG_MAX_NX], inertial_kind[4];
+    float init_p[SCG_MAX_NX][3], inertial_p[4][3];
     // full Q / R (only read when F_Q_DIAG is clear)
     float Q[SCG_MAX_NX * SCG_MAX_NX];
     float R[SCG_MAX_NU * SCG_MAX_NU];
@@ -165,6 +169,10 @@ hipError_t launch_model_eval(int system, const KParams& p, const KTables* tb, co
 hipError_t launch_linearize(int system, const PhysT<float>& ph, const float* state, const float* input,
                             const float* inertial, float* dfdx, float* dfdu, float disc_dt, int64_t ld, int64_t n,
                             hipStream_t s);
+hipError_t launch_fc_linear(int system, const PhysT<float>& ph, const float* x_eval, const float* u_eval, const float* state,
+                            const float* input, const float* inertial, float* out, int64_t ld, int64_t n, hipStream_t s);
+hipError_t launch_discretize_exact(const float* A, const float* B, int nx, int m, float dt, float* Ad, float* Bd,
+                                   const float* z0, const float* w, float* z1, int64_t n, int num_cus, hipStream_t s);
 hipError_t launch_loss(int system, const double* Q, const double* R, const float* state, const float* input,
                        const float* xr, int64_t xr_ld, const float* ur, int64_t ur_ld, float* l, float* l_x, float* l_u,
                        int64_t ld, int64_t n, hipStream_t s);

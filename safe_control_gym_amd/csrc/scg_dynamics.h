@@ -1,0 +1,165 @@
+// The prior model's continuous dynamics x_dot = f(x, u) and the fixed-step integrators, shared by the step kernel
+// (scg_kernels.hip), the stand-alone model queries and the linearised-model kernels (scg_linearize.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "scg_device.h"
+#include "scg_math.h"
+
+namespace scg {
+
+// ------------------------------------------------------------------------------------------
+// continuous dynamics  x_dot = f(x, u)   (quadrotor.py:594-676; cartpole: DESIGN.md A16)
+// ------------------------------------------------------------------------------------------
+// All of it is generic over the real type T: float for the default path, double for the precise mode
+// (compensated_state), where the state travels as hi + lo float32 planes and the ODE is integrated in fp64
+// (fp64 FMA issues at the same 4-cycle rate as unpacked fp32 on this chip).
+template <class T> struct Real;
+template <> struct Real<float> {
+    static __device__ __forceinline__ float rcp(float x) { return rcp_f(x); }
+    static __device__ __forceinline__ void sincos(float x, float& s, float& c) { sincos_f(x, s, c); }
+};
+template <> struct Real<double> {
+    static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+    // fdlibm-style kernels on [-pi/4, pi/4] after a two-piece FMA Cody-Waite reduction; |err| < 4e-15 for |x| < 50
+    static __device__ __forceinline__ void sincos(double x, double& s, double& c) {
+        const double kf = rint(x * 0.63661977236758134308);
+        const int k = (int)kf;
+        double r = fma(kf, -1.5707963267948966, x);
+        r = fma(kf, -6.123233995736766e-17, r);
+        const double z = r * r;
+        double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+        ps = fma(ps, z, 2.75573137070700676789e-06);
+        ps = fma(ps, z, -1.98412698298579493134e-04);
+        ps = fma(ps, z, 8.33333333332248946124e-03);
+        ps = fma(ps, z, -1.66666666666666324348e-01);
+        const double sr = fma(r * z, ps, r);
+        double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+        pc = fma(pc, z, -2.75573143513906633035e-07);
+        pc = fma(pc, z, 2.48015872894767294178e-05);
+        pc = fma(pc, z, -1.38888888888741095749e-03);
+        pc = fma(pc, z, 4.16666666666666019037e-02);
+        const double cr = fma(z * z, pc, fma(z, -0.5, 1.0));
+        const double ss = (k & 1) ? cr : sr, cc = (k & 1) ? sr : cr;
+        s = (k & 2) ? -ss : ss;
+        c = ((k + 1) & 2) ? -cc : cc;
+    }
+};
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return fma(a, b, c); }
+
+template <int SYS, class T> struct Inputs;
+template <class T> struct Inputs<SCG_QUAD_1D, T> { T acc; };                       // T/m - g (+ Fz/m)
+template <class T> struct Inputs<SCG_QUAD_2D, T> { T Tm, ax, az, thdd; };
+template <class T> struct Inputs<SCG_QUAD_3D, T> { T Tm, ax, ay, az, mx, my, mz; };
+template <class T> struct Inputs<SCG_CARTPOLE, T> { T F; };
+
+// ZOH inputs of one step.  In the precise mode the physical constants are the float-rounded kernarg values
+// widened to double -- the same constants the float path uses, so the two modes integrate the same model.
+template <int SYS, class T>
+__device__ __forceinline__ void make_inputs(const PhysT<T>& c, const T* u, T fx, T fy, T fz,
+                                            Inputs<SYS, T>& in) {
+    const T inv_m = c.inv_m, g = c.g;
+    if constexpr (SYS == SCG_QUAD_1D) {
+        in.acc = fma_t(u[0] + (T)fz, inv_m, -g);                                // quadrotor.py:602
+    } else if constexpr (SYS == SCG_QUAD_2D) {
+        in.Tm = (u[0] + u[1]) * inv_m;                                          // quadrotor.py:619-620
+        in.ax = (T)fx * inv_m;
+        in.az = fma_t((T)fz, inv_m, -g);
+        in.thdd = c.l_s2_iyy * (u[1] - u[0]);                                // quadrotor.py:621
+    } else if constexpr (SYS == SCG_QUAD_3D) {
+        in.Tm = ((u[0] + u[1]) + (u[2] + u[3])) * inv_m;                        // quadrotor.py:664
+        in.ax = (T)fx * inv_m;
+        in.ay = (T)fy * inv_m;
+        in.az = fma_t((T)fz, inv_m, -g);
+        in.mx = c.arm_s2 * ((u[0] + u[1]) - (u[2] + u[3])) * c.inv_ixx;   // quadrotor.py:667
+        in.my = c.arm_s2 * ((u[1] + u[2]) - (u[0] + u[3])) * c.inv_iyy;   // quadrotor.py:668
+        in.mz = c.gamma * ((u[0] + u[2]) - (u[1] + u[3])) * c.inv_izz;    // quadrotor.py:669
+    } else {
+        in.F = u[0] + (T)fx;
+    }
+}
+
+template <int SYS, class T>
+__device__ __forceinline__ void f_eval(const PhysT<T>& c, const Inputs<SYS, T>& in, const T (&x)[Dim<SYS>::NX],
+                                       T (&d)[Dim<SYS>::NX]) {
+    if constexpr (SYS == SCG_QUAD_1D) {
+        d[0] = x[1];
+        d[1] = in.acc;
+    } else if constexpr (SYS == SCG_QUAD_2D) {
+        T s, co;
+        Real<T>::sincos(x[4], s, co);
+        d[0] = x[1];
+        d[1] = fma_t(s, in.Tm, in.ax);
+        d[2] = x[3];
+        d[3] = fma_t(co, in.Tm, in.az);
+        d[4] = x[5];
+        d[5] = in.thdd;
+    } else if constexpr (SYS == SCG_QUAD_3D) {
+        T sph, cph, sth, cth, sps, cps;
+        Real<T>::sincos(x[6], sph, cph);
+        Real<T>::sincos(x[7], sth, cth);
+        Real<T>::sincos(x[8], sps, cps);
+        const T P = x[9], Q = x[10], R = x[11];
+        // third column of R = Rz(psi) Ry(theta) Rx(phi)  (transformations.py:125-182)
+        const T sthcph = sth * cph;
+        d[0] = x[1];
+        d[1] = fma_t(fma_t(cps, sthcph, sps * sph), in.Tm, in.ax);
+        d[2] = x[3];
+        d[3] = fma_t(fma_t(sps, sthcph, -(cps * sph)), in.Tm, in.ay);
+        d[4] = x[5];
+        d[5] = fma_t(cth * cph, in.Tm, in.az);
+        // Euler-angle rates (quadrotor.py:671-673)
+        const T rcth = Real<T>::rcp(cth);
+        const T w = fma_t(sph, Q, cph * R);               // sin(phi) q + cos(phi) r
+        d[6] = fma_t(sth * rcth, w, P);
+        d[7] = fma_t(cph, Q, -(sph * R));
+        d[8] = w * rcth;
+        // body rates: Jinv (Mb - w x J w)  (quadrotor.py:670)
+        d[9] = fma_t(-c.cxx, Q * R, in.mx);
+        d[10] = fma_t(-c.cyy, R * P, in.my);
+        d[11] = fma_t(-c.czz, P * Q, in.mz);
+    } else {
+        T s, co;
+        Real<T>::sincos(x[2], s, co);
+        const T thd = x[3];
+        const T tmp = fma_t(c.cp_ml * thd * thd, s, in.F) * c.cp_inv_Mm;
+        const T den = c.cp_l * fma_t(-c.cp_m * c.cp_inv_Mm, co * co, (T)(4.0 / 3.0));
+        const T thdd = fma_t(c.cp_g, s, -(co * tmp)) * Real<T>::rcp(den);
+        d[0] = x[1];
+        d[1] = fma_t(-c.cp_ml * c.cp_inv_Mm, thdd * co, tmp);
+        d[2] = thd;
+        d[3] = thdd;
+    }
+}
+
+// One fixed step; returns the increment (so the float path can add it with its own rounding).
+template <int SYS, class T>
+__device__ __forceinline__ void integrate(const PhysT<T>& c, uint32_t flags, const Inputs<SYS, T>& in,
+                                          const T (&x)[Dim<SYS>::NX], T (&inc)[Dim<SYS>::NX]) {
+    constexpr int NX = Dim<SYS>::NX;
+    const T h = c.h;
+    T k[NX];
+    f_eval<SYS, T>(c, in, x, k);
+    if (flags & F_EULER) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) inc[j] = h * k[j];
+        return;
+    }
+    // RK4, zero-order-hold input (controllers/mpc/mpc_utils.py:93-97)
+    T xt[NX], acc[NX];
+    const T hh = (T)0.5 * h;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) { acc[j] = k[j]; xt[j] = fma_t(hh, k[j], x[j]); }
+    f_eval<SYS, T>(c, in, xt, k);
+#pragma unroll
+    for (int j = 0; j < NX; ++j) { acc[j] = fma_t((T)2, k[j], acc[j]); xt[j] = fma_t(hh, k[j], x[j]); }
+    f_eval<SYS, T>(c, in, xt, k);
+#pragma unroll
+    for (int j = 0; j < NX; ++j) { acc[j] = fma_t((T)2, k[j], acc[j]); xt[j] = fma_t(h, k[j], x[j]); }
+    f_eval<SYS, T>(c, in, xt, k);
+    const T h6 = h * (T)(1.0 / 6.0);
+#pragma unroll
+    for (int j = 0; j < NX; ++j) inc[j] = h6 * (acc[j] + k[j]);
+}
+
+}  // namespace scg

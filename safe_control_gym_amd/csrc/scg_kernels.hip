@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include "scg_device.h"
 #include "scg_math.h"
+#include "scg_dynamics.h"
 
 namespace scg {
 
@@ -149,9 +150,37 @@ __device__ __forceinline__ void apply_disturbances(const KParams& p, const DistT
     }
 }
 
-// nominal (+ uniform Philox offsets) reset state of env i -- quadrotor.py:478-493 with
-// benchmark_env.py:297-307 restricted to 'uniform' draws.
-template <int NX>
+// One draw of a reset-time distribution (scg_distribution; benchmark_env.py:297-307 calls np_random.<distrib>) as a
+// transform of the Philox uniforms u, u2 in [0, 1).  Shared with oracle/philox.py::draw.  The log-based kinds read
+// u + 2^-25 in (0, 1) so that neither log(0) nor log(1 - 1) occurs.
+__device__ __forceinline__ float draw_distribution(int kind, float u, float u2, const float (&p)[3], float lo, float span) {
+    const float uo = u + 2.9802322387695312e-8f;                       // 2^-25
+    switch (kind) {
+        case SCG_RAND_NORMAL: {                                          // Box-Muller, accurate sin / cos
+            const float r = sqrt_f(-2.0f * logf(uo));
+            float sn, cs;
+            sincos_f(6.283185307179586f * u2, sn, cs);
+            return fmaf(p[1] * r, cs, p[0]);
+        }
+        case SCG_RAND_EXPONENTIAL: return -p[0] * logf(1.0f - u);       // 1 - u in (0, 1]
+        case SCG_RAND_LAPLACE: {
+            const float d = u - 0.5f, a = fmaxf(1.0f - 2.0f * fabsf(d), 5.9604644775390625e-8f);
+            return p[0] - copysignf(p[1] * logf(a), d);
+        }
+        case SCG_RAND_LOGISTIC: return fmaf(p[1], logf(uo / (1.0f - uo)), p[0]);
+        case SCG_RAND_TRIANGULAR: {
+            const float base = p[2] - p[0], ratio = (p[1] - p[0]) / base;
+            return u <= ratio ? p[0] + sqrt_f(u * base * (p[1] - p[0])) : p[2] - sqrt_f((1.0f - u) * base * (p[2] - p[1]));
+        }
+        case SCG_RAND_RANDINT: return floorf(fmaf(p[1] - p[0], u, p[0]));
+        default: return fmaf(span, u, lo);                               // SCG_RAND_UNIFORM
+    }
+}
+
+// nominal (+ Philox offsets) reset state of env i -- quadrotor.py:478-493 with benchmark_env.py:297-307: uniform draws
+// from one Philox block per 4 dims (counter words 0..2); with F_RAND_GENERAL a second block per 4 dims (words 4..6)
+// supplies the second uniform of the two-uniform kinds.
+template <int NX, bool GEN = true>
 __device__ __forceinline__ void reset_state_of(const KParams& p, const KTables* __restrict__ tb,
                                                const float* __restrict__ reset_state, int64_t ld, uint32_t i,
                                                uint32_t serial, float (&x)[NX]) {
@@ -164,16 +193,24 @@ __device__ __forceinline__ void reset_state_of(const KParams& p, const KTables* 
     }
     if (p.flags & F_RAND_INIT) {
         const uint64_t g = (uint64_t)(p.env_base + (int64_t)i);
+        const bool general = GEN && (p.flags & F_RAND_GENERAL) != 0;      // GEN = false: a lean tier (uniform only by construction)
 #pragma unroll
         for (int b = 0; b < (NX + 3) / 4; ++b) {
-            uint32_t w[4];
+            uint32_t w[4], w2[4] = {0u, 0u, 0u, 0u};
             philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), serial, (uint32_t)b, p.seed_lo, p.seed_hi, w);
+            if (general) philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), serial, (uint32_t)(4 + b), p.seed_lo, p.seed_hi, w2);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int d = 4 * b + q;
                 if (d < NX) {
                     const float u = (float)(w[q] >> 8) * 5.9604644775390625e-8f;   // 2^-24
-                    x[d] += fmaf(tb->init_span[d], u, tb->init_lo[d]);
+                    if (general) {
+                        const float pr[3] = {tb->init_p[d][0], tb->init_p[d][1], tb->init_p[d][2]};
+                        x[d] += draw_distribution(tb->init_kind[d], u, (float)(w2[q] >> 8) * 5.9604644775390625e-8f, pr,
+                                                  tb->init_lo[d], tb->init_span[d]);
+                    } else {
+                        x[d] += fmaf(tb->init_span[d], u, tb->init_lo[d]);
+                    }
                 }
             }
         }
@@ -197,8 +234,8 @@ __device__ __forceinline__ void reset_state_coop(const KParams& p, const KTables
     constexpr int W = 4 * NB;                 // uniforms per env (>= NX)
     constexpr int JOBS = 64 / NB;             // envs served per pass
     const unsigned long long exec = __ballot(1);
-    if (!(p.flags & F_RAND_INIT) || exec != ~0ull) {
-        // no randomisation, or a ragged last wave: plain per-lane path
+    if (!(p.flags & F_RAND_INIT) || (p.flags & F_RAND_GENERAL) || exec != ~0ull) {
+        // no randomisation, non-uniform distributions, or a ragged last wave: plain per-lane path
         if (need) reset_state_of<NX>(p, tb, reset_state, ld, i, serial, x);
         return;
     }
@@ -308,131 +345,6 @@ __device__ __forceinline__ void reset_state_wg(const KParams& p, const KTables* 
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// continuous dynamics  x_dot = f(x, u)   (quadrotor.py:594-676; cartpole: DESIGN.md A16)
-// ------------------------------------------------------------------------------------------
-// All of it is generic over the real type T: float for the default path, double for the precise mode
-// (compensated_state), where the state travels as hi + lo float32 planes and the ODE is integrated in fp64
-// (fp64 FMA issues at the same 4-cycle rate as unpacked fp32 on this chip).
-template <class T> struct Real;
-template <> struct Real<float> {
-    static __device__ __forceinline__ float rcp(float x) { return rcp_f(x); }
-    static __device__ __forceinline__ void sincos(float x, float& s, float& c) { sincos_f(x, s, c); }
-};
-template <> struct Real<double> {
-    static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
-    // fdlibm-style kernels on [-pi/4, pi/4] after a two-piece FMA Cody-Waite reduction; |err| < 4e-15 for |x| < 50
-    static __device__ __forceinline__ void sincos(double x, double& s, double& c) {
-        const double kf = rint(x * 0.63661977236758134308);
-        const int k = (int)kf;
-        double r = fma(kf, -1.5707963267948966, x);
-        r = fma(kf, -6.123233995736766e-17, r);
-        const double z = r * r;
-        double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-        ps = fma(ps, z, 2.75573137070700676789e-06);
-        ps = fma(ps, z, -1.98412698298579493134e-04);
-        ps = fma(ps, z, 8.33333333332248946124e-03);
-        ps = fma(ps, z, -1.66666666666666324348e-01);
-        const double sr = fma(r * z, ps, r);
-        double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-        pc = fma(pc, z, -2.75573143513906633035e-07);
-        pc = fma(pc, z, 2.48015872894767294178e-05);
-        pc = fma(pc, z, -1.38888888888741095749e-03);
-        pc = fma(pc, z, 4.16666666666666019037e-02);
-        const double cr = fma(z * z, pc, fma(z, -0.5, 1.0));
-        const double ss = (k & 1) ? cr : sr, cc = (k & 1) ? sr : cr;
-        s = (k & 2) ? -ss : ss;
-        c = ((k + 1) & 2) ? -cc : cc;
-    }
-};
-__device__ __forceinline__ float fma_t(float a, float b, float c) { return fmaf(a, b, c); }
-__device__ __forceinline__ double fma_t(double a, double b, double c) { return fma(a, b, c); }
-
-template <int SYS, class T> struct Inputs;
-template <class T> struct Inputs<SCG_QUAD_1D, T> { T acc; };                       // T/m - g (+ Fz/m)
-template <class T> struct Inputs<SCG_QUAD_2D, T> { T Tm, ax, az, thdd; };
-template <class T> struct Inputs<SCG_QUAD_3D, T> { T Tm, ax, ay, az, mx, my, mz; };
-template <class T> struct Inputs<SCG_CARTPOLE, T> { T F; };
-
-// ZOH inputs of one step.  In the precise mode the physical constants are the float-rounded kernarg values
-// widened to double -- the same constants the float path uses, so the two modes integrate the same model.
-template <int SYS, class T>
-__device__ __forceinline__ void make_inputs(const PhysT<T>& c, const T* u, T fx, T fy, T fz,
-                                            Inputs<SYS, T>& in) {
-    const T inv_m = c.inv_m, g = c.g;
-    if constexpr (SYS == SCG_QUAD_1D) {
-        in.acc = fma_t(u[0] + (T)fz, inv_m, -g);                                // quadrotor.py:602
-    } else if constexpr (SYS == SCG_QUAD_2D) {
-        in.Tm = (u[0] + u[1]) * inv_m;                                          // quadrotor.py:619-620
-        in.ax = (T)fx * inv_m;
-        in.az = fma_t((T)fz, inv_m, -g);
-        in.thdd = c.l_s2_iyy * (u[1] - u[0]);                                // quadrotor.py:621
-    } else if constexpr (SYS == SCG_QUAD_3D) {
-        in.Tm = ((u[0] + u[1]) + (u[2] + u[3])) * inv_m;                        // quadrotor.py:664
-        in.ax = (T)fx * inv_m;
-        in.ay = (T)fy * inv_m;
-        in.az = fma_t((T)fz, inv_m, -g);
-        in.mx = c.arm_s2 * ((u[0] + u[1]) - (u[2] + u[3])) * c.inv_ixx;   // quadrotor.py:667
-        in.my = c.arm_s2 * ((u[1] + u[2]) - (u[0] + u[3])) * c.inv_iyy;   // quadrotor.py:668
-        in.mz = c.gamma * ((u[0] + u[2]) - (u[1] + u[3])) * c.inv_izz;    // quadrotor.py:669
-    } else {
-        in.F = u[0] + (T)fx;
-    }
-}
-
-template <int SYS, class T>
-__device__ __forceinline__ void f_eval(const PhysT<T>& c, const Inputs<SYS, T>& in, const T (&x)[Dim<SYS>::NX],
-                                       T (&d)[Dim<SYS>::NX]) {
-    if constexpr (SYS == SCG_QUAD_1D) {
-        d[0] = x[1];
-        d[1] = in.acc;
-    } else if constexpr (SYS == SCG_QUAD_2D) {
-        T s, co;
-        Real<T>::sincos(x[4], s, co);
-        d[0] = x[1];
-        d[1] = fma_t(s, in.Tm, in.ax);
-        d[2] = x[3];
-        d[3] = fma_t(co, in.Tm, in.az);
-        d[4] = x[5];
-        d[5] = in.thdd;
-    } else if constexpr (SYS == SCG_QUAD_3D) {
-        T sph, cph, sth, cth, sps, cps;
-        Real<T>::sincos(x[6], sph, cph);
-        Real<T>::sincos(x[7], sth, cth);
-        Real<T>::sincos(x[8], sps, cps);
-        const T P = x[9], Q = x[10], R = x[11];
-        // third column of R = Rz(psi) Ry(theta) Rx(phi)  (transformations.py:125-182)
-        const T sthcph = sth * cph;
-        d[0] = x[1];
-        d[1] = fma_t(fma_t(cps, sthcph, sps * sph), in.Tm, in.ax);
-        d[2] = x[3];
-        d[3] = fma_t(fma_t(sps, sthcph, -(cps * sph)), in.Tm, in.ay);
-        d[4] = x[5];
-        d[5] = fma_t(cth * cph, in.Tm, in.az);
-        // Euler-angle rates (quadrotor.py:671-673)
-        const T rcth = Real<T>::rcp(cth);
-        const T w = fma_t(sph, Q, cph * R);               // sin(phi) q + cos(phi) r
-        d[6] = fma_t(sth * rcth, w, P);
-        d[7] = fma_t(cph, Q, -(sph * R));
-        d[8] = w * rcth;
-        // body rates: Jinv (Mb - w x J w)  (quadrotor.py:670)
-        d[9] = fma_t(-c.cxx, Q * R, in.mx);
-        d[10] = fma_t(-c.cyy, R * P, in.my);
-        d[11] = fma_t(-c.czz, P * Q, in.mz);
-    } else {
-        T s, co;
-        Real<T>::sincos(x[2], s, co);
-        const T thd = x[3];
-        const T tmp = fma_t(c.cp_ml * thd * thd, s, in.F) * c.cp_inv_Mm;
-        const T den = c.cp_l * fma_t(-c.cp_m * c.cp_inv_Mm, co * co, (T)(4.0 / 3.0));
-        const T thdd = fma_t(c.cp_g, s, -(co * tmp)) * Real<T>::rcp(den);
-        d[0] = x[1];
-        d[1] = fma_t(-c.cp_ml * c.cp_inv_Mm, thdd * co, tmp);
-        d[2] = thd;
-        d[3] = thdd;
-    }
-}
-
 // ---- aero terms of Physics.PYB_GND / PYB_DRAG (base_aviary.py:437-500) as zero-order-hold inputs -------------------
 // Drag (:478-496): drag_factors = -DRAG_COEFF * sum_i (2 pi rpm_i / 60); drag = base_rot (drag_factors * vel), applied to
 // the centre of mass with flags=LINK_FRAME, i.e. the world force is base_rot drag.  Evaluated from the state at the
@@ -508,36 +420,6 @@ __device__ __forceinline__ void ground_effect(const KParams& p, const PhysT<T>& 
 #pragma unroll
         for (int j = 0; j < NU; ++j) ug[j] = u[j];
     }
-}
-
-// One fixed step; returns the increment (so the float path can add it with its own rounding).
-template <int SYS, class T>
-__device__ __forceinline__ void integrate(const PhysT<T>& c, uint32_t flags, const Inputs<SYS, T>& in,
-                                          const T (&x)[Dim<SYS>::NX], T (&inc)[Dim<SYS>::NX]) {
-    constexpr int NX = Dim<SYS>::NX;
-    const T h = c.h;
-    T k[NX];
-    f_eval<SYS, T>(c, in, x, k);
-    if (flags & F_EULER) {
-#pragma unroll
-        for (int j = 0; j < NX; ++j) inc[j] = h * k[j];
-        return;
-    }
-    // RK4, zero-order-hold input (controllers/mpc/mpc_utils.py:93-97)
-    T xt[NX], acc[NX];
-    const T hh = (T)0.5 * h;
-#pragma unroll
-    for (int j = 0; j < NX; ++j) { acc[j] = k[j]; xt[j] = fma_t(hh, k[j], x[j]); }
-    f_eval<SYS, T>(c, in, xt, k);
-#pragma unroll
-    for (int j = 0; j < NX; ++j) { acc[j] = fma_t((T)2, k[j], acc[j]); xt[j] = fma_t(hh, k[j], x[j]); }
-    f_eval<SYS, T>(c, in, xt, k);
-#pragma unroll
-    for (int j = 0; j < NX; ++j) { acc[j] = fma_t((T)2, k[j], acc[j]); xt[j] = fma_t(h, k[j], x[j]); }
-    f_eval<SYS, T>(c, in, xt, k);
-    const T h6 = h * (T)(1.0 / 6.0);
-#pragma unroll
-    for (int j = 0; j < NX; ++j) inc[j] = h6 * (acc[j] + k[j]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -640,7 +522,9 @@ __device__ __forceinline__ void load_goal(const KParams& p, const float* __restr
 // ------------------------------------------------------------------------------------------
 // per-env inertial properties (domain randomisation, quadrotor.py:455-475)
 // ------------------------------------------------------------------------------------------
-// value = nominal + U(low, high), one Philox block (counter word 3 = 15, distinct from the state blocks 0..2)
+// value = nominal + draw, one Philox block (counter word 3 = 15, distinct from the state blocks 0..2 / 4..6); with
+// F_RAND_GENERAL block 14 supplies the second uniforms and the property is floored at 0.1 % of nominal (the reference
+// raises when a draw comes out negative, quadrotor.py:464-465 -- a batched engine cannot abort one env)
 __device__ __forceinline__ void draw_inertial(const KParams& p, const KTables* __restrict__ tb, uint32_t i,
                                               uint32_t serial, float (&prop)[4]) {
 #pragma unroll
@@ -649,9 +533,21 @@ __device__ __forceinline__ void draw_inertial(const KParams& p, const KTables* _
         const uint64_t g = (uint64_t)(p.env_base + (int64_t)i);
         uint32_t w[4];
         philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), serial, 15u, p.seed_lo, p.seed_hi, w);
+        if (p.flags & F_RAND_GENERAL) {
+            uint32_t w2[4];
+            philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), serial, 14u, p.seed_lo, p.seed_hi, w2);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            prop[q] += fmaf(tb->inertial_span[q], (float)(w[q] >> 8) * 5.9604644775390625e-8f, tb->inertial_lo[q]);
+            for (int q = 0; q < 4; ++q) {
+                const float pr[3] = {tb->inertial_p[q][0], tb->inertial_p[q][1], tb->inertial_p[q][2]};
+                prop[q] += draw_distribution(tb->inertial_kind[q], (float)(w[q] >> 8) * 5.9604644775390625e-8f,
+                                             (float)(w2[q] >> 8) * 5.9604644775390625e-8f, pr, tb->inertial_lo[q], tb->inertial_span[q]);
+                prop[q] = fmaxf(prop[q], 1e-3f * tb->inertial_nominal[q]);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                prop[q] += fmaf(tb->inertial_span[q], (float)(w[q] >> 8) * 5.9604644775390625e-8f, tb->inertial_lo[q]);
+        }
     }
 }
 
@@ -729,7 +625,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
     // per-wave LDS scratch of the cooperative reset, placed after the (16-B padded) reference table
     float* wg_scratch = s_ref + ((tracking && (p.flags & F_REF_IN_LDS)) ? (((p.ref_rows * NX + 3) >> 2) << 2) : 0);
     float* coop_scratch = wg_scratch + (threadIdx.x >> 6) * kCoopFloats;      // per-wave form: aliases the pooled form's scratch
-    const bool pooled_reset = SCG_WG_RESET && (p.flags & F_AUTO_RESET) && (p.flags & F_RAND_INIT);
+    const bool pooled_reset = SCG_WG_RESET && (p.flags & F_AUTO_RESET) && (p.flags & F_RAND_INIT) && !(p.flags & F_RAND_GENERAL);
     if (pooled_reset) {
         // list counters of the workgroup-pooled reset; visible to every wave after the first barrier each of them takes
         // (the table-staging barrier below, or the first barrier inside reset_state_wg -- so zero BOTH before any of them)
@@ -1098,7 +994,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
             float xr[NX];
             if (wg_full) reset_state_wg<NX>(p, tb, io.reset_state, ld, i, serial, need_reset, wg_scratch, kstep & 1, xr);
 #if SCG_WG_RESET
-            else if (need_reset) reset_state_of<NX>(p, tb, io.reset_state, ld, i, serial, xr);     // ragged last workgroup / no randomisation
+            else if (need_reset) reset_state_of<NX, EXTRA>(p, tb, io.reset_state, ld, i, serial, xr);   // ragged last workgroup / no randomisation / non-uniform draws
 #else
             else reset_state_coop<NX>(p, tb, io.reset_state, ld, i, serial, need_reset, coop_scratch, xr);
 #endif
@@ -1364,7 +1260,7 @@ LaunchGeom step_geometry(const KParams& p, int system, int64_t n, int num_cus) {
 // Which instantiation covers this call.
 static uint32_t features_needed(const KParams& p, const scg_step_io& io) {
     const bool extra = io.inertial || io.action_disturbance || io.dynamics_force || io.obs_noise || io.obs || io.stats ||
-                       io.episode_id || p.dist || (p.flags & (F_NORMALIZED | F_GND | F_DRAG)) || !(p.flags & F_Q_DIAG);
+                       io.episode_id || p.dist || (p.flags & (F_NORMALIZED | F_GND | F_DRAG | F_RAND_GENERAL)) || !(p.flags & F_Q_DIAG);
     if (extra) return FT_TRACK | FT_CON | FT_EXTRA;
     uint32_t ft = 0;
     if (io.truncated || io.goal_reached || io.mse || io.terminal_record) ft |= FT_INFO;

@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include "scg_device.h"
 #include "scg_math.h"
+#include "scg_dynamics.h"
 
 namespace scg {
 
@@ -359,6 +360,67 @@ __global__ __launch_bounds__(256) void scg_loss_kernel(LossWeights w, const floa
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// linearised model: SymbolicModel.fc_linear_func (math_and_models/symbolic_systems.py:93-101)
+// ------------------------------------------------------------------------------------------
+// x_dot_linear(x_eval, u_eval; x, u) = f(x, u) + dfdx(x, u) (x_eval - x) + dfdu(x, u) (u_eval - u), one lane per env; all
+// four arguments and the result are SoA planes.  x_eval == nullptr evaluates at x_eval = 0, which yields the constant
+// term c of the affine ODE  z' = A z + c  that fd_linear_func (:102-107) integrates (see scg_discretize_exact).
+template <int SYS>
+__global__ __launch_bounds__(256) void scg_fc_linear_kernel(PhysT<float> shared, const float* __restrict__ x_eval,
+                                                            const float* __restrict__ u_eval,
+                                                            const float* __restrict__ state,
+                                                            const float* __restrict__ input,
+                                                            const float* __restrict__ inertial, float* __restrict__ out,
+                                                            int64_t ld, uint32_t n) {
+    constexpr int NX = Dim<SYS>::NX, NU = Dim<SYS>::NU;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        float x[NX], u[NU], dx[NX], du[NU];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) { x[j] = state[j * ld + i]; dx[j] = (x_eval ? x_eval[j * ld + i] : 0.0f) - x[j]; }
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { u[j] = input[j * ld + i]; du[j] = u_eval[j * ld + i] - u[j]; }
+        PhysT<float> c = shared;
+        if (inertial) {
+            float prop[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) prop[q] = inertial[q * ld + i];
+            c = phys_with<SYS>(shared, prop);
+        }
+        float A[NX][NX], B[NX][NU], f[NX];
+        jacobian<SYS>(c, x, u, A, B);
+        Inputs<SYS, float> in;
+        make_inputs<SYS, float>(c, u, 0.f, 0.f, 0.f, in);
+        f_eval<SYS, float>(c, in, x, f);
+#pragma unroll
+        for (int a = 0; a < NX; ++a) {
+            float v = f[a];
+#pragma unroll
+            for (int b = 0; b < NX; ++b) v = fmaf(A[a][b], dx[b], v);
+#pragma unroll
+            for (int b = 0; b < NU; ++b) v = fmaf(B[a][b], du[b], v);
+            out[a * ld + i] = v;
+        }
+    }
+}
+
+hipError_t launch_fc_linear(int system, const PhysT<float>& ph, const float* x_eval, const float* u_eval, const float* state,
+                            const float* input, const float* inertial, float* out, int64_t ld, int64_t n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    const dim3 grid((unsigned)blocks), block(256);
+    const uint32_t nn = (uint32_t)n;
+    switch (system) {
+        case SCG_QUAD_1D: hipLaunchKernelGGL(scg_fc_linear_kernel<SCG_QUAD_1D>, grid, block, 0, s, ph, x_eval, u_eval, state, input, inertial, out, ld, nn); break;
+        case SCG_QUAD_2D: hipLaunchKernelGGL(scg_fc_linear_kernel<SCG_QUAD_2D>, grid, block, 0, s, ph, x_eval, u_eval, state, input, inertial, out, ld, nn); break;
+        case SCG_QUAD_3D: hipLaunchKernelGGL(scg_fc_linear_kernel<SCG_QUAD_3D>, grid, block, 0, s, ph, x_eval, u_eval, state, input, inertial, out, ld, nn); break;
+        case SCG_CARTPOLE: hipLaunchKernelGGL(scg_fc_linear_kernel<SCG_CARTPOLE>, grid, block, 0, s, ph, x_eval, u_eval, state, input, inertial, out, ld, nn); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 template <int SYS>
 static hipError_t launch_lin_sys(const PhysT<float>& ph, const float* state, const float* input, const float* inertial,
                                  float* dfdx, float* dfdu, float disc_dt, int64_t ld, uint32_t n, bool direct,

@@ -160,6 +160,15 @@ class Engine:
                                                ld, n, self._stream()), 'scg_linearize')
         return A, B
 
+    def fc_linear(self, x_eval_soa, u_eval_soa, state_soa, input_soa, inertial_soa, n, ld):
+        """Batched fc_linear_func (symbolic_systems.py:93-101) on SoA planes -> [nx, ld] planes; x_eval_soa None = at 0."""
+        out = torch.empty((self.nx, ld), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _capi.check(self.lib.scg_fc_linear(self.handle, _capi.ptr(x_eval_soa), _capi.ptr(u_eval_soa), _capi.ptr(state_soa),
+                                               _capi.ptr(input_soa), _capi.ptr(inertial_soa), _capi.ptr(out), ld, n,
+                                               self._stream()), 'scg_fc_linear')
+        return out
+
     def quadratic_loss(self, state_soa, input_soa, xr, ur, Q, R, n, ld, want_grad=True):
         """Batched loss / l_x / l_u (symbolic_systems.py:94-123).  xr: [nx] vector or [nx, ld'] planes; ur likewise."""
         Qh = (C.c_double * (self.nx * self.nx))(*[float(v) for v in Q.reshape(-1)])

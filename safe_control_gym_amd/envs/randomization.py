@@ -1,0 +1,81 @@
+"""Distributions of the reset-time randomisation.
+
+The reference draws every randomised quantity with ``getattr(self.np_random, info['distrib'])(*args, **kwargs)``
+(/root/reference/safe_control_gym/envs/benchmark_env.py:297-307): any ``numpy.random.RandomState`` method name is legal in the
+yaml.  On the device the draw is a transform of one or two Philox uniforms per quantity (``scg_distribution`` in
+include/scg_rollout.h); this module maps the RandomState signatures of the supported methods onto it.  Methods that are
+not a transform of a fixed number of uniforms (``choice``, ``permutation``, ``multivariate_normal``, rejection samplers
+such as ``gamma`` / ``beta`` ...) raise ``NotImplementedError`` naming the method.
+"""
+from safe_control_gym_amd import _capi
+
+# method -> (kind, positional / keyword parameter names with RandomState's defaults)
+_SIGNATURES = {
+    'uniform': (_capi.SCG_RAND_UNIFORM, (('low', 0.0), ('high', 1.0))),
+    'normal': (_capi.SCG_RAND_NORMAL, (('loc', 0.0), ('scale', 1.0))),
+    'standard_normal': (_capi.SCG_RAND_NORMAL, ()),
+    'exponential': (_capi.SCG_RAND_EXPONENTIAL, (('scale', 1.0),)),
+    'laplace': (_capi.SCG_RAND_LAPLACE, (('loc', 0.0), ('scale', 1.0))),
+    'logistic': (_capi.SCG_RAND_LOGISTIC, (('loc', 0.0), ('scale', 1.0))),
+    'triangular': (_capi.SCG_RAND_TRIANGULAR, (('left', None), ('mode', None), ('right', None))),
+    'randint': (_capi.SCG_RAND_RANDINT, (('low', None), ('high', None))),
+}
+SUPPORTED = tuple(sorted(_SIGNATURES))
+
+
+def parse_distribution(info, what=''):
+    """``{'distrib': name, 'args': [...], **kwargs}`` -> ``(kind, low, high, (p0, p1, p2))``.
+    ``low`` / ``high`` are meaningful for ``uniform`` only; the other kinds read ``p``."""
+    info = dict(info)
+    name = info.pop('distrib')
+    args = list(info.pop('args', []))
+    if name not in _SIGNATURES:
+        raise NotImplementedError('[ERROR] distrib %r%s is not available on the device (supported: %s).'
+                                  % (name, ' for ' + what if what else '', ', '.join(SUPPORTED)))
+    kind, params = _SIGNATURES[name]
+    info.pop('size', None)
+    if len(args) > len(params):
+        raise TypeError('[ERROR] %s() takes at most %d positional arguments (%d given)%s.'
+                        % (name, len(params), len(args), ' for ' + what if what else ''))
+    vals = {}
+    for k, (pname, default) in enumerate(params):
+        if k < len(args):
+            vals[pname] = args[k]
+            if pname in info:
+                raise TypeError('[ERROR] %s() got multiple values for argument %r.' % (name, pname))
+        elif pname in info:
+            vals[pname] = info.pop(pname)
+        else:
+            vals[pname] = default
+    if info:
+        raise TypeError('[ERROR] %s() got unexpected keyword arguments %s.' % (name, sorted(info)))
+    if name == 'randint' and vals['high'] is None:                       # randint(low) draws from [0, low)
+        vals['low'], vals['high'] = 0.0, vals['low']
+    if any(v is None for v in vals.values()):
+        raise TypeError('[ERROR] %s() is missing a required argument%s.' % (name, ' for ' + what if what else ''))
+    v = [float(vals[p]) for p, _ in params]
+    if name == 'standard_normal':
+        v = [0.0, 1.0]
+    if kind == _capi.SCG_RAND_UNIFORM:
+        return kind, v[0], v[1], (0.0, 0.0, 0.0)
+    if kind in (_capi.SCG_RAND_NORMAL, _capi.SCG_RAND_LAPLACE, _capi.SCG_RAND_LOGISTIC) and v[1] < 0:
+        raise ValueError('[ERROR] scale < 0 in %s()%s.' % (name, ' for ' + what if what else ''))
+    if kind == _capi.SCG_RAND_EXPONENTIAL and v[0] < 0:
+        raise ValueError('[ERROR] scale < 0 in exponential().')
+    if kind == _capi.SCG_RAND_TRIANGULAR and not (v[0] <= v[1] <= v[2] and v[0] < v[2]):
+        raise ValueError('[ERROR] triangular() needs left <= mode <= right and left < right.')
+    if kind == _capi.SCG_RAND_RANDINT and not v[0] < v[1]:
+        raise ValueError('[ERROR] randint() needs low < high.')
+    return kind, 0.0, 0.0, tuple(v + [0.0] * (3 - len(v)))
+
+
+def lower_bound(kind, low, p):
+    """The smallest value the draw can take (-inf when unbounded): used for the reference's positivity check of
+    randomised inertial properties (quadrotor.py:464-465)."""
+    if kind == _capi.SCG_RAND_UNIFORM:
+        return low
+    if kind == _capi.SCG_RAND_EXPONENTIAL:
+        return 0.0
+    if kind in (_capi.SCG_RAND_TRIANGULAR, _capi.SCG_RAND_RANDINT):
+        return p[0]
+    return float('-inf')

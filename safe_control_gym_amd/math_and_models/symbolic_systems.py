@@ -3,7 +3,7 @@
 Mirrors the public surface of the reference's CasADi ``SymbolicModel``
 (math_and_models/symbolic_systems.py:8-123) without CasADi: ``nx, nu, ny, dt``,
 ``fc_func`` (:68), ``fd_func`` (:70-73), ``g_func`` (:75), ``df_func`` (:84-86), ``dg_func``
-(:89-91), ``loss`` (:119-123).  Every function takes keyword arrays like the CasADi ``Function``
+(:89-91), ``fc_linear_func`` / ``fd_linear_func`` / ``g_linear_func`` (:93-112), ``loss`` (:119-123).  Every function takes keyword arrays like the CasADi ``Function``
 objects do and returns a dict with the same output names; inputs may carry leading batch
 dimensions (``x`` of shape (..., nx)).
 
@@ -145,6 +145,46 @@ class AnalyticModel:
         A = np.stack([np.asarray(self._jac[0](xi, ui), dtype=np.float64) for xi, ui in zip(xf, uf)])
         B = np.stack([np.asarray(self._jac[1](xi, ui), dtype=np.float64) for xi, ui in zip(xf, uf)])
         return {'dfdx': A.reshape(lead + (self.nx, self.nx)), 'dfdu': B.reshape(lead + (self.nx, self.nu))}
+
+    # -- linearised model: symbolic_systems.py:93-112 ------------------------------------------
+    def fc_linear_func(self, x_eval, u_eval, x, u):
+        """``f(x, u) + dfdx (x_eval - x) + dfdu (u_eval - u)`` (:95-101)."""
+        if _is_device_tensor(x_eval) or _is_device_tensor(x):
+            return {'f_linear': self._backend().model_linear_dynamics(x_eval, u_eval, x, u)}
+        x_eval, u_eval = np.asarray(x_eval, dtype=np.float64), np.asarray(u_eval, dtype=np.float64)
+        x, u = np.asarray(x, dtype=np.float64), np.asarray(u, dtype=np.float64)
+        d = self.df_func(x, u)
+        return {'f_linear': self._f(x, u) + np.einsum('...ij,...j->...i', d['dfdx'], x_eval - x)
+                + np.einsum('...ij,...j->...i', d['dfdu'], u_eval - u)}
+
+    def fd_linear_func(self, x0, p):
+        """The linearised model integrated over ``dt`` from ``x0`` (= x_eval); ``p = [u_eval; x; u]`` as the CasADi
+        integrator takes it (:102-107).  The ODE is affine, so its flow comes from one matrix exponential (the reference
+        integrates it with CVODES)."""
+        nx, nu = self.nx, self.nu
+        if _is_device_tensor(x0):
+            return {'xf': self._backend().model_linear_step(x0, p[..., :nu], p[..., nu:nu + nx], p[..., nu + nx:])}
+        import scipy.linalg
+        x0, p = np.asarray(x0, dtype=np.float64), np.asarray(p, dtype=np.float64)
+        u_eval, x, u = p[..., :nu], p[..., nu:nu + nx], p[..., nu + nx:]
+        d = self.df_func(x, u)
+        c = self.fc_linear_func(np.zeros_like(x), u_eval, x, u)['f_linear']
+        lead = x0.shape[:-1]
+        A2, c2, z2 = d['dfdx'].reshape(-1, nx, nx), c.reshape(-1, nx), x0.reshape(-1, nx)
+        out = np.empty_like(z2)
+        for k in range(z2.shape[0]):
+            M = np.zeros((nx + 1, nx + 1))
+            M[:nx, :nx], M[:nx, nx] = A2[k], c2[k]
+            E = scipy.linalg.expm(M * self.dt)
+            out[k] = E[:nx, :nx] @ z2[k] + E[:nx, nx]
+        return {'xf': out.reshape(lead + (nx,))}
+
+    def g_linear_func(self, x_eval, u_eval, x, u):
+        """``y + dgdx (x_eval - x) + dgdu (u_eval - u)`` with ``y = x`` (:108-112): the observation model is the identity."""
+        if _is_device_tensor(x_eval):
+            return {'g_linear': x + (x_eval - x)}
+        x_eval, x = np.asarray(x_eval, dtype=np.float64), np.asarray(x, dtype=np.float64)
+        return {'g_linear': x + (x_eval - x)}
 
     # -- cost: quadrotor.py:682, symbolic_systems.py:114-123 ------------------------------------
     def loss(self, x, u, Xr, Ur, Q, R):

@@ -19,6 +19,7 @@ Groups written (inputs and the reference's outputs, float64):
   step_glue      before_step / _preprocess_control / extend_obs / _get_done / _get_reward (rl) / the mse statements of
                  _get_info / after_step                   envs/benchmark_env.py:394-463, quadrotor.py:815-842,886-913,956-993,1011-1025
   gae            compute_returns_and_advantages          controllers/ppo/ppo_utils.py:428-456
+  discretize     discretize_linear_system (exact and Euler; scipy.linalg.expm is importable)   controllers/mpc/mpc_utils.py:24-54
   normalization  RunningMeanStd, MeanStdNormalizer, RewardStdNormalizer                   math_and_models/normalization.py:17-190
 
 Run in the build container only (the reference never travels to the GPU box):
@@ -35,6 +36,8 @@ from copy import deepcopy
 from enum import Enum, IntEnum
 
 import numpy as np
+import scipy
+import scipy.linalg
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = '/root/reference/safe_control_gym'
@@ -135,7 +138,7 @@ def _tests_task(stmt):
 # ---------------------------------------------------------------------------------------------------------------------
 # the namespace every extracted piece runs in
 # ---------------------------------------------------------------------------------------------------------------------
-NS = {'np': NP, 'math': math, 'deepcopy': deepcopy, 'Enum': Enum, 'IntEnum': IntEnum, 'str': str}
+NS = {'np': NP, 'math': math, 'deepcopy': deepcopy, 'Enum': Enum, 'IntEnum': IntEnum, 'str': str, 'scipy': scipy}
 SOURCES = []
 SOURCES += top_level('envs/gym_pybullet_drones/quadrotor_utils.py', ['QuadType', 'cmd2pwm', 'pwm2rpm'], NS)
 SOURCES += top_level('envs/benchmark_env.py', ['Cost', 'Task'], NS)
@@ -144,6 +147,7 @@ SOURCES += top_level('envs/constraints.py', ['ConstrainedVariableType', 'Constra
                                              'BoundedConstraint', 'DefaultConstraint', 'SymmetricStateConstraint',
                                              'get_symbolic_constraint_models', 'ConstraintList', 'create_constraint_list'], NS)
 SOURCES += top_level('controllers/ppo/ppo_utils.py', ['compute_returns_and_advantages'], NS)
+SOURCES += top_level('controllers/mpc/mpc_utils.py', ['discretize_linear_system'], NS)
 SOURCES += top_level('math_and_models/normalization.py', ['RunningMeanStd', 'BaseNormalizer', 'MeanStdNormalizer',
                                                           'RewardStdNormalizer'], NS)
 SOURCES += methods('envs/benchmark_env.py', 'BenchmarkEnv', ['_generate_trajectory', '_get_coordinates', '_figure8', '_circle',
@@ -519,6 +523,23 @@ def gen_gae(rng):
     MANIFEST['groups']['gae'] = dict(cases=cases)
 
 
+def gen_discretize(rng):
+    cases = []
+    for k, (nx, nu, norm, dt) in enumerate([(12, 4, 8.0, 1 / 60), (6, 2, 40.0, 1 / 50), (4, 1, 2.0, 0.02), (2, 1, 300.0, 1 / 60),
+                                            (12, 4, 900.0, 1 / 30)]):
+        A = rng.normal(size=(6, nx, nx))
+        A *= norm / np.abs(A).sum(2).max(1)[:, None, None]
+        B = rng.normal(size=(6, nx, nu)) * [[[0.5]], [[30.0]], [[2000.0]], [[1.0]], [[5.0]], [[100.0]]]
+        for exact in (True, False):
+            out = [NS['discretize_linear_system'](A[i], B[i], dt, exact=exact) for i in range(6)]
+            put('discretize/%d/Ad_%s' % (k, 'exact' if exact else 'euler'), [o[0] for o in out])
+            put('discretize/%d/Bd_%s' % (k, 'exact' if exact else 'euler'), [o[1] for o in out])
+        put('discretize/%d/A' % k, A)
+        put('discretize/%d/B' % k, B)
+        cases.append(dict(nx=nx, nu=nu, dt=dt, norm_inf_A=norm))
+    MANIFEST['groups']['discretize'] = dict(cases=cases)
+
+
 def gen_normalization(rng):
     rms = NS['RunningMeanStd'](shape=(5,))
     batches, means, variances, counts = [], [], [], []
@@ -562,6 +583,7 @@ def main():
     gen_step_glue(rng)
     gen_gae(rng)
     gen_normalization(rng)
+    gen_discretize(rng)        # (last: earlier groups keep the random stream they were first written with)
     OUT['manifest'] = np.array(json.dumps(MANIFEST))
     np.savez_compressed(os.path.join(HERE, 'reference_numpy.npz'), **OUT)
     print('wrote %d arrays, %d reference symbols executed' % (len(OUT) - 1, len(SOURCES)))

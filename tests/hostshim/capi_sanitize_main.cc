@@ -236,6 +236,13 @@ static void check_next_row_entry_points() {
     EXPECT(scg_model_eval(h, f.data(), f.data(), nullptr, f.data(), nullptr, 8, 8, nullptr) == SCG_OK);
     EXPECT(scg_linearize(h, f.data(), f.data(), nullptr, f.data(), f.data(), -1.0, 8, 8, nullptr) == SCG_ERR_INVALID);
     EXPECT(scg_linearize(h, f.data(), f.data(), nullptr, f.data(), f.data(), 0.02, 8, 8, nullptr) == SCG_OK);
+    EXPECT(scg_fc_linear(h, nullptr, nullptr, f.data(), f.data(), nullptr, f.data(), 8, 8, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_fc_linear(h, nullptr, f.data(), f.data(), f.data(), nullptr, f.data(), 8, 8, nullptr) == SCG_OK);
+    EXPECT(scg_discretize_exact(f.data(), f.data(), 12, 5, 0.02, f.data(), f.data(), nullptr, nullptr, nullptr, 4, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_discretize_exact(f.data(), f.data(), 6, 2, 0.0, f.data(), f.data(), nullptr, nullptr, nullptr, 4, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_discretize_exact(f.data(), f.data(), 6, 2, 0.02, nullptr, nullptr, nullptr, nullptr, nullptr, 4, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_discretize_exact(f.data(), f.data(), 6, 2, 0.02, nullptr, nullptr, nullptr, nullptr, f.data(), 4, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_discretize_exact(f.data(), f.data(), 6, 2, 0.02, f.data(), f.data(), f.data(), nullptr, f.data(), 4, nullptr) == SCG_OK);
     EXPECT(scg_quadratic_loss(h, d.data(), d.data(), f.data(), f.data(), f.data(), 4, f.data(), 0, f.data(), nullptr, nullptr, 8, 8, nullptr) == SCG_ERR_INVALID);
     EXPECT(scg_quadratic_loss(h, d.data(), d.data(), f.data(), f.data(), f.data(), 0, f.data(), 0, f.data(), nullptr, nullptr, 8, 8, nullptr) == SCG_OK);
     EXPECT(scg_gae(f.data(), f.data(), f.data(), nullptr, f.data(), f.data(), f.data(), nullptr, nullptr, 0, 8, 8, 0.99f, 0.95f, 1, nullptr) == SCG_ERR_INVALID);

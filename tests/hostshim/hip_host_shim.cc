@@ -59,6 +59,8 @@ hipError_t launch_gae(const float*, const float*, const float*, const float*, co
 hipError_t launch_normalize(float*, const double*, int, int64_t, int64_t, float, hipStream_t) { ++g_shim.launches; return hipSuccess; }
 hipError_t launch_model_eval(int, const KParams&, const KTables*, const float*, const float*, const float*, float*, float*, int64_t, int64_t, hipStream_t) { ++g_shim.launches; return hipSuccess; }
 hipError_t launch_linearize(int, const PhysT<float>&, const float*, const float*, const float*, float*, float*, float, int64_t, int64_t, hipStream_t) { ++g_shim.launches; return hipSuccess; }
+hipError_t launch_fc_linear(int, const PhysT<float>&, const float*, const float*, const float*, const float*, const float*, float*, int64_t, int64_t, hipStream_t) { ++g_shim.launches; return hipSuccess; }
+hipError_t launch_discretize_exact(const float*, const float*, int, int, float, float*, float*, const float*, const float*, float*, int64_t, int, hipStream_t) { ++g_shim.launches; return hipSuccess; }
 hipError_t launch_loss(int, const double*, const double*, const float*, const float*, const float*, int64_t, const float*, int64_t, float*, float*, float*, int64_t, int64_t, hipStream_t) { ++g_shim.launches; return hipSuccess; }
 hipError_t launch_mean_std_normalize(const float*, float*, int, int64_t, int64_t, int64_t, const double*, double*, double*, float, double, hipStream_t) { ++g_shim.launches; return hipSuccess; }
 hipError_t launch_reward_normalize(const float*, const uint8_t*, float*, float*, int64_t, const double*, double*, double*, float, float, double, int, hipStream_t) { ++g_shim.launches; return hipSuccess; }
