@@ -168,7 +168,8 @@ REF_CONSTRAINTS = {
     'quadratic_constraint': RefQuadratic,
     'bounded_constraint': RefBounded,
     'default_constraint': RefDefault,
-    'symmetric_state_constraint': RefSymmetricState,   # cartpole-only in upstream
+    'symmetric_state': RefSymmetricState,              # cartpole-only in upstream
+    'symmetric_state_constraint': RefSymmetricState,
 }
 
 

@@ -589,6 +589,9 @@ enum Feat : uint32_t {
     FT_EXTRA = 4u,   // everything else: disturbances, separate obs buffer (+noise, +goal horizon), per-env inertial
                      // properties, stats sums, non-diagonal Q or R, normalised action space.  In this tier
                      // FT_TRACK / FT_CON are run-time decisions again.
+    FT_DIST = 16u,   // FT_INFO + the passive disturbances drawn in the kernel (scg_set_disturbances: action / dynamics / observation
+                     // noise, the separate obs buffer they need, per-episode offsets) and nothing else of FT_EXTRA: the common
+                     // "noisy env" configuration without the run-time branches of the catch-all tier
     FT_INFO = 8u,    // the per-step info outputs of the default API (info_level='full'): mse / goal_reached /
                      // truncated / terminal_record (terminal obs = the state: obs aliases it in this tier).  A tier of its
                      // own because it is what make() gives by default: 43 us in the EXTRA tier at 2^20 envs.
@@ -615,7 +618,8 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                                                           const RolloutArgs ro) {
     constexpr int NX = Dim<SYS>::NX, NU = Dim<SYS>::NU, NV = NX + NU;
     constexpr bool EXTRA = (FT & FT_EXTRA) != 0;
-    constexpr bool INFO = (FT & (FT_EXTRA | FT_INFO)) != 0;
+    constexpr bool DIST = (FT & (FT_EXTRA | FT_DIST)) != 0;
+    constexpr bool INFO = (FT & (FT_EXTRA | FT_INFO | FT_DIST)) != 0;
     constexpr bool STRIDED = MODE == MODE_STRIDED, FUSED = MODE == MODE_FUSED;
     extern __shared__ __align__(16) float s_ref[];
 
@@ -728,7 +732,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         for (int j = 0; j < NU; ++j) act_noise[j] = 0.f;
 #pragma unroll
         for (int j = 0; j < NX; ++j) obs_noise[j] = 0.f;
-        if (EXTRA && p.dist) {
+        if (DIST && p.dist) {
             const uint32_t episode = io.episode_id ? ldp(io.episode_id, i4) : 0u;
             apply_disturbances<NU>(p, p.dist, SCG_DIST_ACTION, 0, i, serial, episode, t, act_noise);
             constexpr int ND = SYS == SCG_QUAD_3D ? 3 : (SYS == SCG_QUAD_2D ? 2 : 1);
@@ -772,7 +776,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                     th = (RT)fmin(fmax(ad, tb->act_low_d[j]), tb->act_high_d[j]);
                 }
                 if (EXTRA && io.action_disturbance) th += (RT)ldp(PL(io.action_disturbance, j), i4);   // :835-838
-                if (EXTRA) th += (RT)act_noise[j];
+                if (DIST) th += (RT)act_noise[j];
                 if (SYS != SCG_CARTPOLE && (p.flags & F_MOTOR_MAP)) {
                     // cmd2pwm / pwm2rpm / KF rpm^2  (quadrotor_utils.py:38-50,66; base_aviary.py:420)
                     RT pwm;
@@ -963,7 +967,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
 #pragma unroll
                     for (int j = 0; j < NX; ++j) {
                         float o = x[j];
-                        if (EXTRA) o += obs_noise[j];
+                        if (DIST) o += obs_noise[j];
                         if (EXTRA && io.obs_noise) o += ldp(PL(io.obs_noise, j), i4);
                         rec[j] = o;
                     }
@@ -1007,8 +1011,8 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                 }
                 t_out = 0;
                 epr = 0.f; epl = 0;
-                if (EXTRA && io.episode_id) stp(io.episode_id, i4, serial);
-                if (EXTRA && p.dist) {
+                if (DIST && io.episode_id) stp(io.episode_id, i4, serial);
+                if (DIST && p.dist) {
                     // the observation handed back is the one reset() computes: counter 0, its own draws (:497)
 #pragma unroll
                     for (int j = 0; j < NX; ++j) obs_noise[j] = 0.f;
@@ -1041,14 +1045,14 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         }
 
         // ---- _get_observation + extend_obs (quadrotor.py:878-884, benchmark_env.py:406-420)
-        if (EXTRA && io.obs) {
+        if (DIST && io.obs) {
 #pragma unroll
             for (int j = 0; j < NX; ++j) {
                 float o = x[j] + obs_noise[j];
-                if (io.obs_noise) o += ldp(PL(io.obs_noise, j), i4);
+                if (EXTRA && io.obs_noise) o += ldp(PL(io.obs_noise, j), i4);
                 stp(PL(io.obs, j), i4, o);
             }
-            if (p.obs_goal_horizon > 0) {
+            if (EXTRA && p.obs_goal_horizon > 0) {
                 if (tracking) {
                     // extend_obs(obs, ctrl_step_counter + 1) is evaluated before the counter increment:
                     // rows min(t + 1 + k, T-1); a lane that auto-reset reports the reset observation, whose
@@ -1259,11 +1263,12 @@ LaunchGeom step_geometry(const KParams& p, int system, int64_t n, int num_cus) {
 
 // Which instantiation covers this call.
 static uint32_t features_needed(const KParams& p, const scg_step_io& io) {
-    const bool extra = io.inertial || io.action_disturbance || io.dynamics_force || io.obs_noise || io.obs || io.stats ||
-                       io.episode_id || p.dist || (p.flags & (F_NORMALIZED | F_GND | F_DRAG | F_RAND_GENERAL)) || !(p.flags & F_Q_DIAG);
+    const bool extra = io.inertial || io.action_disturbance || io.dynamics_force || io.obs_noise || io.stats ||
+                       p.obs_goal_horizon > 0 || (p.flags & (F_NORMALIZED | F_GND | F_DRAG | F_RAND_GENERAL)) || !(p.flags & F_Q_DIAG);
     if (extra) return FT_TRACK | FT_CON | FT_EXTRA;
     uint32_t ft = 0;
-    if (io.truncated || io.goal_reached || io.mse || io.terminal_record) ft |= FT_INFO;
+    if (p.dist || io.obs || io.episode_id) ft |= FT_DIST;                 // in-kernel disturbances only: their own tier
+    else if (io.truncated || io.goal_reached || io.mse || io.terminal_record) ft |= FT_INFO;
     if (p.flags & F_TRACKING) ft |= FT_TRACK;
     if (p.n_con_rows > 0) ft |= FT_CON;
     return ft;
@@ -1291,6 +1296,11 @@ static void launch_step_ft(uint32_t ft, const LaunchGeom& g, const KParams& p, c
         case FT_INFO | FT_TRACK: SCG_LAUNCH(FT_INFO | FT_TRACK); break;
         case FT_INFO | FT_CON: SCG_LAUNCH(FT_INFO | FT_CON); break;
         case FT_INFO | FT_TRACK | FT_CON: SCG_LAUNCH(FT_INFO | FT_TRACK | FT_CON); break;
+        // the disturbance tier exists for the float state only (the precise mode takes the catch-all tier: fewer kernels to build)
+        case FT_DIST: if constexpr (!COMP) { SCG_LAUNCH(FT_DIST); break; }
+        case FT_DIST | FT_TRACK: if constexpr (!COMP) { SCG_LAUNCH(FT_DIST | FT_TRACK); break; }
+        case FT_DIST | FT_CON: if constexpr (!COMP) { SCG_LAUNCH(FT_DIST | FT_CON); break; }
+        case FT_DIST | FT_TRACK | FT_CON: if constexpr (!COMP) { SCG_LAUNCH(FT_DIST | FT_TRACK | FT_CON); break; }
         default: SCG_LAUNCH(FT_TRACK | FT_CON | FT_EXTRA); break;
     }
 #undef SCG_LAUNCH
@@ -1306,7 +1316,7 @@ static void launch_step_sys(LaunchGeom g, const KParams& p, const scg_step_io& i
 
 // Fused multi-step rollout: lean tiers, float state, table gathered from global memory, exact-cover grid.
 bool fused_rollout_ok(const KParams& p, const scg_step_io& io) {
-    return !(features_needed(p, io) & (FT_EXTRA | FT_INFO)) && !io.state_lo && !(p.flags & F_REF_IN_LDS);
+    return !(features_needed(p, io) & (FT_EXTRA | FT_INFO | FT_DIST)) && !io.state_lo && !(p.flags & F_REF_IN_LDS);
 }
 
 template <int SYS>

@@ -177,7 +177,7 @@ SOURCES += method_statements('envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor
 def GENERAL_CONSTRAINTS():
     return {'linear_constraint': NS['LinearConstraint'], 'quadratic_constraint': NS['QuadraticContstraint'],
             'bounded_constraint': NS['BoundedConstraint'], 'default_constraint': NS['DefaultConstraint'],
-            'symmetric_state_constraint': NS['SymmetricStateConstraint']}
+            'symmetric_state': NS['SymmetricStateConstraint']}
 
 
 # constants of the reference's vehicle (assets/cf2x.urdf:5,12-13; base_aviary.py:90,100-147)
@@ -349,7 +349,7 @@ CONSTRAINT_CASES = [
         {'constraint_form': 'bounded_constraint', 'constrained_variable': 'state', 'lower_bounds': [0.2, -1.0],
          'upper_bounds': [1.8, 1.0], 'tolerance': [0.05, 0.05, 0.05, 0.05], 'strict': True}]),
     dict(name='cartpole_symmetric', quad_type='cartpole', specs=[
-        {'constraint_form': 'symmetric_state_constraint', 'constrained_variable': 'state', 'active_dims': [0, 2], 'bound': [1.0, 0.2],
+        {'constraint_form': 'symmetric_state', 'constrained_variable': 'state', 'active_dims': [0, 2], 'bound': [1.0, 0.2],
          'tolerance': [0.1, 0.02]}]),
 ]
 
@@ -385,7 +385,7 @@ def gen_constraints(rng):
         env = constraint_env(c)
         specs = deepcopy(c['specs'])
         for s in specs:                                   # the yaml loader hands lists; the classes take them as they are
-            if s['constraint_form'] == 'symmetric_state_constraint':
+            if s['constraint_form'] == 'symmetric_state':
                 s['bound'] = np.array(s['bound'], dtype=float)     # `-bound` in the constructor needs an array (constraints.py:393)
         cl = NS['create_constraint_list'](specs, GENERAL_CONSTRAINTS(), env)
         xs, us = sample_states(rng, env, 24)

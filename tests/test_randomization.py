@@ -141,6 +141,6 @@ def test_device_draw_statistics_and_inertial_distributions(gpu):
     assert (props[:, 3] == np.float32(1e-3 * 2.17e-5)).sum() > 100          # Izz ~ N(nominal, nominal): ~16 % floored
     assert props.min() > 0
     with pytest.raises(ValueError, match='negative'):
-        scg.make('quadrotor', quad_type=3, num_envs=8, device='cuda', randomized_inertial_prop=True,
+        scg.make('quadrotor', quad_type=3, num_envs=8, device='cuda', randomized_inertial_prop=True, task='traj_tracking',
                  inertial_prop_randomization_info={'M': {'distrib': 'triangular', 'left': -0.05, 'mode': 0.0, 'right': 0.01}}).reset()
     env.close()
