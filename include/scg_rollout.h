@@ -183,7 +183,7 @@ typedef struct scg_step_io {
                                         cart_mass, -); read every step, re-drawn on auto-reset when
                                         cfg.randomized_inertial */
     float* state;                    /* [nx][ld] */
-    float* state_lo;                 /* nullable [nx][ld] compensation residual (state = hi + lo) */
+    float* state_lo;                 /* nullable [nx][ld] (or [6][ld], see state_lo_kind) compensation residual (state = hi + lo) */
     int32_t* step_count;             /* [n] ctrl_step_counter */
     float* ep_return;                /* nullable [n] running episode return (record_episode_statistics.py:145) */
     int32_t* ep_length;              /* nullable [n]; NULL: the episode length is read off step_count (the two are equal
@@ -214,7 +214,10 @@ typedef struct scg_step_io {
                                         0 sum reward, 1 #done, 2 #violation, 3 sum finished returns,
                                         4 sum finished lengths, 5 #truncated, 6-7 reserved */
     uint32_t reset_serial;           /* Philox counter word for resets happening in this call */
-    uint32_t reserved1;
+    uint32_t state_lo_kind;          /* which states state_lo holds residuals for: 0 = all nx (planes [nx][ld]); 1 = the
+                                        rotational chain of the 3-D quadrotor only, states 6..11 as planes [6][ld] -- positions
+                                        and velocities are then integrated in float32, attitude and rates in float64
+                                        ("attitude" precise mode: 48 B per env-step less; lean and info tiers only) */
 } scg_step_io;
 
 /* One entry of a DisturbanceList (envs/disturbances.py:46-84), evaluated inside the step kernel.

@@ -90,7 +90,7 @@ class ScgStepIO(C.Structure):
         ('obs', _fp), ('reward', _fp), ('done', _fp), ('constraint_values', _fp),
         ('constraint_violation', _fp), ('truncated', _fp), ('goal_reached', _fp), ('mse', _fp),
         ('terminal_record', _fp), ('terminal_stride', C.c_int64), ('stats', _fp),
-        ('reset_serial', C.c_uint32), ('reserved1', C.c_uint32),
+        ('reset_serial', C.c_uint32), ('state_lo_kind', C.c_uint32),
     ]
 
 

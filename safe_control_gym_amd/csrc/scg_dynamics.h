@@ -162,4 +162,65 @@ __device__ __forceinline__ void integrate(const PhysT<T>& c, uint32_t flags, con
     for (int j = 0; j < NX; ++j) inc[j] = h6 * (acc[j] + k[j]);
 }
 
+// ---- mixed-precision step of the 3-D quadrotor ("attitude" precise mode) ---------------------------------------------
+// The open-loop drift of the float32 step is born in the rotational chain (torque -> rate -> attitude) and amplified by the
+// thrust direction; the translational chain only integrates it (tools/precise_mode_study.py: float32 positions and
+// velocities + float64 attitude and rates hold 2e-6 over 1000 open-loop steps, float32 everything 2e-1).  So: attitude and
+// rates (states 6..11) in double -- hi + lo float32 planes in memory --, positions and velocities (states 0..5) in float,
+// the acceleration  R(:, 2) T/m  evaluated in double from the double attitude and rounded once.
+__device__ __forceinline__ void f_mixed3d(const PhysT<double>& c, const Inputs<SCG_QUAD_3D, double>& in, const float (&xt)[6],
+                                          const double (&xa)[6], float (&dt)[6], double (&da)[6]) {
+    double sph, cph, sth, cth, sps, cps;
+    Real<double>::sincos(xa[0], sph, cph);
+    Real<double>::sincos(xa[1], sth, cth);
+    Real<double>::sincos(xa[2], sps, cps);
+    const double P = xa[3], Q = xa[4], R = xa[5];
+    const double sthcph = sth * cph;
+    dt[0] = xt[1];
+    dt[1] = (float)fma(fma(cps, sthcph, sps * sph), in.Tm, in.ax);
+    dt[2] = xt[3];
+    dt[3] = (float)fma(fma(sps, sthcph, -(cps * sph)), in.Tm, in.ay);
+    dt[4] = xt[5];
+    dt[5] = (float)fma(cth * cph, in.Tm, in.az);
+    const double rcth = 1.0 / cth;
+    const double w = fma(sph, Q, cph * R);
+    da[0] = fma(sth * rcth, w, P);
+    da[1] = fma(cph, Q, -(sph * R));
+    da[2] = w * rcth;
+    da[3] = fma(-c.cxx, Q * R, in.mx);
+    da[4] = fma(-c.cyy, R * P, in.my);
+    da[5] = fma(-c.czz, P * Q, in.mz);
+}
+
+__device__ __forceinline__ void integrate_mixed3d(const PhysT<double>& c, uint32_t flags, const Inputs<SCG_QUAD_3D, double>& in,
+                                                  float (&xt)[6], double (&xa)[6]) {
+    const double h = c.h;
+    const float hf = (float)h;
+    float kt[6];
+    double ka[6];
+    f_mixed3d(c, in, xt, xa, kt, ka);
+    if (flags & F_EULER) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { xt[j] = fmaf(hf, kt[j], xt[j]); xa[j] = fma(h, ka[j], xa[j]); }
+        return;
+    }
+    float st[6], at[6];
+    double sa[6], aa[6];
+    const double hh = 0.5 * h;
+    const float hhf = 0.5f * hf;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { at[j] = kt[j]; aa[j] = ka[j]; st[j] = fmaf(hhf, kt[j], xt[j]); sa[j] = fma(hh, ka[j], xa[j]); }
+    f_mixed3d(c, in, st, sa, kt, ka);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { at[j] = fmaf(2.0f, kt[j], at[j]); aa[j] = fma(2.0, ka[j], aa[j]); st[j] = fmaf(hhf, kt[j], xt[j]); sa[j] = fma(hh, ka[j], xa[j]); }
+    f_mixed3d(c, in, st, sa, kt, ka);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { at[j] = fmaf(2.0f, kt[j], at[j]); aa[j] = fma(2.0, ka[j], aa[j]); st[j] = fmaf(hf, kt[j], xt[j]); sa[j] = fma(h, ka[j], xa[j]); }
+    f_mixed3d(c, in, st, sa, kt, ka);
+    const double h6 = h * (1.0 / 6.0);
+    const float h6f = (float)h6;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { xt[j] = fmaf(h6f, at[j] + kt[j], xt[j]); xa[j] = fma(h6, aa[j] + ka[j], xa[j]); }
+}
+
 }  // namespace scg

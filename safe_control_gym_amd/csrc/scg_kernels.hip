@@ -610,7 +610,7 @@ struct RolloutArgs {
 };
 constexpr int MODE_SINGLE = 0, MODE_STRIDED = 1, MODE_FUSED = 2;
 
-template <int SYS, bool COMP, uint32_t FT, int MODE>
+template <int SYS, int COMP, uint32_t FT, int MODE>
 __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io,
                                                           const KTables* __restrict__ tb,
                                                           const ConTable* __restrict__ ct,
@@ -621,6 +621,12 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
     constexpr bool DIST = (FT & (FT_EXTRA | FT_DIST)) != 0;
     constexpr bool INFO = (FT & (FT_EXTRA | FT_INFO | FT_DIST)) != 0;
     constexpr bool STRIDED = MODE == MODE_STRIDED, FUSED = MODE == MODE_FUSED;
+    // COMP: 0 float state; 1 precise mode, every state as hi + lo float32 planes, float64 integration; 2 "attitude" precise
+    // mode (3-D quadrotor): residual planes for the rotational chain only (states 6..11 <-> state_lo planes 0..5), see
+    // integrate_mixed3d
+    static_assert(COMP != 2 || SYS == SCG_QUAD_3D, "the attitude-only residual planes are defined for the 3-D quadrotor");
+    constexpr int NLO = COMP == 1 ? NX : (COMP == 2 ? 6 : 1);        // residual planes
+    constexpr int LO0 = COMP == 2 ? NX - 6 : 0;                       // state dim of residual plane 0
     extern __shared__ __align__(16) float s_ref[];
 
     const bool tracking = EXTRA ? ((p.flags & F_TRACKING) != 0) : ((FT & FT_TRACK) != 0);
@@ -643,7 +649,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
     // Per-lane inputs of one env.  With SCG_PREFETCH the next grid-stride iteration's inputs are
     // requested before this iteration's arithmetic, so their HBM latency hides under ~1200 VALU ops.
     struct LaneIn {
-        float x[NX], a_raw[NU], xlo[COMP ? NX : 1];
+        float x[NX], a_raw[NU], xlo[NLO];
         int t, epl;
         float epr, fx, fy, fz;
     };
@@ -671,7 +677,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         L.t = ldp(io.step_count, b4);                                       // ctrl_step_counter (pre-increment)
         if (COMP) {
 #pragma unroll
-            for (int j = 0; j < NX; ++j) L.xlo[j] = ldp(PL(io.state_lo, j), b4);
+            for (int j = 0; j < NLO; ++j) L.xlo[j] = ldp(PL(io.state_lo, j), b4);
         }
         L.epr = 0.f; L.epl = 0;
         if (io.ep_return) L.epr = ldp(io.ep_return, b4);
@@ -708,7 +714,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         const bool last = !FUSED || (kstep + 1 >= ro.steps);         // outputs are stored after the last fused step
         const uint32_t serial = io.reset_serial + (FUSED ? (uint32_t)kstep : 0u);
         // ---- this lane's inputs (NX+NU+1 independent 256-B wave transactions were issued together)
-        float x[NX], a_raw[NU], xlo[COMP ? NX : 1];
+        float x[NX], a_raw[NU], xlo[NLO];
 #pragma unroll
         for (int j = 0; j < NX; ++j) x[j] = cur.x[j];
         if (FUSED && kstep > 0) {
@@ -721,7 +727,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         }
         if (COMP) {
 #pragma unroll
-            for (int j = 0; j < NX; ++j) xlo[j] = cur.xlo[j];
+            for (int j = 0; j < NLO; ++j) xlo[j] = cur.xlo[j];
         }
         const int t = cur.t;
         float epr = cur.epr; int epl = cur.epl;
@@ -803,7 +809,20 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                 }
             };
             if (!aero) make_inputs<SYS, RT>(ph, u, efx, efy, efz, in);
-            if (sizeof(RT) == 8) {
+            if constexpr (COMP == 2) {
+                // attitude precise mode: float translational chain, double rotational chain (no aero terms in this mode)
+                float xt[6];
+                double xa[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { xt[j] = x[j]; xa[j] = (double)x[LO0 + j] + (double)xlo[j]; }
+                for (int s = 0; s < p.substeps; ++s) integrate_mixed3d(ph, p.flags, in, xt, xa);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    x[j] = xt[j];
+                    x[LO0 + j] = (float)xa[j];
+                    xlo[j] = (float)(xa[j] - (double)x[LO0 + j]);
+                }
+            } else if (sizeof(RT) == 8) {
                 RT xd[NX];
 #pragma unroll
                 for (int j = 0; j < NX; ++j) xd[j] = (RT)x[j] + (RT)xlo[COMP ? j : 0];
@@ -844,7 +863,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                 for (int j = 0; j < NX; ++j) x[j] = (float)xs[j];
             }
         };
-        if constexpr (COMP) advance(double{}, tb->phd);
+        if constexpr (COMP != 0) advance(double{}, tb->phd);
         else advance(float{}, p.ph);
 
         // ---- error to the goal of this step: X_GOAL (stabilisation) or X_GOAL[min(t, T-1)]
@@ -1007,7 +1026,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                 for (int j = 0; j < NX; ++j) x[j] = xr[j];
                 if (COMP) {
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) xlo[j] = 0.f;
+                    for (int j = 0; j < NLO; ++j) xlo[j] = 0.f;
                 }
                 t_out = 0;
                 epr = 0.f; epl = 0;
@@ -1033,7 +1052,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
             for (int j = 0; j < NX; ++j) stp(PLS(io.state, j), i4, x[j]);
             if (COMP) {
 #pragma unroll
-                for (int j = 0; j < NX; ++j) stp(PLS(io.state_lo, j), i4, xlo[j]);
+                for (int j = 0; j < NLO; ++j) stp(PLS(io.state_lo, j), i4, xlo[j]);
             }
             stp(io.step_count, i4, t_out);
             if (io.ep_return) stp(io.ep_return, i4, epr);
@@ -1274,8 +1293,8 @@ static uint32_t features_needed(const KParams& p, const scg_step_io& io) {
     return ft;
 }
 
-template <int SYS, bool COMP>
-static void launch_step_ft(uint32_t ft, const LaunchGeom& g, const KParams& p, const scg_step_io& io,
+template <int SYS, int COMP>
+static bool launch_step_ft(uint32_t ft, const LaunchGeom& g, const KParams& p, const scg_step_io& io,
                            const KTables* tb, const ConTable* ct, const float* ref, uint32_t n, hipStream_t s) {
 #define SCG_LAUNCH(FTV)                                                                                   \
     do {                                                                                                  \
@@ -1297,21 +1316,30 @@ static void launch_step_ft(uint32_t ft, const LaunchGeom& g, const KParams& p, c
         case FT_INFO | FT_CON: SCG_LAUNCH(FT_INFO | FT_CON); break;
         case FT_INFO | FT_TRACK | FT_CON: SCG_LAUNCH(FT_INFO | FT_TRACK | FT_CON); break;
         // the disturbance tier exists for the float state only (the precise mode takes the catch-all tier: fewer kernels to build)
-        case FT_DIST: if constexpr (!COMP) { SCG_LAUNCH(FT_DIST); break; }
-        case FT_DIST | FT_TRACK: if constexpr (!COMP) { SCG_LAUNCH(FT_DIST | FT_TRACK); break; }
-        case FT_DIST | FT_CON: if constexpr (!COMP) { SCG_LAUNCH(FT_DIST | FT_CON); break; }
-        case FT_DIST | FT_TRACK | FT_CON: if constexpr (!COMP) { SCG_LAUNCH(FT_DIST | FT_TRACK | FT_CON); break; }
-        default: SCG_LAUNCH(FT_TRACK | FT_CON | FT_EXTRA); break;
+        case FT_DIST: if constexpr (COMP == 0) { SCG_LAUNCH(FT_DIST); break; }
+        case FT_DIST | FT_TRACK: if constexpr (COMP == 0) { SCG_LAUNCH(FT_DIST | FT_TRACK); break; }
+        case FT_DIST | FT_CON: if constexpr (COMP == 0) { SCG_LAUNCH(FT_DIST | FT_CON); break; }
+        case FT_DIST | FT_TRACK | FT_CON: if constexpr (COMP == 0) { SCG_LAUNCH(FT_DIST | FT_TRACK | FT_CON); break; }
+        default:
+            // the attitude-only precise mode is built for the lean and info tiers (no disturbances / aero / per-env inertia)
+            if constexpr (COMP == 2) return false;
+            else SCG_LAUNCH(FT_TRACK | FT_CON | FT_EXTRA);
+            break;
     }
 #undef SCG_LAUNCH
+    return true;
 }
 
 template <int SYS>
-static void launch_step_sys(LaunchGeom g, const KParams& p, const scg_step_io& io, const KTables* tb,
+static bool launch_step_sys(LaunchGeom g, const KParams& p, const scg_step_io& io, const KTables* tb,
                             const ConTable* ct, const float* ref, uint32_t n, int num_cus, hipStream_t s) {
     const uint32_t ft = features_needed(p, io);
-    if (io.state_lo) launch_step_ft<SYS, true>(ft, g, p, io, tb, ct, ref, n, s);
-    else launch_step_ft<SYS, false>(ft, g, p, io, tb, ct, ref, n, s);
+    if (io.state_lo && io.state_lo_kind == 1) {
+        if constexpr (SYS == SCG_QUAD_3D) return launch_step_ft<SYS, 2>(ft, g, p, io, tb, ct, ref, n, s);
+        else return false;
+    }
+    if (io.state_lo) return launch_step_ft<SYS, 1>(ft, g, p, io, tb, ct, ref, n, s);
+    return launch_step_ft<SYS, 0>(ft, g, p, io, tb, ct, ref, n, s);
 }
 
 // Fused multi-step rollout: lean tiers, float state, table gathered from global memory, exact-cover grid.
@@ -1353,13 +1381,15 @@ hipError_t launch_rollout_fused(int system, const KParams& p, const scg_step_io&
 hipError_t launch_step(int system, const KParams& p, const scg_step_io& io, const KTables* tb,
                        const ConTable* ct, const float* ref, int64_t n, int num_cus, hipStream_t s) {
     const LaunchGeom g = step_geometry(p, system, n, num_cus);
+    bool ok = false;
     switch (system) {
-        case SCG_QUAD_1D: launch_step_sys<SCG_QUAD_1D>(g, p, io, tb, ct, ref, (uint32_t)n, num_cus, s); break;
-        case SCG_QUAD_2D: launch_step_sys<SCG_QUAD_2D>(g, p, io, tb, ct, ref, (uint32_t)n, num_cus, s); break;
-        case SCG_QUAD_3D: launch_step_sys<SCG_QUAD_3D>(g, p, io, tb, ct, ref, (uint32_t)n, num_cus, s); break;
-        case SCG_CARTPOLE: launch_step_sys<SCG_CARTPOLE>(g, p, io, tb, ct, ref, (uint32_t)n, num_cus, s); break;
+        case SCG_QUAD_1D: ok = launch_step_sys<SCG_QUAD_1D>(g, p, io, tb, ct, ref, (uint32_t)n, num_cus, s); break;
+        case SCG_QUAD_2D: ok = launch_step_sys<SCG_QUAD_2D>(g, p, io, tb, ct, ref, (uint32_t)n, num_cus, s); break;
+        case SCG_QUAD_3D: ok = launch_step_sys<SCG_QUAD_3D>(g, p, io, tb, ct, ref, (uint32_t)n, num_cus, s); break;
+        case SCG_CARTPOLE: ok = launch_step_sys<SCG_CARTPOLE>(g, p, io, tb, ct, ref, (uint32_t)n, num_cus, s); break;
         default: return hipErrorInvalidValue;
     }
+    if (!ok) return hipErrorInvalidValue;          // a feature combination no kernel is built for (validated by scg_step)
     return hipGetLastError();
 }
 

@@ -87,6 +87,8 @@ class Engine:
         io.ld = ld
         rec = bufs.get('terminal_record')
         io.terminal_stride = rec.shape[1] if rec is not None else 0
+        lo = bufs.get('state_lo')
+        io.state_lo_kind = 1 if (lo is not None and lo.shape[0] != self.nx) else 0      # [6, ld]: attitude-only residuals
         for name in self._IO_FIELDS:
             t = bufs.get(name)
             setattr(io, name, None if t is None else t.data_ptr())

@@ -333,7 +333,7 @@ def test_precise_mode_open_loop_1000_step_drift(gpu):
     x0[:, [0, 2, 4]] = [0.2, -0.1, 1.0]
     x0 = (x0 + rng.normal(size=(n, 12)) * 0.05).astype(np.float32).astype(np.float64)
     errs = {}
-    for comp in (False, True):
+    for comp in (False, True, 'attitude'):
         env, ref, sampler = make_pair(3, n, randomized_init=False, init_states=x0,
                                       engine_kwargs=dict(compensated_state=comp), **kw)
         sync_reset(env, ref, sampler)
@@ -345,7 +345,9 @@ def test_precise_mode_open_loop_1000_step_drift(gpu):
             out_e, out_r = sync_step(env, ref, sampler, f)
             assert not bool(out_e[2].any()) and not out_r[2].any()
             xe = env.state.double()
-            if comp:
+            if comp == 'attitude':                      # residual planes of states 6..11 only
+                xe[:, 6:] += env._bufs['state_lo'][:, :n].T.double()
+            elif comp:
                 xe = xe + env._bufs['state_lo'][:, :n].T.double()
             worst = max(worst, rel_err(xe.cpu().numpy(), np.stack([r.state for r in ref.envs])))
             if k + 1 in (100, 300, 1000):
@@ -353,10 +355,12 @@ def test_precise_mode_open_loop_1000_step_drift(gpu):
         errs[comp] = at
         xs = np.stack([r.state for r in ref.envs])
         assert np.abs(xs[:, [0, 2, 4]] - [0.2, -0.1, 1.0]).max() < 0.02, 'controller did not converge'
-    print('open-loop replay drift  float32: %s   precise (fp64 integration): %s'
-          % ({k: '%.1e' % v for k, v in errs[False].items()}, {k: '%.1e' % v for k, v in errs[True].items()}))
+    print('open-loop replay drift  float32: %s   precise (fp64 integration): %s   attitude-only residuals: %s'
+          % tuple({k: '%.1e' % v for k, v in errs[c].items()} for c in (False, True, 'attitude')))
     assert errs[True][1000] <= 1e-5
     assert errs[True][1000] < errs[False][1000]
+    # float64 attitude / rates with residual planes, float32 positions / velocities: same bound at 48 B per env-step less
+    assert errs['attitude'][1000] <= 1e-5 and errs['attitude'][1000] < errs[False][1000]
 
 
 def _pd_controller(xs, hover):
@@ -479,3 +483,61 @@ def test_reference_verbose_api_config_runs(gpu):
     # judged on the RAW action (constraints.py:167-168), which stayed inside, while the state keeps evolving
     assert env.inertial_properties.shape == (8, 4) and float(env.inertial_properties[:, 0].min()) > 0.05
     env.close()
+
+
+@pytest.mark.parametrize('mode', [True, 'attitude'])
+@pytest.mark.parametrize('info_level', ['minimal', 'full'])
+def test_precise_modes_teacher_forced_parity_resets_and_queues(gpu, mode, info_level):
+    """Both precise modes (all residual planes / attitude-only residual planes with float32 positions and velocities) in the
+    lean and the info tier: teacher-forced single-step parity through auto-resets and a bounded constraint, the residual
+    planes' shape and reset behaviour, two-queue rollout == step loop bit for bit, and the refusal of configurations the
+    attitude mode is not built for."""
+    import safe_control_gym_amd as scg
+    from safe_control_gym_amd._capi import ScgError
+    n = 130
+    cons = [{'constraint_form': 'bounded_constraint', 'constrained_variable': 'state', 'active_dims': [0, 2, 4],
+             'lower_bounds': [-3, -3, -0.1], 'upper_bounds': [3, 3, 2]}]
+    kw = dict(task='traj_tracking', cost='quadratic', ctrl_freq=60, pyb_freq=240, episode_len_sec=0.3, constraints=cons)
+    env, ref, sampler = make_pair(3, n, randomized_init=True, engine_kwargs=dict(compensated_state=mode, info_level=info_level), **kw)
+    sync_reset(env, ref, sampler)
+    lo = env._bufs['state_lo']
+    assert lo.shape[0] == (6 if mode == 'attitude' else 12)
+    rng = np.random.default_rng(23)
+    worst = 0.0
+    for k in range(40):                                   # 18-step episodes: every env auto-resets twice
+        force_state(env, ref)
+        lo.zero_()                                        # teacher forcing sets the hi planes: the residual restarts at 0
+        worst = max(worst, compare_step(*sync_step(env, ref, sampler, _actions(env, rng, n)), ref))
+    assert worst <= RTOL
+    assert float(lo.abs().max()) > 0 and float(lo.abs().max()) < 1e-6          # residuals of float32 roundings, in use
+    # a masked reset clears the residuals of the masked lanes only
+    mask = torch.zeros(n, dtype=torch.bool, device='cuda'); mask[::3] = True
+    keep = lo[:, 1].clone()
+    env.reset(mask=mask)
+    assert float(lo[:, :n][:, mask].abs().max()) == 0.0 and torch.equal(lo[:, 1], keep)
+    env.close()
+    # two launch queues: bit-identical to the step loop in this mode too
+    big = 300001
+    kw2 = dict(quad_type=3, num_envs=big, device='cuda', seed=4, randomized_init=True, task='traj_tracking', cost='quadratic',
+               episode_len_sec=0.25, compensated_state=mode, info_level=info_level)
+    a, b = scg.make('quadrotor', **kw2), scg.make('quadrotor', **kw2)
+    a.reset(), b.reset()
+    g = torch.Generator(device='cuda'); g.manual_seed(8)
+    alo, ahi = float(a.action_space.low[0]), float(a.action_space.high[0])
+    acts = torch.rand((5, 4, a.plane_stride), generator=g, device='cuda') * (ahi - alo) + alo
+    a.rollout(acts, steps=19)
+    for k in range(19):
+        b.step(acts[k % 5])
+    torch.cuda.synchronize()
+    for key in ('state', 'state_lo', 'step_count', 'reward', 'done', 'ep_return'):
+        assert torch.equal(a._bufs[key], b._bufs[key]), key
+    a.close(), b.close()
+    if mode == 'attitude':
+        with pytest.raises(ValueError, match='3-D'):
+            scg.make('quadrotor', quad_type=2, num_envs=8, device='cuda', compensated_state='attitude').reset()
+        noisy = scg.make('quadrotor', quad_type=3, num_envs=8, device='cuda', task='traj_tracking', compensated_state='attitude',
+                         disturbances={'dynamics': [{'disturbance_func': 'white_noise', 'std': 0.01}]})
+        noisy.reset()
+        with pytest.raises(ScgError, match='lean and info'):
+            noisy.step(torch.zeros((8, 4), device='cuda'))
+        noisy.close()
