@@ -11,6 +11,9 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 if [ "${PMC_TRAFFIC_ONLY:-0}" = "1" ]; then
   groups=("FETCH_SIZE" "WRITE_SIZE")
+elif [ "${PMC_GROUPS_ONLY:-}" = "SQ" ]; then
+  groups=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+          "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA")
 else
   groups=("FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
@@ -18,7 +21,7 @@ else
 fi
 for group in "${groups[@]}"; do
   i=$((i+1))
-  rocprofv3 --pmc $group --output-format csv -d "$out/pass$i" -- python3 "$root/bench.py" --steps 60 --warmup 10 --no-cpu-baseline --no-bare "$@" > "$out/pass$i.log" 2>&1 || echo "pass $i ($group) failed"
+  rocprofv3 --pmc $group --output-format csv -d "$out/pass$i" -- python3 "$root/bench.py" --steps 60 --warmup 10 --repeats 1 --no-cpu-baseline --no-sub-records "$@" > "$out/pass$i.log" 2>&1 || echo "pass $i ($group) failed"
 done
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections

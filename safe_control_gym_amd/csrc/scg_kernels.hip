@@ -43,15 +43,18 @@ namespace scg {
 #define SCG_NUM_SGPR 0         // > 0: cap the step kernel's SGPR allocation (amdgpu_num_sgpr); <= 80 admits 8 workgroups per CU
 #endif
 constexpr int kBlock = SCG_BLOCK;
+#ifndef SCG_COMP_WAVES
+#define SCG_COMP_WAVES 1       // waves per SIMD the register allocator must allow in the precise-mode instantiations (1 = no demand)
+#endif
 #if SCG_NUM_SGPR > 0
 #define SCG_SGPR_CAP __attribute__((amdgpu_num_sgpr(SCG_NUM_SGPR)))
 #else
 #define SCG_SGPR_CAP
 #endif
 #if SCG_MIN_WAVES > 0
-#define SCG_BOUNDS __launch_bounds__(kBlock, SCG_MIN_WAVES) SCG_SGPR_CAP
+#define SCG_BOUNDS __launch_bounds__(kBlock, (COMP != 0 ? SCG_COMP_WAVES : SCG_MIN_WAVES)) SCG_SGPR_CAP
 #else
-#define SCG_BOUNDS __launch_bounds__(kBlock) SCG_SGPR_CAP
+#define SCG_BOUNDS __launch_bounds__(kBlock, (COMP != 0 ? SCG_COMP_WAVES : 1)) SCG_SGPR_CAP
 #endif
 
 // Philox4x32-10 (Salmon et al., SC'11).  Counter layout shared with oracle/philox.py.

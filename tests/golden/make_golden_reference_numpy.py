@@ -19,6 +19,9 @@ Groups written (inputs and the reference's outputs, float64):
   step_glue      before_step / _preprocess_control / extend_obs / _get_done / _get_reward (rl) / the mse statements of
                  _get_info / after_step                   envs/benchmark_env.py:394-463, quadrotor.py:815-842,886-913,956-993,1011-1025
   gae            compute_returns_and_advantages          controllers/ppo/ppo_utils.py:428-456
+  vec_env        DummyVecEnv (auto-reset, terminal stash) under VecRecordEpisodeStatistics (episode returns / lengths / trackers),
+                 run over a deterministic toy env (tests/golden/toy_env.py)      envs/env_wrappers/vectorized_env/dummy_vec_env.py:10-59,
+                                                                                 envs/env_wrappers/record_episode_statistics.py:92-169
   discretize     discretize_linear_system (exact and Euler; scipy.linalg.expm is importable)   controllers/mpc/mpc_utils.py:24-54
   normalization  RunningMeanStd, MeanStdNormalizer, RewardStdNormalizer                   math_and_models/normalization.py:17-190
 
@@ -32,6 +35,9 @@ import math
 import os
 import sys
 import types
+import copy
+from abc import ABC, abstractmethod
+from collections import deque
 from copy import deepcopy
 from enum import Enum, IntEnum
 
@@ -40,6 +46,7 @@ import scipy
 import scipy.linalg
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
 REF = '/root/reference/safe_control_gym'
 
 
@@ -138,7 +145,8 @@ def _tests_task(stmt):
 # ---------------------------------------------------------------------------------------------------------------------
 # the namespace every extracted piece runs in
 # ---------------------------------------------------------------------------------------------------------------------
-NS = {'np': NP, 'math': math, 'deepcopy': deepcopy, 'Enum': Enum, 'IntEnum': IntEnum, 'str': str, 'scipy': scipy}
+NS = {'np': NP, 'math': math, 'deepcopy': deepcopy, 'Enum': Enum, 'IntEnum': IntEnum, 'str': str, 'scipy': scipy,
+      'copy': copy, 'ABC': ABC, 'abstractmethod': abstractmethod, 'deque': deque}
 SOURCES = []
 SOURCES += top_level('envs/gym_pybullet_drones/quadrotor_utils.py', ['QuadType', 'cmd2pwm', 'pwm2rpm'], NS)
 SOURCES += top_level('envs/benchmark_env.py', ['Cost', 'Task'], NS)
@@ -148,6 +156,10 @@ SOURCES += top_level('envs/constraints.py', ['ConstrainedVariableType', 'Constra
                                              'get_symbolic_constraint_models', 'ConstraintList', 'create_constraint_list'], NS)
 SOURCES += top_level('controllers/ppo/ppo_utils.py', ['compute_returns_and_advantages'], NS)
 SOURCES += top_level('controllers/mpc/mpc_utils.py', ['discretize_linear_system'], NS)
+SOURCES += top_level('envs/env_wrappers/vectorized_env/vec_env_utils.py', ['tile_images', '_flatten_obs', '_flatten_list'], NS)
+SOURCES += top_level('envs/env_wrappers/vectorized_env/vec_env.py', ['VecEnv', 'VecEnvWrapper'], NS)
+SOURCES += top_level('envs/env_wrappers/vectorized_env/dummy_vec_env.py', ['DummyVecEnv'], NS)
+SOURCES += top_level('envs/env_wrappers/record_episode_statistics.py', ['VecRecordEpisodeStatistics'], NS)
 SOURCES += top_level('math_and_models/normalization.py', ['RunningMeanStd', 'BaseNormalizer', 'MeanStdNormalizer',
                                                           'RewardStdNormalizer'], NS)
 SOURCES += methods('envs/benchmark_env.py', 'BenchmarkEnv', ['_generate_trajectory', '_get_coordinates', '_figure8', '_circle',
@@ -540,6 +552,34 @@ def gen_discretize(rng):
     MANIFEST['groups']['discretize'] = dict(cases=cases)
 
 
+def gen_vec_env(rng):
+    from toy_env import ToyEnv
+    horizons = [3, 5, 4, 7]
+    venv = NS['VecRecordEpisodeStatistics'](NS['DummyVecEnv']([(lambda i=i, h=h: ToyEnv(i, h)) for i, h in enumerate(horizons)]), deque_size=50)
+    venv.add_tracker('constraint_violation', 0, mode='queue')
+    obs0, _ = venv.reset()
+    put('vec_env/obs0', obs0)
+    T = 30
+    actions = rng.uniform(-1.0, 1.0, size=(T, len(horizons), 1))
+    obs_l, rew_l, done_l, term_l, epr_l, epl_l, viol_l = [], [], [], [], [], [], []
+    for t in range(T):
+        obs, rew, done, info = venv.step(actions[t])
+        obs_l.append(obs); rew_l.append(rew); done_l.append(done)
+        term_l.append([info['n'][i]['terminal_observation'] if done[i] else np.full(3, np.nan) for i in range(len(horizons))])
+        epr_l.append([info['n'][i]['episode']['r'] if done[i] else np.nan for i in range(len(horizons))])
+        epl_l.append([info['n'][i]['episode']['l'] if done[i] else np.nan for i in range(len(horizons))])
+        viol_l.append([info['n'][i]['episode']['constraint_violation'] if done[i] else np.nan for i in range(len(horizons))])
+    put('vec_env/actions', actions); put('vec_env/obs', obs_l); put('vec_env/rew', rew_l); put('vec_env/done', done_l)
+    put('vec_env/terminal_observation', term_l); put('vec_env/episode_r', epr_l); put('vec_env/episode_l', epl_l)
+    put('vec_env/episode_constraint_violation', viol_l)
+    put('vec_env/return_queue', list(venv.return_queue)); put('vec_env/length_queue', list(venv.length_queue))
+    put('vec_env/violation_queue', list(venv.queued_stats['constraint_violation']))
+    put('vec_env/running_return', venv.episode_return); put('vec_env/running_length', venv.episode_length)
+    MANIFEST['groups']['vec_env'] = dict(horizons=horizons, steps=T,
+                                         note='VecRecordEpisodeStatistics(DummyVecEnv([ToyEnv(i, horizon_i)])) + a queued constraint_violation '
+                                              'tracker; NaN where the key is absent (env not done at that step)')
+
+
 def gen_normalization(rng):
     rms = NS['RunningMeanStd'](shape=(5,))
     batches, means, variances, counts = [], [], [], []
@@ -583,7 +623,8 @@ def main():
     gen_step_glue(rng)
     gen_gae(rng)
     gen_normalization(rng)
-    gen_discretize(rng)        # (last: earlier groups keep the random stream they were first written with)
+    gen_discretize(rng)        # (appended: earlier groups keep the random stream they were first written with)
+    gen_vec_env(rng)
     OUT['manifest'] = np.array(json.dumps(MANIFEST))
     np.savez_compressed(os.path.join(HERE, 'reference_numpy.npz'), **OUT)
     print('wrote %d arrays, %d reference symbols executed' % (len(OUT) - 1, len(SOURCES)))

@@ -492,6 +492,7 @@ def test_precise_modes_teacher_forced_parity_resets_and_queues(gpu, mode, info_l
     lean and the info tier: teacher-forced single-step parity through auto-resets and a bounded constraint, the residual
     planes' shape and reset behaviour, two-queue rollout == step loop bit for bit, and the refusal of configurations the
     attitude mode is not built for."""
+    import torch
     import safe_control_gym_amd as scg
     from safe_control_gym_amd._capi import ScgError
     n = 130

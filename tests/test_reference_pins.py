@@ -404,3 +404,35 @@ def test_device_discretisation_matches_reference_function(gpu, k):
         for i in range(A.shape[0]):
             assert np.abs(ad[i].double().cpu().numpy() - wa[i]).max() <= tol * max(1.0, np.abs(wa[i]).max()), (tag, i)
             assert np.abs(bd[i].double().cpu().numpy() - wb[i]).max() <= tol * max(1.0, np.abs(wb[i]).max()), (tag, i)
+
+
+# ---- the vectorisation wrappers (A14): DummyVecEnv.step_wait + VecRecordEpisodeStatistics.step_wait, executed ---------------
+def test_oracle_vec_env_matches_reference_wrappers():
+    """The reference's own DummyVecEnv (auto-reset: the returned observation is the reset one, the finished step's is stashed
+    as terminal_observation, dummy_vec_env.py:34-49) under its VecRecordEpisodeStatistics (record_episode_statistics.py:
+    142-169), run over a deterministic toy env: the oracle's RefVecEnv over an identical copy returns the same observations,
+    rewards, dones, terminal observations, episode returns / lengths and queues."""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, 'golden'))
+    from toy_env import ToyEnv
+    from oracle.ref_vec import RefVecEnv
+    g = GROUPS['vec_env']
+    vec = RefVecEnv([ToyEnv(i, h) for i, h in enumerate(g['horizons'])])
+    obs0, _ = vec.reset()
+    assert np.array_equal(obs0, G['vec_env/obs0'])
+    n = len(g['horizons'])
+    for t in range(g['steps']):
+        obs, rew, done, info = vec.step(G['vec_env/actions'][t])
+        assert np.array_equal(obs, G['vec_env/obs'][t]) and np.array_equal(done, G['vec_env/done'][t].astype(bool)), t
+        assert rel_err(rew, G['vec_env/rew'][t]) <= TIGHT
+        for i in range(n):
+            if done[i]:
+                assert np.array_equal(info['n'][i]['terminal_observation'], G['vec_env/terminal_observation'][t][i])
+                assert rel_err(info['n'][i]['episode']['r'], G['vec_env/episode_r'][t][i]) <= TIGHT
+                assert info['n'][i]['episode']['l'] == G['vec_env/episode_l'][t][i]
+            else:
+                assert 'terminal_observation' not in info['n'][i] and np.isnan(G['vec_env/episode_r'][t][i])
+    assert rel_err(np.array(vec.return_queue), G['vec_env/return_queue']) <= TIGHT
+    assert np.array_equal(np.array(vec.length_queue), G['vec_env/length_queue'])
+    assert rel_err(vec.episode_return, G['vec_env/running_return']) <= TIGHT
+    assert np.array_equal(vec.episode_length, G['vec_env/running_length'])
