@@ -294,6 +294,10 @@ constexpr int kWgResetFloats = 4 + kBlock + ((kBlock * 4 + 3) & ~3);
 #ifndef SCG_WG_RESET
 #define SCG_WG_RESET 1
 #endif
+#ifndef SCG_WG_RESET_FUSED
+#define SCG_WG_RESET_FUSED 0   // 0 (measured faster: 1.56 vs 1.91 us per step at 2^16 CartPole envs): the fused multi-step rollout keeps the
+                               // per-wave form -- no workgroup barriers inside its step loop
+#endif
 
 template <int NX>
 __device__ __forceinline__ void reset_state_wg(const KParams& p, const KTables* __restrict__ tb,
@@ -638,7 +642,8 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
     // per-wave LDS scratch of the cooperative reset, placed after the (16-B padded) reference table
     float* wg_scratch = s_ref + ((tracking && (p.flags & F_REF_IN_LDS)) ? (((p.ref_rows * NX + 3) >> 2) << 2) : 0);
     float* coop_scratch = wg_scratch + (threadIdx.x >> 6) * kCoopFloats;      // per-wave form: aliases the pooled form's scratch
-    const bool pooled_reset = SCG_WG_RESET && (p.flags & F_AUTO_RESET) && (p.flags & F_RAND_INIT) && !(p.flags & F_RAND_GENERAL);
+    const bool pooled_reset = SCG_WG_RESET && (SCG_WG_RESET_FUSED || MODE != MODE_FUSED) && (p.flags & F_AUTO_RESET) &&
+                              (p.flags & F_RAND_INIT) && !(p.flags & F_RAND_GENERAL);
     if (pooled_reset) {
         // list counters of the workgroup-pooled reset; visible to every wave after the first barrier each of them takes
         // (the table-staging barrier below, or the first barrier inside reset_state_wg -- so zero BOTH before any of them)
@@ -1020,6 +1025,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
             float xr[NX];
             if (wg_full) reset_state_wg<NX>(p, tb, io.reset_state, ld, i, serial, need_reset, wg_scratch, kstep & 1, xr);
 #if SCG_WG_RESET
+            else if (!SCG_WG_RESET_FUSED && MODE == MODE_FUSED) reset_state_coop<NX>(p, tb, io.reset_state, ld, i, serial, need_reset, coop_scratch, xr);
             else if (need_reset) reset_state_of<NX, EXTRA>(p, tb, io.reset_state, ld, i, serial, xr);   // ragged last workgroup / no randomisation / non-uniform draws
 #else
             else reset_state_coop<NX>(p, tb, io.reset_state, ld, i, serial, need_reset, coop_scratch, xr);

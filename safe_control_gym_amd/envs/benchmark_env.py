@@ -155,6 +155,10 @@ class BenchmarkEnv:
         # the engine's planes that the NEXT step() overwrites.  Default: fresh with the drop-in API (info_level='full'),
         # views with the lean one.  See step().
         self.COPY_OUTPUTS = (info_level == 'full') if copy_outputs is None else bool(copy_outputs)
+        # how fresh outputs are produced: the kernel writes this step's obs / rew / done straight into newly allocated tensors
+        # (an obs buffer apart from the state planes: +4 obs_dim bytes of stores per env-step, no copy kernel); the precise
+        # modes, whose kernels are not built with a separate obs buffer, clone the views instead
+        self._fresh_outputs = False          # decided in _alloc_buffers
         # precise mode: state kept as hi + lo float32 planes and integrated in float64.  True / 'full':
         # every state; 'attitude' (3-D quadrotor): residual planes and float64 arithmetic for the rotational chain only
         # (attitude + body rates), float32 positions and velocities -- 48 B per env-step less, same <= 1e-5 drift bound
@@ -446,7 +450,8 @@ class BenchmarkEnv:
         if self.constraints is not None:
             b['constraint_values'] = torch.zeros((self.constraints.num_device_rows, ld), dtype=f32, device=dev)
             b['constraint_violation'] = torch.zeros(ld, dtype=torch.uint8, device=dev)
-        if self.obs_dim != nx or 'observation' in self.disturbances:
+        self._fresh_outputs = self.COPY_OUTPUTS and not self.COMPENSATED_STATE
+        if self.obs_dim != nx or 'observation' in self.disturbances or self._fresh_outputs:
             b['obs'] = torch.zeros((self.obs_dim, ld), dtype=f32, device=dev)
         if self.INFO_LEVEL == 'full':
             b['mse'] = torch.zeros(ld, dtype=f32, device=dev)
@@ -798,12 +803,20 @@ class BenchmarkEnv:
         ``make()``) ``obs``, ``rew`` and ``done`` are fresh tensors, as the reference's are: the usual RL loop keeps the
         previous ``obs`` until after the next ``step()`` (controllers/ppo/ppo.py:259-276).  With ``copy_outputs=False``
         (default of ``info_level='minimal'``) they are zero-copy VIEWS of the engine's planes -- valid until the next
-        ``step()`` / ``rollout()`` / ``reset()``, ``.clone()`` what must outlive it (saves ~100 B/env of copy traffic per
-        step).  The tensors inside ``info`` are always views of per-step buffers."""
+        ``step()`` / ``rollout()`` / ``reset()``, ``.clone()`` what must outlive it.  Fresh outputs are written by the kernel
+        itself into newly allocated tensors (+4 obs_dim bytes of stores per env-step, no copy kernel).  The tensors inside
+        ``info`` are always views of per-step buffers."""
         self._check_initial_reset()
         act, rows = self._load_action(action)
         self._raw_action, self._raw_action_rows = act, rows
         b = self._bufs
+        outs = None
+        if self._fresh_outputs:
+            # copy_outputs: this step's outputs get tensors of their own, written by the kernel (no clone afterwards)
+            f32 = torch.float32
+            outs = (torch.empty((self.obs_dim, self._ld), dtype=f32, device=self.device),
+                    torch.empty(self._ld, dtype=f32, device=self.device), torch.empty(self._ld, dtype=torch.bool, device=self.device))
+            b['obs'], b['reward'], b['done'] = outs
         if self.adversary_disturbance is not None:
             # adversary inputs (benchmark_env.py:256-266, quadrotor.py:529-536,837-838) arrive as planes; the passive
             # disturbances are generated inside the kernel (scg_set_disturbances)
@@ -819,11 +832,15 @@ class BenchmarkEnv:
                 io['reset_state'] = self._reset_state_buf
                 self._engine.bind_static(io, self._ld)
                 self._bound = True
-            self._engine.step_bound(act, self.num_envs, self._serial, action_rows=rows)
+            self._engine.step_bound(act, self.num_envs, self._serial, action_rows=rows, outs=outs)
         self._serial += 1
-        obs, rew, done = self._out_views
-        if self.COPY_OUTPUTS:
-            obs, rew, done = obs.clone(), rew.clone(), done.clone()
+        if outs is not None:
+            n = self.num_envs
+            obs, rew, done = outs[0][:, :n].T, outs[1][:n], outs[2][:n]
+        else:
+            obs, rew, done = self._out_views
+            if self.COPY_OUTPUTS:
+                obs, rew, done = obs.clone(), rew.clone(), done.clone()
         info = dict(self._info_views)
         if info.get('constraint_values', 0) is None:                 # folded constraints (|y| - bound): needs a max()
             info['constraint_values'] = self.constraints.fold(b['constraint_values'][:, :self.num_envs].T)

@@ -106,9 +106,12 @@ class Engine:
         self._bind(bufs, ld)
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
 
-    def step_bound(self, action, n, serial, action_rows=False):
-        """Hot path of env.step(): ~4 ctypes stores and one foreign call."""
+    def step_bound(self, action, n, serial, action_rows=False, outs=None):
+        """Hot path of env.step(): ~4 ctypes stores and one foreign call.  ``outs`` = (obs planes, reward, done) re-points this
+        step's outputs at tensors of the caller's (copy_outputs: fresh ones every step, written by the kernel itself)."""
         io = self._io
+        if outs is not None:
+            io.obs, io.reward, io.done = outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr()
         io.action = action.data_ptr()
         io.action_rows = int(action_rows)
         io.reset_serial = serial & 0xffffffff

@@ -144,8 +144,9 @@ def test_disturbed_rollout_equals_step_loop(gpu):
     a.rollout(acts, steps=20)
     for k in range(20):
         b.step(acts[k % 7])
-    assert torch.equal(a.state, b.state) and torch.equal(a._bufs['obs'], b._bufs['obs'])
-    assert torch.equal(a._bufs['reward'], b._bufs['reward'])
+    # (the live lanes: step() writes each step's outputs into freshly allocated tensors whose pad lanes are never touched)
+    assert torch.equal(a.state, b.state) and torch.equal(a._bufs['obs'][:, :500], b._bufs['obs'][:, :500])
+    assert torch.equal(a._bufs['reward'][:500], b._bufs['reward'][:500])
     assert not torch.equal(a._bufs['obs'][:, :500], a._bufs['state'][:, :500])
     a.close(), b.close()
 

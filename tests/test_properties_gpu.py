@@ -378,8 +378,8 @@ def test_two_queue_rollout_is_bit_identical_to_the_step_loop(gpu, tier):
         if key == 'action':
             continue
         x, y = a._bufs[key], b._bufs[key]
-        if key == 'terminal_record':                      # rows of envs that never finished hold stale zeros on both sides
-            x, y = x[:n], y[:n]
+        # the n live lanes / rows (the pad lanes of a freshly allocated per-step output tensor are never written)
+        x, y = (x[:n], y[:n]) if (x.ndim == 1 or key == 'terminal_record') else (x[:, :n], y[:, :n])
         assert torch.equal(x, y), (tier, key)
     assert int(a.ctrl_step_counter.max()) < 15           # episodes of 15 steps: every env was reset at least once
     a.close(), b.close()

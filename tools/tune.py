@@ -31,6 +31,7 @@ def main():
     ap.add_argument('--rounds', type=int, default=2)
     ap.add_argument('--steps', type=int, default=1500)
     ap.add_argument('--arms', default='')
+    ap.add_argument('--field', default='roofline.kernel_us_per_launch', help='dotted path of the number to compare (us; lower is better)')
     ap.add_argument('bench_args', nargs='*')
     a = ap.parse_args()
     vdir = os.path.join(ROOT, 'safe_control_gym_amd', 'lib', 'variants')
@@ -45,7 +46,9 @@ def main():
     for r in range(a.rounds):
         for name, lib, envx in arms:
             j = run(lib, envx, a.steps, a.bench_args)
-            us = j.get('roofline', {}).get('kernel_us_per_launch')
+            us = j
+            for part in a.field.split('.'):
+                us = us.get(part) if isinstance(us, dict) else None
             res[name].append(us)
             print('round %d %-20s %s' % (r, name, us if us else j), flush=True)
     print('---- summary (kernel us per launch; lower is better)')
