@@ -522,3 +522,25 @@ def test_all_gather_of_episode_returns_through_rccl(gpu):
             assert torch.equal(x, y) and torch.equal(x, z) and y.data_ptr() != x.data_ptr() and int(ones.item()) == 1
         finally:
             dist.destroy_process_group()
+
+
+def test_bench_launcher_runs_two_ranks_on_this_gpu(gpu):
+    """`python bench.py --gpus 2` with no launcher environment: the parent (no GPU call) starts two rank processes, which here share
+    the box's one GPU and exchange over gloo (SCG_SINGLE_DEVICE=1: RCCL refuses two ranks on one device); rank 0's line comes back
+    through the parent with ranks_seen = 2, the sharded workload C5 and a positive throughput.  3 processes touch the card (<= 6)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['SCG_SINGLE_DEVICE'] = '1'
+    run = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '5',
+                          '--envs-per-gpu', '65536', '--repeats', '2'], env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['ranks_seen'] == 2 and j['backend'] == 'gloo' and j['steps'] == 20
+    assert j['config']['total_envs'] == 131072 and j['config']['workload'].startswith('C5')
+    assert j['value'] > 1e8 and 'per_rank_ms_per_step_min_max' in j and 'cpu_baseline' not in j

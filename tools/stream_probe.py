@@ -1,5 +1,5 @@
 """Probe behind the two launch queues of scg_rollout: one env of 2^20 vs the same batch cut in 2 / 3 envs whose rollouts are issued
-on separate HIP streams (run with SCG_ROLLOUT_QUEUES=1 so that scg_rollout itself does not split).  Measured: 29.1 / 25.7 / 31.8 us
+on separate HIP streams (the envs are made with rollout_queues=1 so that scg_rollout itself does not split).  Measured: 29.1 / 25.7 / 31.8 us
 per step of the whole batch for 1 / 2 / 3 streams (and 29.9 for 4)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +8,7 @@ import safe_control_gym_amd as scg
 
 def mk(n, base):
     e = scg.make('quadrotor', quad_type=3, num_envs=n, device='cuda', seed=1337, env_index_base=base, randomized_init=True,
-                 task='traj_tracking', cost='quadratic', info_level='minimal', track_episode_stats=True)
+                 task='traj_tracking', cost='quadratic', info_level='minimal', track_episode_stats=True, rollout_queues=1)
     e.reset()
     lo, hi = float(e.action_space.low[0]), float(e.action_space.high[0])
     a = torch.rand((300, 4, e.plane_stride), device='cuda') * (hi - lo) + lo
