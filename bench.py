@@ -160,14 +160,14 @@ def build_env(args, workload, rank, n, track, extra=None):
         common[k] = yaml.safe_load(v)
     common.update(extra or {})
     if workload in ('c4', 'c5'):
-        env = scg.make('quadrotor', quad_type=3, task='traj_tracking', cost='quadratic', **common)
+        env = scg.make('quadrotor', **{**dict(quad_type=3, task='traj_tracking', cost='quadratic'), **common})
         name = 'Quadrotor-3D traj_tracking (circle), quadratic cost Q=R=I, RK4 dt=1/60, auto-reset'
     elif workload == 'c3':
-        env = scg.make('quadrotor', quad_type=2, task='stabilization', cost='rl_reward', constraints=C3_CONSTRAINTS, **common)
+        env = scg.make('quadrotor', **{**dict(quad_type=2, task='stabilization', cost='rl_reward', constraints=C3_CONSTRAINTS), **common})
         name = 'Quadrotor-2D stabilization, rl_reward, BoundedConstraint(active_dims [0,2,4])'
     elif workload == 'c2':
         common.update(ctrl_freq=50, pyb_freq=50)
-        env = scg.make('cartpole', task='stabilization', cost='quadratic', **common)
+        env = scg.make('cartpole', **{**dict(task='stabilization', cost='quadratic'), **common})
         name = 'CartPole stabilization, quadratic cost, RK4 dt=1/50 (no reference env: parity unpinned)'
     else:
         raise SystemExit('unknown workload %r' % workload)

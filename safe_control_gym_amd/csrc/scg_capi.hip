@@ -548,9 +548,9 @@ int scg_step(scg_handle* h, const scg_step_io* io, int64_t n, void* stream) {
         if (h->system != SCG_QUAD_3D)
             return fail(SCG_ERR_UNSUPPORTED, "scg_step: attitude-only residual planes (state_lo_kind = 1) are defined for the 3-D quadrotor");
         if (h->kp.dist || io->obs || io->inertial || io->action_disturbance || io->dynamics_force || io->stats || io->episode_id ||
-            (h->kp.flags & (F_NORMALIZED | F_GND | F_DRAG | F_RAND_GENERAL)) || !(h->kp.flags & F_Q_DIAG))
+            (h->kp.flags & (F_GND | F_DRAG | F_RAND_GENERAL)) || !(h->kp.flags & F_Q_DIAG))
             return fail(SCG_ERR_UNSUPPORTED, "scg_step: state_lo_kind = 1 supports the lean and info configurations only "
-                                             "(no disturbances, aero terms, per-env inertia, full Q / R, normalised actions, obs buffer)");
+                                             "(no disturbances, aero terms, per-env inertia, full Q / R, obs buffer)");
     }
     if (n == 0) return SCG_OK;
     if (n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_step: n > 2^30 envs per device (32-bit lane offsets)");

@@ -596,9 +596,10 @@ enum Feat : uint32_t {
     FT_EXTRA = 4u,   // everything else: disturbances, separate obs buffer (+noise, +goal horizon), per-env inertial
                      // properties, stats sums, non-diagonal Q or R, normalised action space.  In this tier
                      // FT_TRACK / FT_CON are run-time decisions again.
-    FT_DIST = 16u,   // FT_INFO + the passive disturbances drawn in the kernel (scg_set_disturbances: action / dynamics / observation
-                     // noise, the separate obs buffer they need, per-episode offsets) and nothing else of FT_EXTRA: the common
-                     // "noisy env" configuration without the run-time branches of the catch-all tier
+    FT_DIST = 16u,   // FT_INFO + a separate obs buffer: the passive disturbances drawn in the kernel (scg_set_disturbances: action /
+                     // dynamics / observation noise, per-episode offsets), the goal horizon appended to the observation
+                     // (benchmark_env.py:406-420) and kernel-written fresh outputs -- the usual RL configurations (normalised
+                     // actions are a run-time branch of every tier), without the run-time branches of the catch-all tier
     FT_INFO = 8u,    // the per-step info outputs of the default API (info_level='full'): mse / goal_reached /
                      // truncated / terminal_record (terminal obs = the state: obs aliases it in this tier).  A tier of its
                      // own because it is what make() gives by default: 43 us in the EXTRA tier at 2^20 envs.
@@ -778,13 +779,13 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
 #pragma unroll
             for (int j = 0; j < NU; ++j) {
                 float a = clampf(a_raw[j], tb->act_low[j], tb->act_high[j]);
-                if (EXTRA && (p.flags & F_NORMALIZED)) {
+                if (p.flags & F_NORMALIZED) {                                    // (a wave-uniform branch in every tier)
                     if (SYS == SCG_CARTPOLE) a *= p.action_scale;
                     else a = fmaf(p.norm_act_scale, a, 1.0f) * p.hover_thrust;   // quadrotor.py:828
                 }
                 a_clip[j] = a;                                                   // current_preprocessed_action (:833)
                 RT th = (RT)a;
-                if (sizeof(RT) == 8 && !(EXTRA && (p.flags & F_NORMALIZED))) {
+                if (sizeof(RT) == 8 && !(p.flags & F_NORMALIZED)) {
                     // the float32-typed bounds are exact in both precisions; clip in double all the same
                     const double ad = (double)a_raw[j];
                     th = (RT)fmin(fmax(ad, tb->act_low_d[j]), tb->act_high_d[j]);
@@ -998,7 +999,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                         if (EXTRA && io.obs_noise) o += ldp(PL(io.obs_noise, j), i4);
                         rec[j] = o;
                     }
-                    if (EXTRA && p.obs_goal_horizon > 0) {
+                    if (DIST && p.obs_goal_horizon > 0) {
                         if (tracking) {
                             for (int k = 0; k < p.obs_goal_horizon; ++k) {
                                 float g[NX];
@@ -1080,7 +1081,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                 if (EXTRA && io.obs_noise) o += ldp(PL(io.obs_noise, j), i4);
                 stp(PL(io.obs, j), i4, o);
             }
-            if (EXTRA && p.obs_goal_horizon > 0) {
+            if (DIST && p.obs_goal_horizon > 0) {
                 if (tracking) {
                     // extend_obs(obs, ctrl_step_counter + 1) is evaluated before the counter increment:
                     // rows min(t + 1 + k, T-1); a lane that auto-reset reports the reset observation, whose
@@ -1292,7 +1293,7 @@ LaunchGeom step_geometry(const KParams& p, int system, int64_t n, int num_cus) {
 // Which instantiation covers this call.
 static uint32_t features_needed(const KParams& p, const scg_step_io& io) {
     const bool extra = io.inertial || io.action_disturbance || io.dynamics_force || io.obs_noise || io.stats ||
-                       p.obs_goal_horizon > 0 || (p.flags & (F_NORMALIZED | F_GND | F_DRAG | F_RAND_GENERAL)) || !(p.flags & F_Q_DIAG);
+                       (p.flags & (F_GND | F_DRAG | F_RAND_GENERAL)) || !(p.flags & F_Q_DIAG);
     if (extra) return FT_TRACK | FT_CON | FT_EXTRA;
     uint32_t ft = 0;
     if (p.dist || io.obs || io.episode_id) ft |= FT_DIST;                 // in-kernel disturbances only: their own tier
