@@ -191,7 +191,10 @@ typedef struct scg_step_io {
     uint32_t* episode_id;            /* nullable [n] serial of the reset that began the env's episode; needed only
                                         when a disturbance draws its step_offset per episode */
     /* out */
-    float* obs;                      /* nullable [obs_dim][ld]; NULL when obs aliases state */
+    float* obs;                      /* nullable [obs_dim][ld]; NULL when the observation IS the state (no goal horizon, no
+                                        observation noise).  obs == state is allowed with a goal horizon and no observation
+                                        noise: the buffer then holds obs_dim planes, the first nx of which are the state, and
+                                        the kernel writes the state once and only the goal rows behind it */
     float* reward;                   /* [n] */
     uint8_t* done;                   /* [n] */
     float* constraint_values;        /* nullable [nc][ld] */

@@ -397,8 +397,10 @@ int scg_set_disturbances(scg_handle* h, const scg_disturbance* entries, int32_t 
 
 // buffers the attached disturbances need (shared by scg_step / scg_rollout / scg_rollout_fused)
 static int check_dist_io(const scg_handle* h, const scg_step_io* io, const char* who) {
-    if (h->dist_obs && !io->obs)
-        return fail(SCG_ERR_INVALID, "%s: an observation disturbance needs an obs buffer (obs must not alias state)", who);
+    if (h->dist_obs && (!io->obs || (const void*)io->obs == (const void*)io->state))
+        return fail(SCG_ERR_INVALID, "%s: an observation disturbance needs an obs buffer of its own (obs must not alias state)", who);
+    if (io->obs_noise && (const void*)io->obs == (const void*)io->state)
+        return fail(SCG_ERR_INVALID, "%s: obs_noise needs an obs buffer of its own (obs must not alias state)", who);
     if (h->dist_needs_episode && !io->episode_id)
         return fail(SCG_ERR_INVALID, "%s: a per-episode step_offset needs the episode_id plane", who);
     return SCG_OK;
@@ -519,6 +521,8 @@ int scg_reset(scg_handle* h, float* state, float* state_lo, int32_t* step_count,
         return fail(SCG_ERR_INVALID, "scg_reset: traj_tracking needs scg_set_reference() first");
     if (h->dist_needs_episode && !episode_id)
         return fail(SCG_ERR_INVALID, "scg_reset: a per-episode step_offset needs the episode_id plane");
+    if (h->dist_obs && obs && obs == state)
+        return fail(SCG_ERR_INVALID, "scg_reset: an observation disturbance needs an obs buffer of its own (obs must not alias state)");
     HIP_TRY(launch_reset(h->system, h->kp, h->d_tb, state, state_lo, step_count, ep_return, ep_length, obs, mask,
                          reset_state, inertial, episode_id, h->d_ref, reset_serial, ld, n, (hipStream_t)stream));
     return SCG_OK;

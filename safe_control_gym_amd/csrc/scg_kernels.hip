@@ -1075,11 +1075,14 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
 
         // ---- _get_observation + extend_obs (quadrotor.py:878-884, benchmark_env.py:406-420)
         if (DIST && io.obs) {
+            // obs == state (noise-free goal-horizon observation): the state planes ARE the first nx obs planes, written above
+            if (reinterpret_cast<const void*>(io.obs) != reinterpret_cast<const void*>(io.state)) {
 #pragma unroll
-            for (int j = 0; j < NX; ++j) {
-                float o = x[j] + obs_noise[j];
-                if (EXTRA && io.obs_noise) o += ldp(PL(io.obs_noise, j), i4);
-                stp(PL(io.obs, j), i4, o);
+                for (int j = 0; j < NX; ++j) {
+                    float o = x[j] + obs_noise[j];
+                    if (EXTRA && io.obs_noise) o += ldp(PL(io.obs_noise, j), i4);
+                    stp(PL(io.obs, j), i4, o);
+                }
             }
             if (DIST && p.obs_goal_horizon > 0) {
                 if (tracking) {
@@ -1130,11 +1133,11 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
 // ------------------------------------------------------------------------------------------
 template <int SYS>
 __global__ __launch_bounds__(kBlock) void scg_reset_kernel(const KParams p, const KTables* __restrict__ tb,
-                                                           float* __restrict__ state,
+                                                           float* state,
                                                            float* __restrict__ state_lo,
                                                            int32_t* __restrict__ step_count,
                                                            float* __restrict__ ep_return,
-                                                           int32_t* __restrict__ ep_length, float* __restrict__ obs,
+                                                           int32_t* __restrict__ ep_length, float* obs,
                                                            const uint8_t* __restrict__ mask,
                                                            const float* __restrict__ reset_state,
                                                            float* __restrict__ inertial,
@@ -1164,9 +1167,11 @@ __global__ __launch_bounds__(kBlock) void scg_reset_kernel(const KParams p, cons
         if (ep_length) stp(ep_length, i4, 0);
         if (episode_id) stp(episode_id, i4, serial);
         if (obs) {
-            if (p.dist) apply_disturbances<NX>(p, p.dist, SCG_DIST_OBSERVATION, 1, i, serial, serial, 0, x);   // obs only
+            if (obs != state) {          // obs == state: noise-free goal-horizon observation, the state planes are its head
+                if (p.dist) apply_disturbances<NX>(p, p.dist, SCG_DIST_OBSERVATION, 1, i, serial, serial, 0, x);   // obs only
 #pragma unroll
-            for (int j = 0; j < NX; ++j) stp(PL(obs, j), i4, x[j]);
+                for (int j = 0; j < NX; ++j) stp(PL(obs, j), i4, x[j]);
+            }
             if (p.obs_goal_horizon > 0) {
                 if (p.flags & F_TRACKING) {
                     for (int k = 0; k < p.obs_goal_horizon; ++k) {

@@ -451,7 +451,12 @@ class BenchmarkEnv:
             b['constraint_values'] = torch.zeros((self.constraints.num_device_rows, ld), dtype=f32, device=dev)
             b['constraint_violation'] = torch.zeros(ld, dtype=torch.uint8, device=dev)
         self._fresh_outputs = self.COPY_OUTPUTS and not self.COMPENSATED_STATE
-        if self.obs_dim != nx or 'observation' in self.disturbances or self._fresh_outputs:
+        if self.obs_dim != nx and 'observation' not in self.disturbances and not self.COPY_OUTPUTS:
+            # noise-free goal-horizon observation handed out as a view: one buffer of obs_dim planes whose head IS the state
+            # (scg_step_io.obs == state): the kernel writes the state once and only the goal rows behind it
+            b['obs'] = torch.zeros((self.obs_dim, ld), dtype=f32, device=dev)
+            b['state'] = b['obs'][:nx]
+        elif self.obs_dim != nx or 'observation' in self.disturbances or self._fresh_outputs:
             b['obs'] = torch.zeros((self.obs_dim, ld), dtype=f32, device=dev)
         if self.INFO_LEVEL == 'full':
             b['mse'] = torch.zeros(ld, dtype=f32, device=dev)

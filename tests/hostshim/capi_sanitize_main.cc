@@ -146,6 +146,9 @@ static void check_tables(int system) {
     EXPECT(scg_set_disturbances(h, nullptr, 2) == SCG_ERR_INVALID);
     // with a per-episode offset and an observation entry attached, step() asks for the planes they need
     { Buffers b(128); EXPECT(scg_step(h, &b.io, 100, nullptr) == SCG_ERR_INVALID); }
+    // an observation entry needs an obs buffer of its own: obs == state (the goal-horizon sharing) is refused
+    { Buffers b(128); std::vector<uint32_t> ep(128); b.io.episode_id = ep.data(); b.io.obs = (float*)b.io.state;
+      EXPECT(scg_step(h, &b.io, 100, nullptr) == SCG_ERR_INVALID); }
     EXPECT(scg_set_disturbances(h, nullptr, 0) == SCG_OK);
     EXPECT(scg_destroy(h) == SCG_OK);
     EXPECT(g_shim.live_allocations == 0);
@@ -162,6 +165,8 @@ static void check_step_and_rollout() {
     { Buffers x(64); EXPECT(scg_step(h, &x.io, 65, nullptr) == SCG_ERR_INVALID); EXPECT(scg_step(h, &x.io, -1, nullptr) == SCG_ERR_INVALID); }
     { Buffers x(64); x.io.reward = nullptr; EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_ERR_INVALID); }
     { Buffers x(64); x.io.obs_noise = x.f.data(); EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_ERR_INVALID); }
+    { Buffers x(64); x.io.obs = (float*)x.io.state; x.io.obs_noise = x.f.data(); EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_ERR_INVALID); }
+    { Buffers x(64); x.io.obs = (float*)x.io.state; EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_OK); }
     { Buffers x(64); x.io.terminal_record = x.f.data(); x.io.terminal_stride = 13; EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_ERR_INVALID); }
     { Buffers x(64); x.io.terminal_record = x.f.data(); x.io.terminal_stride = 16; EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_OK); }
     { Buffers x(64); x.io.action_rows = 2; EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_ERR_INVALID); }

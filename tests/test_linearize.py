@@ -495,3 +495,41 @@ def test_linear_model_queries_match_oracle(gpu, system, n):
         worst = max(worst, (np.abs(fl[k] - rf) / scale_f).max(), (np.abs(zl[k] - rz) / np.maximum(np.abs(rz), 1.0)).max())
     assert worst <= 2 * RTOL, worst
     env.close()
+
+
+@pytest.mark.gpu
+def test_linear_model_full_size_properties(gpu):
+    """2^20 envs: size-independent properties of fc_linear_func / fd_linear_func (symbolic_systems.py:93-112).
+    (i) at the expansion point the linear model IS the model: f_lin(x*, u*; x*, u*) == f(x*, u*);
+    (ii) affinity: f_lin(x* + a d) - f_lin(x*) == a (f_lin(x* + d) - f_lin(x*));
+    (iii) fd_linear at (x*, u*) with f(x*, u*) = 0 (hover) is the fixed point x*; (iv) a sampled oracle comparison."""
+    import torch
+    n = 1 << 20
+    env = _make(3, n, randomized_init=True)
+    env.reset()
+    g = torch.Generator(device='cuda'); g.manual_seed(9)
+    xs = env.state.clone()
+    xs[:, 6:9].clamp_(-1.0, 1.0)
+    us = torch.as_tensor(np.asarray(env.U_EQ, dtype=np.float32), device='cuda').expand(n, -1) * \
+        (1 + 0.1 * torch.randn((n, 4), generator=g, device='cuda'))
+    f0 = env.model_linear_dynamics(xs, us, xs, us)
+    f = env.symbolic.fc_func(xs, us)['f']
+    assert float(((f0 - f).abs() / f.abs().clamp(min=1.0)).max()) <= RTOL
+    d = 0.05 * torch.randn((n, 12), generator=g, device='cuda')
+    f1 = env.model_linear_dynamics(xs + d, us, xs, us)
+    f3 = env.model_linear_dynamics(xs + 3 * d, us, xs, us)
+    scale = (f1 - f0).abs().amax(1, keepdim=True).clamp(min=1.0) + f0.abs()
+    assert float((((f3 - f0) - 3 * (f1 - f0)).abs() / scale).max()) <= 8 * RTOL
+    hover = torch.zeros((n, 12), device='cuda'); hover[:, 0:6:2] = xs[:, 0:6:2]
+    ueq = torch.as_tensor(np.asarray(env.U_EQ, dtype=np.float32), device='cuda').expand(n, -1).contiguous()
+    z = env.model_linear_step(hover, ueq, hover, ueq)
+    assert float((z - hover).abs().max()) <= 1e-5
+    idx = np.random.default_rng(1).choice(n, 64, replace=False)
+    ti = torch.as_tensor(idx, device='cuda')
+    p = params_of(3)
+    r64 = lambda t: t[ti].double().cpu().numpy()
+    xe = xs + d
+    for k in range(64):
+        rf = ref_linearize.fc_linear(3, r64(xe)[k], r64(us)[k], r64(xs)[k], r64(us)[k], p)
+        assert (np.abs(r64(f1)[k] - rf) / np.maximum(np.abs(rf), 1.0)).max() <= 4 * RTOL
+    env.close()

@@ -293,6 +293,43 @@ def test_lds_staged_reference_table(gpu):
         compare_step(*sync_step(env, ref, sampler, _actions(env, rng, n)), ref)
 
 
+@pytest.mark.parametrize('name,system,kw', [c for c in FEATURES if 'goal_horizon' in c[0]], ids=lambda v: v if isinstance(v, str) else None)
+@pytest.mark.parametrize('info_level', ['minimal', 'full'])
+def test_goal_horizon_observation_sharing_the_state_planes(gpu, name, system, kw, info_level):
+    """copy_outputs=False with a noise-free goal horizon: one buffer of obs_dim planes whose head is the state
+    (scg_step_io.obs == state; the kernel writes the state once and only the goal rows).  Same numbers as the
+    oracle through resets, auto-resets (short episodes) and the multi-step rollout."""
+    import torch
+    n = 130
+    kw = dict(kw, episode_len_sec=0.5)
+    env, ref, sampler = make_pair(system, n, randomized_init=True, engine_kwargs=dict(copy_outputs=False, info_level=info_level), **kw)
+    obs_e, obs_r = sync_reset(env, ref, sampler)
+    b = env._bufs
+    assert b['obs'].data_ptr() == b['state'].data_ptr() and b['obs'].shape[0] == env.obs_dim > env.state_dim
+    assert rel_err(obs_e.cpu().numpy(), obs_r) <= RTOL
+    rng = np.random.default_rng(23)
+    worst, dones = 0.0, 0
+    for k in range(45):
+        force_state(env, ref)
+        out = sync_step(env, ref, sampler, _actions(env, rng, n))
+        worst = max(worst, compare_step(*out, ref))
+        dones += int(out[1][2].sum())
+        assert torch.equal(out[0][0][:, :env.state_dim], env.state)
+    assert dones >= n, 'the short episodes never ended'
+    # the multi-step rollout leaves the same observation as the step loop
+    twin = make_pair(system, n, randomized_init=True, engine_kwargs=dict(copy_outputs=False, info_level=info_level), **kw)[0]
+    env.seed(5); twin.seed(5)
+    env.reset(); twin.reset()
+    acts = torch.as_tensor(np.stack([_actions(env, rng, n) for _ in range(40)]), device='cuda')
+    for a in acts:
+        o1 = env.step(a)[0]
+    soa = acts.permute(0, 2, 1).contiguous()
+    pad = torch.zeros((40, env.action_dim, twin.plane_stride), device='cuda'); pad[:, :, :n] = soa
+    twin.rollout(pad, steps=40)
+    assert torch.equal(o1, twin._bufs['obs'][:, :n].T) and torch.equal(env.state, twin.state)
+    env.close(); twin.close()
+
+
 def test_constraint_api_on_explicit_state(gpu):
     """Constraint.get_value / is_violated / ConstraintList.get_values through scg_eval_constraints."""
     n = 50
