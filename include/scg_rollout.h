@@ -184,6 +184,10 @@ typedef struct scg_step_io {
                                         cfg.randomized_inertial */
     float* state;                    /* [nx][ld] */
     float* state_lo;                 /* nullable [nx][ld] (or [6][ld], see state_lo_kind) compensation residual (state = hi + lo) */
+    float* state_out;                /* nullable [nx][ld]: where the new state is written; NULL (or == state) = in place.  With
+                                        a buffer of its own `state` is only read: a caller that hands every step's observation
+                                        out as a tensor of its own (the reference returns fresh arrays) passes a new buffer
+                                        here, keeps it as the next step's `state`, and moves no byte twice.  scg_step only */
     int32_t* step_count;             /* [n] ctrl_step_counter */
     float* ep_return;                /* nullable [n] running episode return (record_episode_statistics.py:145) */
     int32_t* ep_length;              /* nullable [n]; NULL: the episode length is read off step_count (the two are equal
@@ -192,7 +196,7 @@ typedef struct scg_step_io {
                                         when a disturbance draws its step_offset per episode */
     /* out */
     float* obs;                      /* nullable [obs_dim][ld]; NULL when the observation IS the state (no goal horizon, no
-                                        observation noise).  obs == state is allowed with a goal horizon and no observation
+                                        observation noise).  obs == state (== state_out if given) is allowed with a goal horizon and no observation
                                         noise: the buffer then holds obs_dim planes, the first nx of which are the state, and
                                         the kernel writes the state once and only the goal rows behind it */
     float* reward;                   /* [n] */

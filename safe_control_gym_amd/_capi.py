@@ -85,7 +85,7 @@ class ScgStepIO(C.Structure):
         ('ld', C.c_int64),
         ('action', _fp), ('action_disturbance', _fp), ('dynamics_force', _fp), ('obs_noise', _fp),
         ('reset_state', _fp),
-        ('inertial', _fp), ('state', _fp), ('state_lo', _fp), ('step_count', _fp), ('ep_return', _fp), ('ep_length', _fp),
+        ('inertial', _fp), ('state', _fp), ('state_lo', _fp), ('state_out', _fp), ('step_count', _fp), ('ep_return', _fp), ('ep_length', _fp),
         ('episode_id', _fp),
         ('obs', _fp), ('reward', _fp), ('done', _fp), ('constraint_values', _fp),
         ('constraint_violation', _fp), ('truncated', _fp), ('goal_reached', _fp), ('mse', _fp),

@@ -397,10 +397,13 @@ int scg_set_disturbances(scg_handle* h, const scg_disturbance* entries, int32_t 
 
 // buffers the attached disturbances need (shared by scg_step / scg_rollout / scg_rollout_fused)
 static int check_dist_io(const scg_handle* h, const scg_step_io* io, const char* who) {
-    if (h->dist_obs && (!io->obs || (const void*)io->obs == (const void*)io->state))
+    const bool obs_is_state = io->obs && (io->obs == io->state || io->obs == io->state_out);
+    if (h->dist_obs && (!io->obs || obs_is_state))
         return fail(SCG_ERR_INVALID, "%s: an observation disturbance needs an obs buffer of its own (obs must not alias state)", who);
-    if (io->obs_noise && (const void*)io->obs == (const void*)io->state)
+    if (io->obs_noise && obs_is_state)
         return fail(SCG_ERR_INVALID, "%s: obs_noise needs an obs buffer of its own (obs must not alias state)", who);
+    if (io->obs && io->state_out && io->state_out != io->state && io->obs == io->state)
+        return fail(SCG_ERR_INVALID, "%s: with state_out, a shared obs buffer must be the one the state is written to (obs == state_out)", who);
     if (h->dist_needs_episode && !io->episode_id)
         return fail(SCG_ERR_INVALID, "%s: a per-episode step_offset needs the episode_id plane", who);
     return SCG_OK;
@@ -597,6 +600,7 @@ int scg_rollout(scg_handle* h, const scg_step_io* io, int64_t n, int32_t steps, 
     if (steps < 0 || action_period < 1 || action_stride < 0)
         return fail(SCG_ERR_INVALID, "scg_rollout: need steps >= 0, action_period >= 1, action_stride >= 0");
     if (io->action_rows) return fail(SCG_ERR_INVALID, "scg_rollout: actions are [period][nu][ld] planes (action_rows must be 0)");
+    if (io->state_out && io->state_out != io->state) return fail(SCG_ERR_INVALID, "scg_rollout: a multi-step rollout updates the state in place (state_out must be NULL)");
     if (n < 0 || io->ld < n || n > (int64_t)1 << 30)
         return fail(SCG_ERR_INVALID, "scg_rollout: need 0 <= n <= ld and n <= 2^30 (n=%lld ld=%lld)", (long long)n, (long long)io->ld);
     if (steps == 0) return SCG_OK;
@@ -671,6 +675,7 @@ int scg_rollout_fused(scg_handle* h, const scg_step_io* io, int64_t n, int32_t s
     if (steps < 0 || action_period < 1 || action_stride < 0)
         return fail(SCG_ERR_INVALID, "scg_rollout_fused: need steps >= 0, action_period >= 1, action_stride >= 0");
     if (io->action_rows) return fail(SCG_ERR_INVALID, "scg_rollout_fused: actions are [period][nu][ld] planes (action_rows must be 0)");
+    if (io->state_out && io->state_out != io->state) return fail(SCG_ERR_INVALID, "scg_rollout_fused: a multi-step rollout updates the state in place (state_out must be NULL)");
     if (steps == 0 || n == 0) return SCG_OK;
     if (!fused_rollout_ok(h->kp, *io)) return scg_rollout(h, io, n, steps, action_stride, action_period, stream);
     if (n < 0 || io->ld < n || n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_rollout_fused: bad n / ld");

@@ -1059,7 +1059,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         // ---- stores (a fused rollout keeps the env in registers until its last step)
         if (last) {
 #pragma unroll
-            for (int j = 0; j < NX; ++j) stp(PLS(io.state, j), i4, x[j]);
+            for (int j = 0; j < NX; ++j) stp(PLS(io.state_out ? io.state_out : io.state, j), i4, x[j]);   // in place or ping-pong
             if (COMP) {
 #pragma unroll
                 for (int j = 0; j < NLO; ++j) stp(PLS(io.state_lo, j), i4, xlo[j]);
@@ -1075,8 +1075,8 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
 
         // ---- _get_observation + extend_obs (quadrotor.py:878-884, benchmark_env.py:406-420)
         if (DIST && io.obs) {
-            // obs == state (noise-free goal-horizon observation): the state planes ARE the first nx obs planes, written above
-            if (reinterpret_cast<const void*>(io.obs) != reinterpret_cast<const void*>(io.state)) {
+            // obs == the state written above (noise-free goal-horizon observation): the state planes ARE the first nx obs planes
+            if (reinterpret_cast<const void*>(io.obs) != reinterpret_cast<const void*>(io.state_out ? io.state_out : io.state)) {
 #pragma unroll
                 for (int j = 0; j < NX; ++j) {
                     float o = x[j] + obs_noise[j];

@@ -159,6 +159,7 @@ class BenchmarkEnv:
         # (an obs buffer apart from the state planes: +4 obs_dim bytes of stores per env-step, no copy kernel); the precise
         # modes, whose kernels are not built with a separate obs buffer, clone the views instead
         self._fresh_outputs = False          # decided in _alloc_buffers
+        self._pingpong = False
         # precise mode: state kept as hi + lo float32 planes and integrated in float64.  True / 'full':
         # every state; 'attitude' (3-D quadrotor): residual planes and float64 arithmetic for the rotational chain only
         # (attitude + body rates), float32 positions and velocities -- 48 B per env-step less, same <= 1e-5 drift bound
@@ -263,6 +264,7 @@ class BenchmarkEnv:
         self._ensure_engine()
         if sd['plane_stride'] != self._ld or set(sd['planes']) != {k for k in self._CHECKPOINT_PLANES if k in self._bufs}:
             raise ValueError('[ERROR] checkpoint was taken from a differently configured env.')
+        self._own_state()
         for k, v in sd['planes'].items():
             self._bufs[k].copy_(v)
         self._reset_state_buf = None if sd['reset_state'] is None else sd['reset_state'].to(self.device).clone()
@@ -451,12 +453,15 @@ class BenchmarkEnv:
             b['constraint_values'] = torch.zeros((self.constraints.num_device_rows, ld), dtype=f32, device=dev)
             b['constraint_violation'] = torch.zeros(ld, dtype=torch.uint8, device=dev)
         self._fresh_outputs = self.COPY_OUTPUTS and not self.COMPENSATED_STATE
-        if self.obs_dim != nx and 'observation' not in self.disturbances and not self.COPY_OUTPUTS:
-            # noise-free goal-horizon observation handed out as a view: one buffer of obs_dim planes whose head IS the state
-            # (scg_step_io.obs == state): the kernel writes the state once and only the goal rows behind it
+        # fresh outputs of a noise-free observation: the state ping-pongs.  Every step writes the new state (scg_step_io.state_out)
+        # into a newly allocated buffer, which IS the observation handed out and the next step's input: no byte is moved twice
+        self._pingpong = self._fresh_outputs and 'observation' not in self.disturbances
+        if self.obs_dim != nx and 'observation' not in self.disturbances and (self._pingpong or not self.COPY_OUTPUTS):
+            # noise-free goal-horizon observation: one buffer of obs_dim planes whose head IS the state (scg_step_io.obs ==
+            # state): the kernel writes the state once and only the goal rows behind it
             b['obs'] = torch.zeros((self.obs_dim, ld), dtype=f32, device=dev)
             b['state'] = b['obs'][:nx]
-        elif self.obs_dim != nx or 'observation' in self.disturbances or self._fresh_outputs:
+        elif self.obs_dim != nx or 'observation' in self.disturbances:
             b['obs'] = torch.zeros((self.obs_dim, ld), dtype=f32, device=dev)
         if self.INFO_LEVEL == 'full':
             b['mse'] = torch.zeros(ld, dtype=f32, device=dev)
@@ -691,6 +696,7 @@ class BenchmarkEnv:
             raise ValueError('[ERROR] rollout() needs a contiguous float32 [T, %d, %d] device tensor.'
                              % (self.action_dim, self._ld))
         steps = actions.shape[0] if steps is None else int(steps)
+        self._own_state()
         io = dict(self._bufs)
         io['reset_state'] = self._reset_state_buf
         self._engine.rollout(io, self.num_envs, self._ld, self._serial, steps, actions, fused=fused)
@@ -720,6 +726,19 @@ class BenchmarkEnv:
         src = self._bufs['obs'] if 'obs' in self._bufs else self._bufs['state']
         return src[:, :self.num_envs].T
 
+    def _own_state(self):
+        """Ping-pong mode: the current state buffer is the observation the last ``step()`` / ``reset()`` handed out.  Whoever
+        is about to write the state IN PLACE (reset, rollout, load_state_dict) first gives the engine a private copy."""
+        if not self._pingpong:
+            return
+        b = self._bufs
+        if 'obs' in b:
+            b['obs'] = b['obs'].clone()
+            b['state'] = b['obs'][:self.state_dim]
+        else:
+            b['state'] = b['state'].clone()
+        self._bound = False
+
     def reset(self, mask=None):
         """(Re-)initialise all envs (or those where ``mask`` is set).  Returns obs or (obs, info).
 
@@ -739,6 +758,7 @@ class BenchmarkEnv:
         if mask is not None:
             m = torch.zeros(self._ld, dtype=torch.uint8, device=self.device)
             m[:self.num_envs] = torch.as_tensor(mask, device=self.device).to(torch.uint8)
+        self._own_state()
         rb = self._bufs
         if self.COMPENSATED_STATE == 'attitude':
             # scg_reset zeroes nx residual planes; this mode has 6: zero them here (masked lanes only)
@@ -751,7 +771,7 @@ class BenchmarkEnv:
         self._bound = False
         self._serial += 1
         obs = self._obs_view()
-        if self.COPY_OUTPUTS:
+        if self.COPY_OUTPUTS and not self._pingpong:          # ping-pong: nobody writes this buffer again (_own_state)
             obs = obs.clone()
         if self.INFO_IN_RESET:
             return obs, self._get_reset_info()
@@ -816,18 +836,32 @@ class BenchmarkEnv:
         self._raw_action, self._raw_action_rows = act, rows
         b = self._bufs
         outs = None
+        new_state = None
         if self._fresh_outputs:
             # copy_outputs: this step's outputs get tensors of their own, written by the kernel (no clone afterwards)
             f32 = torch.float32
-            outs = (torch.empty((self.obs_dim, self._ld), dtype=f32, device=self.device),
-                    torch.empty(self._ld, dtype=f32, device=self.device), torch.empty(self._ld, dtype=torch.bool, device=self.device))
-            b['obs'], b['reward'], b['done'] = outs
+            fresh = torch.empty((self.obs_dim, self._ld), dtype=f32, device=self.device)
+            rew_t = torch.empty(self._ld, dtype=f32, device=self.device)
+            done_t = torch.empty(self._ld, dtype=torch.bool, device=self.device)
+            if self._pingpong:
+                # the new state is written into `fresh` (with the goal rows behind it, if any); the buffer read this step
+                # stays untouched: it is the observation the previous call handed out
+                new_state = fresh
+                outs = (fresh if 'obs' in b else None, rew_t, done_t)
+            else:
+                outs = (fresh, rew_t, done_t)
+                b['obs'] = fresh
+            b['reward'], b['done'] = rew_t, done_t
         if self.adversary_disturbance is not None:
             # adversary inputs (benchmark_env.py:256-266, quadrotor.py:529-536,837-838) arrive as planes; the passive
             # disturbances are generated inside the kernel (scg_set_disturbances)
             io = dict(b)
             io['action'] = act
             io['reset_state'] = self._reset_state_buf
+            if new_state is not None:
+                io['state_out'] = new_state
+                if 'obs' in b:
+                    io['obs'] = new_state
             self._adversary_planes(io)
             self._engine.step(io, self.num_envs, self._ld, self._serial, action_rows=rows)
             self._bound = False
@@ -837,11 +871,15 @@ class BenchmarkEnv:
                 io['reset_state'] = self._reset_state_buf
                 self._engine.bind_static(io, self._ld)
                 self._bound = True
-            self._engine.step_bound(act, self.num_envs, self._serial, action_rows=rows, outs=outs)
+            self._engine.step_bound(act, self.num_envs, self._serial, action_rows=rows, outs=outs, state_out=new_state)
         self._serial += 1
+        if new_state is not None:
+            if 'obs' in b:
+                b['obs'] = new_state
+            b['state'] = new_state[:self.state_dim]
         if outs is not None:
             n = self.num_envs
-            obs, rew, done = outs[0][:, :n].T, outs[1][:n], outs[2][:n]
+            obs, rew, done = (new_state if new_state is not None else outs[0])[:, :n].T, outs[1][:n], outs[2][:n]
         else:
             obs, rew, done = self._out_views
             if self.COPY_OUTPUTS:

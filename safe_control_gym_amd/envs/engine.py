@@ -78,7 +78,7 @@ class Engine:
                         'scg_reset')
 
     _IO_FIELDS = ('action', 'action_disturbance', 'dynamics_force', 'obs_noise', 'reset_state', 'inertial', 'state',
-                  'state_lo', 'step_count', 'ep_return', 'ep_length', 'episode_id', 'obs', 'reward', 'done',
+                  'state_lo', 'state_out', 'step_count', 'ep_return', 'ep_length', 'episode_id', 'obs', 'reward', 'done',
                   'constraint_values', 'constraint_violation', 'truncated', 'goal_reached', 'mse',
                   'terminal_record', 'stats')
 
@@ -106,12 +106,16 @@ class Engine:
         self._bind(bufs, ld)
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
 
-    def step_bound(self, action, n, serial, action_rows=False, outs=None):
-        """Hot path of env.step(): ~4 ctypes stores and one foreign call.  ``outs`` = (obs planes, reward, done) re-points this
-        step's outputs at tensors of the caller's (copy_outputs: fresh ones every step, written by the kernel itself)."""
+    def step_bound(self, action, n, serial, action_rows=False, outs=None, state_out=None):
+        """Hot path of env.step(): ~4 ctypes stores and one foreign call.  ``outs`` = (obs planes or None, reward, done)
+        re-points this step's outputs at tensors of the caller's (copy_outputs: fresh ones every step, written by the kernel
+        itself); ``state_out`` = the buffer the new state goes to, which becomes the bound ``state`` of the next call."""
         io = self._io
         if outs is not None:
-            io.obs, io.reward, io.done = outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr()
+            io.obs = None if outs[0] is None else outs[0].data_ptr()
+            io.reward, io.done = outs[1].data_ptr(), outs[2].data_ptr()
+        if state_out is not None:
+            io.state_out = state_out.data_ptr()
         io.action = action.data_ptr()
         io.action_rows = int(action_rows)
         io.reset_serial = serial & 0xffffffff
@@ -121,7 +125,10 @@ class Engine:
             with torch.cuda.device(self.device):
                 status = self.lib.scg_step(self.handle, self._io_ref, n, self._stream())
         if status != 0:
+            io.state_out = None
             _capi.check(status, 'scg_step')
+        if state_out is not None:
+            io.state, io.state_out = io.state_out, None
 
     def rollout(self, bufs, n, ld, serial, steps, actions, fused=False):
         """``steps`` launches (or one fused launch); ``actions`` is a contiguous [period, nu, ld] float32 tensor

@@ -167,6 +167,14 @@ static void check_step_and_rollout() {
     { Buffers x(64); x.io.obs_noise = x.f.data(); EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_ERR_INVALID); }
     { Buffers x(64); x.io.obs = (float*)x.io.state; x.io.obs_noise = x.f.data(); EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_ERR_INVALID); }
     { Buffers x(64); x.io.obs = (float*)x.io.state; EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_OK); }
+    // state_out: a ping-pong step is fine, obs may share the buffer the state is written to (not the one it is read from),
+    // the multi-step rollouts update in place only
+    { Buffers x(64); std::vector<float> o(64); x.io.state_out = o.data(); EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_OK);
+      x.io.obs = o.data(); EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_OK);
+      x.io.obs = (float*)x.io.state; EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_ERR_INVALID);
+      x.io.obs = nullptr; EXPECT(scg_rollout(h, &x.io, 8, 2, 0, 1, nullptr) == SCG_ERR_INVALID);
+      EXPECT(scg_rollout_fused(h, &x.io, 8, 2, 0, 1, nullptr) == SCG_ERR_INVALID);
+      x.io.state_out = x.io.state; EXPECT(scg_rollout(h, &x.io, 8, 2, 0, 1, nullptr) == SCG_OK); }
     { Buffers x(64); x.io.terminal_record = x.f.data(); x.io.terminal_stride = 13; EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_ERR_INVALID); }
     { Buffers x(64); x.io.terminal_record = x.f.data(); x.io.terminal_stride = 16; EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_OK); }
     { Buffers x(64); x.io.action_rows = 2; EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_ERR_INVALID); }

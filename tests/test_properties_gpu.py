@@ -385,6 +385,81 @@ def test_two_queue_rollout_is_bit_identical_to_the_step_loop(gpu, tier):
     a.close(), b.close()
 
 
+@pytest.mark.parametrize('kw', [dict(task='traj_tracking', cost='quadratic'),
+                                dict(task='traj_tracking', cost='rl_reward', obs_goal_horizon=2, normalized_rl_action_space=True),
+                                dict(task='stabilization', cost='rl_reward', info_level='minimal', copy_outputs=True)],
+                         ids=['default', 'goal_horizon', 'minimal_fresh'])
+def test_fresh_outputs_ping_pong_state(gpu, kw):
+    """copy_outputs=True without observation noise: every step writes the new state into a newly allocated buffer
+    (scg_step_io.state_out) that IS the observation handed out.  (i) same numbers, bit for bit, as a twin env handing out
+    views; (ii) an observation, once handed out, never changes -- not by later steps, a masked reset, a full reset, a
+    rollout() or a checkpoint load; (iii) env.state is the last observation's storage (nothing is moved twice)."""
+    n = 3000
+    base = dict(quad_type=2, num_envs=n, device='cuda', seed=11, randomized_init=True, episode_len_sec=0.4, ctrl_freq=50, pyb_freq=50)
+    env = scg.make('quadrotor', **{**base, **kw})
+    twin = scg.make('quadrotor', **{**base, **kw, 'copy_outputs': False})
+    o0, t0 = env.reset(), twin.reset()
+    assert env._pingpong and not twin._pingpong
+    assert torch.equal(o0, t0)
+    g = torch.Generator(device='cuda'); g.manual_seed(2)
+    lo = torch.as_tensor(env.action_space.low, device='cuda'); hi = torch.as_tensor(env.action_space.high, device='cuda')
+    held, dones = [(o0, o0.clone())], 0
+    for k in range(60):
+        a = torch.rand((n, env.action_dim), generator=g, device='cuda') * (hi - lo) + lo
+        obs, rew, done, info = env.step(a)
+        tobs, trew, tdone, tinfo = twin.step(a)
+        assert torch.equal(obs, tobs) and torch.equal(rew, trew) and torch.equal(done, tdone)
+        assert obs.data_ptr() == env.state.data_ptr()
+        assert torch.equal(obs[:, :env.state_dim], env.state)
+        held.append((obs, obs.clone()))
+        dones += int(done.sum())
+        if k == 20:
+            mask = torch.zeros(n, dtype=torch.bool); mask[::3] = True
+            env.reset(mask=mask); twin.reset(mask=mask)
+        if k == 40:
+            env.load_state_dict(env.state_dict())
+    assert dones > n
+    assert len({h[0].data_ptr() for h in held}) == len(held)
+    ld = env.plane_stride
+    acts = torch.rand((5, env.action_dim, ld), generator=g, device='cuda') * (hi - lo)[None, :, None] + lo[None, :, None]
+    env.rollout(acts); twin.rollout(acts)
+    assert torch.equal(env.state, twin.state)
+    env.reset(); twin.reset()
+    assert torch.equal(env.state, twin.state)
+    for tensor, snapshot in held:
+        assert torch.equal(tensor, snapshot)
+    env.close(); twin.close()
+
+
+def test_state_out_through_the_c_abi(gpu):
+    """scg_step_io.state_out: the new state goes to a buffer of the caller's, `state` is only read; scg_rollout refuses it."""
+    from safe_control_gym_amd import _capi
+    n = 1000
+    env = scg.make('quadrotor', quad_type=3, num_envs=n, device='cuda', seed=4, randomized_init=True, info_level='minimal',
+                   task='traj_tracking', cost='quadratic')
+    env.reset()
+    eng, b, ld = env._engine, env._bufs, env.plane_stride
+    before = b['state'].clone()
+    a = torch.zeros((4, ld), device='cuda'); a[:, :n] = torch.as_tensor(np.asarray(env.U_GOAL, dtype=np.float32), device='cuda')[:, None] * 1.1
+    out = torch.full((12, ld), float('nan'), device='cuda')
+    io = dict(b); io['action'] = a; io['state_out'] = out
+    eng.step(io, n, ld, env._serial)
+    torch.cuda.synchronize()
+    assert torch.equal(b['state'], before)                               # the input was only read
+    step_count = b['step_count'].clone()
+    b['step_count'].zero_()
+    if 'ep_return' in b:
+        b['ep_return'].zero_()
+    io2 = dict(b); io2['action'] = a
+    eng.step(io2, n, ld, env._serial)                                    # the same step in place
+    assert torch.equal(out[:, :n], b['state'][:, :n]) and torch.isnan(out[:, n:]).all()
+    assert torch.equal(step_count[:n], b['step_count'][:n])
+    acts = a[None].contiguous()
+    with pytest.raises(_capi.ScgError, match='state_out'):
+        eng.rollout(dict(io), n, ld, env._serial, 2, acts)
+    env.close()
+
+
 def test_reference_push_after_step_protocol_keeps_the_previous_observation(gpu):
     """The reference's rollout loop (controllers/ppo/ppo.py:259-276) steps the env and runs the observation normaliser
     BEFORE it pushes the previous ``obs`` into the buffer.  With a plain ``make()`` env (copy_outputs defaults to True
