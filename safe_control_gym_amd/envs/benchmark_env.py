@@ -841,8 +841,8 @@ class BenchmarkEnv:
             # copy_outputs: this step's outputs get tensors of their own, written by the kernel (no clone afterwards)
             f32 = torch.float32
             fresh = torch.empty((self.obs_dim, self._ld), dtype=f32, device=self.device)
-            rew_t = torch.empty(self._ld, dtype=f32, device=self.device)
-            done_t = torch.empty(self._ld, dtype=torch.bool, device=self.device)
+            rew_t = torch.empty(self.num_envs, dtype=f32, device=self.device)       # exactly n: the kernel writes lanes < n only
+            done_t = torch.empty(self.num_envs, dtype=torch.bool, device=self.device)
             if self._pingpong:
                 # the new state is written into `fresh` (with the goal rows behind it, if any); the buffer read this step
                 # stays untouched: it is the observation the previous call handed out
@@ -878,8 +878,7 @@ class BenchmarkEnv:
                 b['obs'] = new_state
             b['state'] = new_state[:self.state_dim]
         if outs is not None:
-            n = self.num_envs
-            obs, rew, done = (new_state if new_state is not None else outs[0])[:, :n].T, outs[1][:n], outs[2][:n]
+            obs, rew, done = (new_state if new_state is not None else outs[0])[:, :self.num_envs].T, outs[1], outs[2]
         else:
             obs, rew, done = self._out_views
             if self.COPY_OUTPUTS:
