@@ -39,6 +39,7 @@ import os
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -99,11 +100,12 @@ def spawn_ranks(args, argv):
     world = args.gpus
     port = _free_port()
     procs = []
+    rank0_out = tempfile.TemporaryFile(mode='w+')          # a file, not a pipe: rank 0 can never block on a full pipe
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+                                      stdout=rank0_out if r == 0 else subprocess.DEVNULL, text=True))
     deadline = time.time() + args.spawn_timeout
     failed = None
     pending = set(range(world))
@@ -133,7 +135,8 @@ def spawn_ranks(args, argv):
         who = 'timeout after %.0f s' % args.spawn_timeout if failed[0] < 0 else 'rank %d exited with %d' % failed
         sys.stderr.write('bench.py: %s; the other ranks were stopped\n' % who)
         return failed[1] if failed[1] != 0 else 1
-    out = procs[0].stdout.read()
+    rank0_out.seek(0)
+    out = rank0_out.read()
     line = None
     for ln in out.splitlines():
         if ln.startswith('{'):
