@@ -326,7 +326,7 @@ def dry_run_rank(args):
     returns = torch.arange(rank * n, (rank + 1) * n, dtype=torch.float32)
     if world > 1:
         dist.all_reduce(ones)
-        gathered = parallel.all_gather_episode_returns(returns, total_envs=n * world)
+        gathered = parallel.begin_all_gather_episode_returns(returns, total_envs=n * world).wait()    # as the timed region does
     else:
         gathered = returns
     ok = bool(torch.equal(gathered, torch.arange(n * world, dtype=torch.float32)))
@@ -372,10 +372,13 @@ def run_rank(args):
         done_steps = 0
         while done_steps < steps:
             chunk = min(GATHER_EVERY, steps - done_steps) if world > 1 else steps - done_steps
+            # the exchange of the path: the returns as of this chunk's start travel over xGMI on RCCL's stream
+            # while the chunk's step kernels run; the region ends only after the gather has landed (wait + the closing fence)
+            pending = parallel.begin_all_gather_episode_returns(env.episode_return, total_envs=n * world) if world > 1 else None
             env.rollout(actions, steps=chunk)
             done_steps += chunk
-            if world > 1:
-                parallel.all_gather_episode_returns(env.episode_return, total_envs=n * world)
+            if pending is not None:
+                pending.wait()
 
     # every rank proves itself to the collective backend: a sum of ones on the device the rank computes on
     ranks_seen, backend = 1, 'none'
@@ -453,8 +456,8 @@ def run_rank(args):
                                   'pass over the whole batch') if two_queues else
                                  'one fused scg_step kernel per step (scg_rollout issues the launches)',
                        'launches_per_step': 2 if two_queues else 1,
-                       'sharding': 'envs block-sharded by global index; all-gather of episode returns every '
-                                   '%d steps' % GATHER_EVERY if world > 1 else 'single GPU'},
+                       'sharding': 'envs block-sharded by global index; all-gather of episode returns (RCCL, asynchronous, overlapping the step '
+                                   'kernels) at least every %d steps and once per timed region' % GATHER_EVERY if world > 1 else 'single GPU'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'kernel_us_per_launch': step_us, 'bytes_per_launch': moved_bytes * n,

@@ -79,6 +79,34 @@ def all_gather_episode_returns(local_returns, total_envs=None, force_collective=
     return torch.cat([out[r * width:r * width + counts[r]] for r in range(world)])
 
 
+class PendingGather:
+    """An all-gather of episode returns in flight (``begin_all_gather_episode_returns``); ``wait()`` -> the [total] tensor."""
+
+    def __init__(self, out, work, deferred=None, keep=None):
+        self._out, self._work, self._deferred, self._keep = out, work, deferred, keep     # keep: the snapshot being sent
+
+    def wait(self):
+        if self._deferred is not None:                      # no asynchronous path for this backend / shard shape
+            self._out, self._deferred = self._deferred(), None
+        elif self._work is not None:
+            self._work.wait()                               # RCCL: the current stream waits, the host does not
+            self._work = None
+        return self._out
+
+
+def begin_all_gather_episode_returns(local_returns, total_envs=None, force_collective=False):
+    """Start the all-gather on a SNAPSHOT of the returns and hand back a ``PendingGather``: the step kernels issued next keep
+    updating the plane while RCCL moves the snapshot over xGMI on its own stream (the exchange costs the step path nothing).
+    Even shards over RCCL run asynchronously; gloo, uneven shards and a world of one complete inside ``wait()``."""
+    snap = local_returns.clone()
+    ready = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective)
+    if ready and dist.get_backend() == 'nccl' and total_envs is not None and total_envs % dist.get_world_size() == 0:
+        out = torch.empty(dist.get_world_size() * snap.shape[0], dtype=snap.dtype, device=snap.device)
+        return PendingGather(out, dist.all_gather_into_tensor(out, snap, async_op=True), keep=snap)
+    return PendingGather(None, None, deferred=lambda: all_gather_episode_returns(snap, total_envs=total_envs,
+                                                                                 force_collective=force_collective))
+
+
 def all_reduce_stats(stats):
     """Sum a small stats tensor (e.g. the kernel's [8] batch sums) over ranks."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

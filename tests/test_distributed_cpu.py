@@ -25,6 +25,10 @@ def _worker(rank, world, port, total, q):
     local = torch.arange(lo, hi, dtype=torch.float32) * 0.5 + 1.0          # "episode return" of global env i
     gathered = parallel.all_gather_episode_returns(local, total_envs=total)
     gathered2 = parallel.all_gather_episode_returns(local)                  # sizes discovered by a collective
+    pending = parallel.begin_all_gather_episode_returns(local, total_envs=total)     # the form bench.py overlaps with the steps
+    local += 100.0                                                          # the plane keeps changing: a snapshot travels
+    assert torch.equal(pending.wait(), gathered)
+    local -= 100.0
     stats = parallel.all_reduce_stats(torch.tensor([float(hi - lo), float(local.sum())], dtype=torch.float64))
     q.put((rank, gathered.numpy(), gathered2.numpy(), stats.numpy()))
     dist.barrier()
@@ -64,6 +68,9 @@ def test_single_process_passthrough():
     from safe_control_gym_amd import parallel
     x = torch.arange(5, dtype=torch.float32)
     assert torch.equal(parallel.all_gather_episode_returns(x), x)
+    pending = parallel.begin_all_gather_episode_returns(x, total_envs=5)
+    x += 1
+    assert torch.equal(pending.wait(), x - 1)
 
 
 # ---- the launcher of bench.py: `python bench.py --gpus N` starts its own N ranks (no GPU call in the parent) -----------

@@ -595,6 +595,21 @@ def test_all_gather_of_episode_returns_through_rccl(gpu):
             dist.all_reduce(ones)
             torch.cuda.synchronize()
             assert torch.equal(x, y) and torch.equal(x, z) and y.data_ptr() != x.data_ptr() and int(ones.item()) == 1
+            # the asynchronous form bench.py uses: RCCL gathers a snapshot on its own stream while step kernels keep updating
+            # the plane; the gathered values are those at the time of the call
+            env = scg.make('quadrotor', quad_type=3, num_envs=1 << 16, device='cuda', seed=3, randomized_init=True,
+                           task='traj_tracking', cost='quadratic', info_level='minimal', track_episode_stats=True)
+            env.reset()
+            acts = torch.zeros((1, 4, env.plane_stride), device='cuda') + float(env.action_space.high[0]) * 0.6
+            env.rollout(acts, steps=7)
+            before = env.episode_return.clone()
+            pending = parallel.begin_all_gather_episode_returns(env.episode_return, total_envs=1 << 16, force_collective=True)
+            assert pending._work is not None                           # the RCCL path, not the deferred one
+            env.rollout(acts, steps=30)
+            got = pending.wait()
+            torch.cuda.synchronize()
+            assert torch.equal(got, before) and not torch.equal(env.episode_return, before)
+            env.close()
         finally:
             dist.destroy_process_group()
 
