@@ -431,6 +431,36 @@ def test_fresh_outputs_ping_pong_state(gpu, kw):
     env.close(); twin.close()
 
 
+def test_rollout_is_capturable_in_a_hip_graph(gpu):
+    """env.rollout() with one launch queue only enqueues kernels on the current stream, so it can be captured in a HIP graph
+    (torch.cuda.graph) and replayed: the replay leaves the same buffers as the plain call.  The reset serials are kernel
+    arguments, i.e. part of the capture: every replay of one graph draws the same reset offsets (documented in INTEGRATION.md)."""
+    n, K = 1 << 14, 40
+    kw = dict(num_envs=n, device='cuda', seed=9, randomized_init=True, task='stabilization', cost='quadratic', ctrl_freq=50,
+              pyb_freq=50, episode_len_sec=0.3, info_level='minimal', track_episode_stats=True, rollout_queues=1)
+    a, b = scg.make('cartpole', **kw), scg.make('cartpole', **kw)
+    a.reset(), b.reset()
+    g = torch.Generator(device='cuda'); g.manual_seed(1)
+    lo, hi = float(a.action_space.low[0]), float(a.action_space.high[0])
+    acts = torch.rand((7, 1, a.plane_stride), generator=g, device='cuda') * (hi - lo) + lo
+    a.rollout(acts, steps=10)
+    a.rollout(acts, steps=K)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        b.rollout(acts, steps=10)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            b.rollout(acts, steps=K)
+    torch.cuda.synchronize()
+    assert int(b.ctrl_step_counter.max()) <= 10                       # the capture itself ran nothing
+    graph.replay()
+    torch.cuda.synchronize()
+    for key in ('state', 'step_count', 'ep_return', 'reward', 'done'):
+        assert torch.equal(a._bufs[key], b._bufs[key]), key
+    a.close(), b.close()
+
+
 def test_state_out_through_the_c_abi(gpu):
     """scg_step_io.state_out: the new state goes to a buffer of the caller's, `state` is only read; scg_rollout refuses it."""
     from safe_control_gym_amd import _capi
