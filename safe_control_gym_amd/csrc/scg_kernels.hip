@@ -593,13 +593,14 @@ __device__ __forceinline__ PhysT<T> phys_of_env(const PhysT<T>& shared, const KT
 enum Feat : uint32_t {
     FT_TRACK = 1u,   // Task.TRAJ_TRACKING: LDS-staged X_GOAL table (else the constant stabilisation goal)
     FT_CON = 2u,     // a ConstraintList is attached
-    FT_EXTRA = 4u,   // everything else: disturbances, separate obs buffer (+noise, +goal horizon), per-env inertial
-                     // properties, stats sums, non-diagonal Q or R, normalised action space.  In this tier
+    FT_EXTRA = 4u,   // everything else: adversary / explicit noise planes (action_disturbance, dynamics_force, obs_noise), per-env
+                     // inertial properties, stats sums, non-diagonal Q or R, aero terms, non-uniform reset draws.  In this tier
                      // FT_TRACK / FT_CON are run-time decisions again.
-    FT_DIST = 16u,   // FT_INFO + a separate obs buffer: the passive disturbances drawn in the kernel (scg_set_disturbances: action /
-                     // dynamics / observation noise, per-episode offsets), the goal horizon appended to the observation
-                     // (benchmark_env.py:406-420) and kernel-written fresh outputs -- the usual RL configurations (normalised
-                     // actions are a run-time branch of every tier), without the run-time branches of the catch-all tier
+    FT_DIST = 16u,   // FT_INFO + an obs buffer (io.obs; it may BE the state buffer, obs == state / state_out: then only the goal
+                     // rows are written): the passive disturbances drawn in the kernel (scg_set_disturbances: action / dynamics /
+                     // observation noise, per-episode offsets) and the goal horizon appended to the observation
+                     // (benchmark_env.py:406-420) -- the usual RL configurations without the run-time branches of the catch-all
+                     // tier.  Normalised actions are a wave-uniform run-time branch of EVERY tier.
     FT_INFO = 8u,    // the per-step info outputs of the default API (info_level='full'): mse / goal_reached /
                      // truncated / terminal_record (terminal obs = the state: obs aliases it in this tier).  A tier of its
                      // own because it is what make() gives by default: 43 us in the EXTRA tier at 2^20 envs.
