@@ -103,17 +103,21 @@ def methods(rel, cls, names, ns):
     return [(rel, '%s.%s' % (cls, n), _find(c.body, n).lineno, _find(c.body, n).end_lineno) for n in names]
 
 
-def method_statements(rel, cls, name, pick, fn_name, ns, returns=None):
+def method_statements(rel, cls, name, pick, fn_name, ns, returns=None, body=None):
     """A run of statements of method `cls.name` selected by `pick(stmt) -> bool`, wrapped unchanged into a function
-    ``fn_name(self)`` (for __init__ blocks, and for methods whose tail calls PyBullet); `returns` names a local of those
-    statements that the wrapper hands back (a method cut before its own ``return``)."""
+    ``fn_name(self)`` (for __init__ blocks, and for methods whose tail calls PyBullet or gym); `returns` names a local (or a
+    tuple of locals) of those statements that the wrapper hands back (a method cut before its own ``return``); `body(method)`
+    picks a nested statement list (a branch of an ``if``) instead of the method's top level."""
     tree, path = _tree(rel)
     m = _find(_find(tree.body, cls).body, name)
-    chosen = [s for s in m.body if pick(s)]
+    chosen = [s for s in (body(m) if body else m.body) if pick(s)]
     assert chosen, (rel, cls, name)
     first, last = chosen[0].lineno, chosen[-1].end_lineno
     if returns:
-        chosen = chosen + [ast.Return(value=ast.Name(id=returns, ctx=ast.Load()))]
+        names = [returns] if isinstance(returns, str) else list(returns)
+        value = ast.Name(id=names[0], ctx=ast.Load()) if len(names) == 1 else \
+            ast.Tuple(elts=[ast.Name(id=n, ctx=ast.Load()) for n in names], ctx=ast.Load())
+        chosen = chosen + [ast.Return(value=value)]
     fn = ast.FunctionDef(name=fn_name, args=ast.arguments(posonlyargs=[], args=[ast.arg(arg='self')], kwonlyargs=[],
                                                            kw_defaults=[], defaults=[]),
                          body=chosen, decorator_list=[], lineno=first, col_offset=0)
@@ -186,6 +190,38 @@ SOURCES += method_statements('envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor
                              returns='info')
 
 
+# _set_observation_space: the thresholds and the low / high arrays of the state bounds -- everything before the first gym call
+# (self.state_space = spaces.Box(low, high), which casts to float32)
+_seen_box = []
+
+
+def _until_state_space(stmt):
+    if _seen_box or _assigns_self(stmt, 'state_space'):
+        _seen_box.append(1)
+        return False
+    return not (isinstance(stmt, ast.Expr) and isinstance(stmt.value, ast.Constant))
+
+
+SOURCES += method_statements('envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor', '_set_observation_space', _until_state_space,
+                             'state_bounds', NS, returns=('low', 'high'))
+
+
+# _set_action_space: the two thrust-bound statements of its direct-thrust branch (the statements around them construct gym spaces)
+def _direct_thrust_branch(method):
+    branch = [s for s in method.body if isinstance(s, ast.If) and 'NORMALIZED_RL_ACTION_SPACE' in ast.unparse(s.test)][-1]
+    return [ast.Assign(targets=[ast.Name(id='action_dim', ctx=ast.Store())],
+                       value=ast.Attribute(value=ast.Name(id='self', ctx=ast.Load()), attr='action_dim_', ctx=ast.Load()),
+                       lineno=branch.lineno)] + branch.orelse
+
+
+def _thrust_bound(stmt):
+    return isinstance(stmt, ast.Assign) and isinstance(stmt.targets[0], ast.Name) and stmt.targets[0].id in ('action_dim', 'n_motors', 'a_low', 'a_high')
+
+
+SOURCES += method_statements('envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor', '_set_action_space', _thrust_bound, 'thrust_bounds', NS,
+                             returns=('a_low', 'a_high'), body=_direct_thrust_branch)
+
+
 def GENERAL_CONSTRAINTS():
     return {'linear_constraint': NS['LinearConstraint'], 'quadratic_constraint': NS['QuadraticContstraint'],
             'bounded_constraint': NS['BoundedConstraint'], 'default_constraint': NS['DefaultConstraint'],
@@ -206,30 +242,38 @@ def put(key, value):
 
 
 def spaces(quad_type):
-    """Bounds as gym.spaces.Box(dtype=float32) would hold them (quadrotor.py:742-791): float32 arrays."""
-    r85, r180 = 85 * math.pi / 180, math.pi
-    if quad_type == 1:
-        low, high = [0, -F32MAX], [2.5, F32MAX]
-    elif quad_type == 2:
-        low, high = [-5, -F32MAX, 0, -F32MAX, -r85, -F32MAX], [5, F32MAX, 2.5, F32MAX, r85, F32MAX]
-    else:
-        low = [-5, -F32MAX, -5, -F32MAX, 0, -F32MAX, -r85, -r85, -r180, -F32MAX, -F32MAX, -F32MAX]
-        high = [5, F32MAX, 5, F32MAX, 2.5, F32MAX, r85, r85, r180, F32MAX, F32MAX, F32MAX]
-    return Holder(low=np.array(low, dtype=np.float32), high=np.array(high, dtype=np.float32), shape=(len(low),))
+    """The state bounds as the reference's own statements build them (quadrotor.py:742-791, executed), cast to float32 as
+    gym.spaces.Box(dtype=float32) holds them."""
+    h = Holder(QUAD_TYPE=NS['QuadType'](quad_type), GROUND_PLANE_Z=0)          # base_aviary.py:121
+    low, high = types.MethodType(NS['state_bounds'], h)()
+    return Holder(low=np.asarray(low, dtype=np.float32), high=np.asarray(high, dtype=np.float32), shape=(len(low),))
 
 
 def action_space(quad_type, normalized=False):
-    """quadrotor.py:720-733."""
+    """quadrotor.py:720-733: the direct-thrust bounds from the reference's own two statements (executed)."""
     nu = {1: 1, 2: 2, 3: 4}[quad_type]
     if normalized:
         return Holder(low=-np.ones(nu, dtype=np.float32), high=np.ones(nu, dtype=np.float32), shape=(nu,))
-    n_motor = 4 / nu
-    a_low = CF['KF'] * n_motor * (CF['PWM2RPM_SCALE'] * CF['MIN_PWM'] + CF['PWM2RPM_CONST']) ** 2
-    a_high = CF['KF'] * n_motor * (CF['PWM2RPM_SCALE'] * CF['MAX_PWM'] + CF['PWM2RPM_CONST']) ** 2
-    return Holder(low=np.full(nu, np.float32(a_low)), high=np.full(nu, np.float32(a_high)), shape=(nu,))
+    h = Holder(action_dim_=nu, **CF)
+    a_low, a_high = types.MethodType(NS['thrust_bounds'], h)()
+    return Holder(low=np.full(nu, a_low, np.float32), high=np.full(nu, a_high, np.float32), shape=(nu,))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def gen_spaces(rng):
+    cases = []
+    for qt in (1, 2, 3):
+        sp, ac = spaces(qt), action_space(qt)
+        put('spaces/q%d/state_low' % qt, sp.low)
+        put('spaces/q%d/state_high' % qt, sp.high)
+        put('spaces/q%d/thrust_low' % qt, ac.low)
+        put('spaces/q%d/thrust_high' % qt, ac.high)
+        cases.append('q%d' % qt)
+    MANIFEST['groups']['spaces'] = dict(cases=cases, note='state bounds: the statements of Quadrotor._set_observation_space before its '
+                                        'first gym call; thrust bounds: the a_low / a_high statements of _set_action_space; both cast '
+                                        'to float32 as spaces.Box(dtype=np.float32) does; GROUND_PLANE_Z = 0 (base_aviary.py:121)')
+
+
 def gen_motor_map(rng):
     cases = []
     for nu in (1, 2, 4):
@@ -625,6 +669,7 @@ def main():
     gen_normalization(rng)
     gen_discretize(rng)        # (appended: earlier groups keep the random stream they were first written with)
     gen_vec_env(rng)
+    gen_spaces(rng)            # (appended; draws nothing)
     OUT['manifest'] = np.array(json.dumps(MANIFEST))
     np.savez_compressed(os.path.join(HERE, 'reference_numpy.npz'), **OUT)
     print('wrote %d arrays, %d reference symbols executed' % (len(OUT) - 1, len(SOURCES)))
