@@ -168,7 +168,7 @@ SOURCES += top_level('math_and_models/normalization.py', ['RunningMeanStd', 'Bas
                                                           'RewardStdNormalizer'], NS)
 SOURCES += methods('envs/benchmark_env.py', 'BenchmarkEnv', ['_generate_trajectory', '_get_coordinates', '_figure8', '_circle',
                                                              '_square', 'before_step', 'extend_obs', 'after_step',
-                                                             '_check_initial_reset'], NS)
+                                                             '_check_initial_reset', '_randomize_values_by_info'], NS)
 SOURCES += methods('envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor', ['_preprocess_control', '_get_reward', '_get_done'], NS)
 SOURCES += method_statements('envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor', '__init__',
                              lambda s: _assigns_self(s, 'U_GOAL') or _tests_task(s), 'build_goals', NS)
@@ -596,6 +596,36 @@ def gen_discretize(rng):
     MANIFEST['groups']['discretize'] = dict(cases=cases)
 
 
+RAND_SPECS = {
+    'a_normal_kw': {'distrib': 'normal', 'loc': 0.1, 'scale': 0.2}, 'b_normal_args': {'distrib': 'normal', 'args': [-0.3], 'scale': 0.05},
+    'c_standard_normal': {'distrib': 'standard_normal'}, 'd_exponential': {'distrib': 'exponential', 'scale': 0.3},
+    'e_laplace': {'distrib': 'laplace', 'loc': 0.2, 'scale': 0.1}, 'f_logistic': {'distrib': 'logistic', 'args': [0.0, 0.05]},
+    'g_triangular': {'distrib': 'triangular', 'left': -0.2, 'mode': 0.1, 'right': 0.3}, 'h_randint': {'distrib': 'randint', 'low': -2, 'high': 3},
+    'i_randint_one_arg': {'distrib': 'randint', 'args': [4]}, 'j_uniform': {'distrib': 'uniform', 'low': -0.05, 'high': 0.15},
+    'k_uniform_args': {'distrib': 'uniform', 'args': [-0.5], 'high': 0.25},
+}
+
+
+def gen_randomization(rng):
+    """BenchmarkEnv._randomize_values_by_info (benchmark_env.py:277-308) with numpy.random.RandomState standing where gym's
+    seeding.np_random puts one (gym 0.21: a RandomState): value = original + np_random.<distrib>(*args, **kwargs), keys visited
+    in the order of `original_values`, keys without an info entry untouched, the info dict not consumed."""
+    original = {k: 0.25 * (i + 1) for i, k in enumerate(sorted(RAND_SPECS))}
+    original['z_untouched'] = 7.0
+    info = copy.deepcopy(RAND_SPECS)
+    h = Holder(np_random=np.random.RandomState(2024))
+    bind(h, NS, ['_randomize_values_by_info'])
+    rows = []
+    for _ in range(48):
+        out = h._randomize_values_by_info(original, info)
+        rows.append([out[k] for k in sorted(original)])
+    assert info == RAND_SPECS, 'the reference consumed the caller\'s info dict'
+    put('randomization/values', np.asarray(rows, dtype=np.float64))
+    put('randomization/original', [original[k] for k in sorted(original)])
+    MANIFEST['groups']['randomization'] = dict(keys=sorted(original), specs=RAND_SPECS, seed=2024, calls=48,
+                                               note='rows = successive calls with one RandomState(seed); columns = sorted keys')
+
+
 def gen_vec_env(rng):
     from toy_env import ToyEnv
     horizons = [3, 5, 4, 7]
@@ -670,6 +700,7 @@ def main():
     gen_discretize(rng)        # (appended: earlier groups keep the random stream they were first written with)
     gen_vec_env(rng)
     gen_spaces(rng)            # (appended; draws nothing)
+    gen_randomization(rng)     # (appended; its own RandomState)
     OUT['manifest'] = np.array(json.dumps(MANIFEST))
     np.savez_compressed(os.path.join(HERE, 'reference_numpy.npz'), **OUT)
     print('wrote %d arrays, %d reference symbols executed' % (len(OUT) - 1, len(SOURCES)))

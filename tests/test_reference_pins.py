@@ -33,7 +33,8 @@ def test_manifest_lists_the_executed_reference_symbols():
                  ('safe_control_gym/envs/benchmark_env.py', 'BenchmarkEnv.after_step'),
                  ('safe_control_gym/envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor._get_done'),
                  ('safe_control_gym/envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor._set_observation_space statements'),
-                 ('safe_control_gym/envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor._set_action_space statements')):
+                 ('safe_control_gym/envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor._set_action_space statements'),
+                 ('safe_control_gym/envs/benchmark_env.py', 'BenchmarkEnv._randomize_values_by_info')):
         assert want in syms
     assert all(s['lines'][0] <= s['lines'][1] for s in MANIFEST['sources'])
 
@@ -41,6 +42,39 @@ def test_manifest_lists_the_executed_reference_symbols():
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU: the oracle (and the package's host-side tables) against the reference's output
 # ---------------------------------------------------------------------------------------------------------------------
+def test_randomisation_semantics_match_reference_function():
+    """BenchmarkEnv._randomize_values_by_info (benchmark_env.py:277-308), executed with a RandomState: the package's parser
+    (envs/randomization.py) binds every entry to (kind, parameters); those parameters, handed to the same RandomState methods in
+    the same order and ADDED to the originals, reproduce the reference's values bit for bit -- i.e. kind, argument binding,
+    the additive rule, the visiting order and the untouched keys all agree with the executed function."""
+    from safe_control_gym_amd import _capi
+    from safe_control_gym_amd.envs.randomization import parse_distribution
+    g = GROUPS['randomization']
+    keys, specs = g['keys'], g['specs']
+    want, original = G['randomization/values'], G['randomization/original']
+    rs = np.random.RandomState(g['seed'])
+    call = {_capi.SCG_RAND_UNIFORM: lambda lo, hi, p: rs.uniform(lo, hi),
+            _capi.SCG_RAND_NORMAL: lambda lo, hi, p: rs.normal(p[0], p[1]),
+            _capi.SCG_RAND_EXPONENTIAL: lambda lo, hi, p: rs.exponential(p[0]),
+            _capi.SCG_RAND_LAPLACE: lambda lo, hi, p: rs.laplace(p[0], p[1]),
+            _capi.SCG_RAND_LOGISTIC: lambda lo, hi, p: rs.logistic(p[0], p[1]),
+            _capi.SCG_RAND_TRIANGULAR: lambda lo, hi, p: rs.triangular(p[0], p[1], p[2]),
+            _capi.SCG_RAND_RANDINT: lambda lo, hi, p: rs.randint(int(p[0]), int(p[1]))}
+    got = np.empty_like(want)
+    for r in range(g['calls']):
+        for c, k in enumerate(keys):                                   # the reference walks `original_values` in its own order
+            if k not in specs:
+                got[r, c] = original[c]
+                continue
+            kind, lo, hi, prm = parse_distribution(specs[k], k)
+            if specs[k]['distrib'] == 'standard_normal':
+                got[r, c] = original[c] + rs.standard_normal()         # its own RandomState method (a different stream use)
+            else:
+                got[r, c] = original[c] + call[kind](lo, hi, prm)
+    assert np.array_equal(got, want)
+    assert want[:, keys.index('z_untouched')].tolist() == [7.0] * g['calls']
+
+
 @pytest.mark.parametrize('qt', [1, 2, 3])
 def test_state_and_thrust_bounds_match_reference_statements(qt):
     """The out-of-bound box of `_get_done` and the thrust clip: the reference's own statements of `_set_observation_space` /
