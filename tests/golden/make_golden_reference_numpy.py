@@ -158,7 +158,7 @@ SOURCES += top_level('math_and_models/transformations.py', ['unit_vector', 'proj
 SOURCES += top_level('envs/constraints.py', ['ConstrainedVariableType', 'Constraint', 'QuadraticContstraint', 'LinearConstraint',
                                              'BoundedConstraint', 'DefaultConstraint', 'SymmetricStateConstraint',
                                              'get_symbolic_constraint_models', 'ConstraintList', 'create_constraint_list'], NS)
-SOURCES += top_level('controllers/ppo/ppo_utils.py', ['compute_returns_and_advantages'], NS)
+SOURCES += top_level('controllers/ppo/ppo_utils.py', ['compute_returns_and_advantages', 'PPOBuffer', 'random_sample'], NS)
 SOURCES += top_level('controllers/mpc/mpc_utils.py', ['discretize_linear_system'], NS)
 SOURCES += top_level('envs/env_wrappers/vectorized_env/vec_env_utils.py', ['tile_images', '_flatten_obs', '_flatten_list'], NS)
 SOURCES += top_level('envs/env_wrappers/vectorized_env/vec_env.py', ['VecEnv', 'VecEnvWrapper'], NS)
@@ -626,6 +626,45 @@ def gen_randomization(rng):
                                                note='rows = successive calls with one RandomState(seed); columns = sorted keys')
 
 
+def gen_ppo_buffer(rng):
+    """PPOBuffer (ppo_utils.py:282-407) and random_sample (:410-426).  `Box` is only the right-hand side of one isinstance():
+    bound to an empty class, the action space is then read through `.n` (the reference's own second branch)."""
+    import torch
+    NS['Box'] = type('Box', (), {})
+    NS['torch'] = torch
+    T, N, od, ad = 5, 3, 4, 2
+    buf = NS['PPOBuffer'](Holder(shape=(od,)), Holder(n=ad), T, N)
+    pushes = []
+    for k in range(7):                                                  # two more than max_length: the ring wraps
+        b = {'obs': rng.normal(size=(N, od)), 'act': rng.normal(size=(N, ad)), 'rew': rng.normal(size=N), 'mask': (rng.uniform(size=N) > 0.3) * 1.0,
+             'v': rng.normal(size=(N, 1)), 'logp': rng.normal(size=N), 'terminal_v': rng.normal(size=N)}
+        if k == 3:
+            b.pop('logp')                                               # a partial push leaves the other containers alone
+        pushes.append(b)
+        buf.push(b)
+        for key, v in b.items():
+            put('ppo_buffer/push%d/%s' % (k, key), v)
+    put('ppo_buffer/t', buf.t)
+    got = buf.get()
+    for key in buf.keys:
+        put('ppo_buffer/get/%s' % key, got[key].numpy())
+    idx = np.array([0, 14, 7, 3, 11])
+    smp = buf.sample(idx)
+    put('ppo_buffer/sample_indices', idx)
+    for key in buf.keys:
+        put('ppo_buffer/sample/%s' % key, smp[key])
+    sizes = {}
+    for drop_last in (True, False):
+        np.random.seed(5)
+        batches = [b['obs'].shape[0] for b in buf.sampler(4, drop_last=drop_last)]
+        np.random.seed(5)
+        ids = np.concatenate(list(NS['random_sample'](np.arange(T * N), 4, drop_last)))
+        sizes[str(drop_last)] = batches
+        put('ppo_buffer/sampler_indices_drop_last_%s' % drop_last, ids)
+    MANIFEST['groups']['ppo_buffer'] = dict(T=T, N=N, obs_dim=od, act_dim=ad, pushes=7, keys=list(buf.keys), sampler_batch_sizes=sizes,
+                                            push_keys=[sorted(b.keys()) for b in pushes])
+
+
 def gen_vec_env(rng):
     from toy_env import ToyEnv
     horizons = [3, 5, 4, 7]
@@ -701,6 +740,7 @@ def main():
     gen_vec_env(rng)
     gen_spaces(rng)            # (appended; draws nothing)
     gen_randomization(rng)     # (appended; its own RandomState)
+    gen_ppo_buffer(np.random.default_rng(77))     # (appended; its own generator)
     OUT['manifest'] = np.array(json.dumps(MANIFEST))
     np.savez_compressed(os.path.join(HERE, 'reference_numpy.npz'), **OUT)
     print('wrote %d arrays, %d reference symbols executed' % (len(OUT) - 1, len(SOURCES)))

@@ -34,7 +34,8 @@ def test_manifest_lists_the_executed_reference_symbols():
                  ('safe_control_gym/envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor._get_done'),
                  ('safe_control_gym/envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor._set_observation_space statements'),
                  ('safe_control_gym/envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor._set_action_space statements'),
-                 ('safe_control_gym/envs/benchmark_env.py', 'BenchmarkEnv._randomize_values_by_info')):
+                 ('safe_control_gym/envs/benchmark_env.py', 'BenchmarkEnv._randomize_values_by_info'),
+                 ('safe_control_gym/controllers/ppo/ppo_utils.py', 'PPOBuffer')):
         assert want in syms
     assert all(s['lines'][0] <= s['lines'][1] for s in MANIFEST['sources'])
 
@@ -42,6 +43,38 @@ def test_manifest_lists_the_executed_reference_symbols():
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU: the oracle (and the package's host-side tables) against the reference's output
 # ---------------------------------------------------------------------------------------------------------------------
+def test_ppo_buffer_matches_reference_class():
+    """PPOBuffer (ppo_utils.py:282-407), executed: ring index, partial pushes, mask initialised to ones, the time-major flattening of
+    get() / sample(), and the mini-batch structure of sampler() (a permutation cut into batches, the remainder kept or dropped)."""
+    import torch
+    from safe_control_gym_amd.controllers.ppo.ppo_utils import PPOBuffer
+    g = GROUPS['ppo_buffer']
+    T, N = g['T'], g['N']
+
+    class Space:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+    buf = PPOBuffer(Space(shape=(g['obs_dim'],)), Space(shape=(g['act_dim'],)), T, N, device='cpu')
+    assert buf.keys == g['keys']
+    for k in range(g['pushes']):
+        buf.push({key: torch.as_tensor(G['ppo_buffer/push%d/%s' % (k, key)]) for key in g['push_keys'][k]})
+    assert buf.t == int(G['ppo_buffer/t'])
+    got = buf.get()
+    for key in buf.keys:
+        assert np.array_equal(got[key].numpy(), G['ppo_buffer/get/%s' % key].astype(np.float32)), key
+    smp = buf.sample(G['ppo_buffer/sample_indices'].astype(np.int64))
+    for key in buf.keys:
+        assert np.array_equal(smp[key].numpy(), G['ppo_buffer/sample/%s' % key].astype(np.float32)), key
+    for drop_last in (True, False):
+        batches = list(buf.sampler(4, drop_last=drop_last))
+        assert [b['obs'].shape[0] for b in batches] == g['sampler_batch_sizes'][str(drop_last)]
+        ref_ids = G['ppo_buffer/sampler_indices_drop_last_%s' % drop_last]
+        assert len(np.unique(ref_ids)) == len(ref_ids) == sum(g['sampler_batch_sizes'][str(drop_last)])   # each index once
+        rows = torch.cat([b['obs'] for b in batches]).numpy()
+        flat = got['obs'].numpy()
+        assert len({r.tobytes() for r in rows}) == len(rows) and all(any(np.array_equal(r, f) for f in flat) for r in rows)
+
+
 def test_randomisation_semantics_match_reference_function():
     """BenchmarkEnv._randomize_values_by_info (benchmark_env.py:277-308), executed with a RandomState: the package's parser
     (envs/randomization.py) binds every entry to (kind, parameters); those parameters, handed to the same RandomState methods in
