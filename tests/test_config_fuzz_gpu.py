@@ -125,8 +125,6 @@ def test_random_configuration_rollout_equals_step_loop(gpu, seed):
     system, kw, engine, _ = draw_config(rng)
     n = [1000, 1537, 4099][seed % 3]
     engine = dict(engine, rollout_queues=2, rollout_split_min=256)
-    if engine.get('randomized_inertial_prop'):
-        kw = dict(kw)
     mk = lambda: (scg.make('cartpole', num_envs=n, device='cuda', seed=5, randomized_init=True, **kw, **engine) if system == 'cartpole'
                   else scg.make('quadrotor', quad_type=system, num_envs=n, device='cuda', seed=5, randomized_init=True, **kw, **engine))
     a, b, c = mk(), mk(), mk()
