@@ -303,9 +303,26 @@ def cpu_baseline(args):
             ref.reset()
         k += 1
     py_rate = k / (time.perf_counter() - t1)
-    return {'value': steps * n / el, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
-            'sample': 'oracle/c float64 OpenMP port, %d envs x %d steps (%.1f s) of the same workload; '
-                      'python oracle 1 core: %.0f env-steps/s' % (n, steps, el, py_rate)}
+    # SURVEY 8(d) baseline (ii): the same step vectorised over the env axis in NumPy, one core (C4 only)
+    np_rate = None
+    if w in ('c4', 'c5'):
+        from oracle.ref_batched import BatchedC4
+        bat, nb = BatchedC4(ref), 1 << 16
+        sb, tb = x0[:nb].copy(), np.zeros(nb, dtype=np.int32)
+        bat.step(acts[0][:nb], sb, tb, x0[:nb])
+        kb, t2 = 0, time.perf_counter()
+        while time.perf_counter() - t2 < 2.0:
+            bat.step(acts[kb % 8][:nb], sb, tb, x0[:nb])
+            kb += 1
+        np_rate = kb * nb / (time.perf_counter() - t2)
+    out = {'value': steps * n / el, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
+           'sample': 'oracle/c float64 OpenMP port, %d envs x %d steps (%.1f s) of the same workload; '
+                     'python oracle 1 core: %.0f env-steps/s' % (n, steps, el, py_rate),
+           'python_oracle_1core': py_rate}
+    if np_rate is not None:
+        out['sample'] += '; numpy-batched oracle 1 core (2^16 envs): %.3g env-steps/s' % np_rate
+        out['numpy_batched_1core'] = np_rate
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -225,6 +225,46 @@ def test_reference_trajectory_quirks():
     assert np.allclose(env.X_GOAL[0, :6], [0, -0.62831853, 0.25, 0.25, 0.25, 0.25])
 
 
+def test_numpy_batched_step_matches_python_oracle_and_c_port():
+    """oracle/ref_batched.py (SURVEY 8d baseline (ii), the C4 step vectorised over envs) against the scalar oracle env by env,
+    and against the C port over 150 steps with auto-resets (teacher-forced so that tumbling lanes cannot diverge)."""
+    from oracle.c_port import CPort
+    from oracle.ref_batched import BatchedC4
+    from oracle.ref_env import INIT_STATE_LABELS
+    rng = np.random.default_rng(21)
+    ref = RefEnv(system=3, task='traj_tracking', cost='quadratic', ctrl_freq=60, pyb_freq=240, randomized_init=False,
+                 reset_sampler=zeros_sampler)
+    bat, port = BatchedC4(ref), CPort.from_ref_env(ref)
+    lo = np.array([ref.INIT_STATE_RAND_INFO[k]['low'] for k in INIT_STATE_LABELS[3]])
+    hi = np.array([ref.INIT_STATE_RAND_INFO[k]['high'] for k in INIT_STATE_LABELS[3]])
+    n = 48
+    x0 = rng.uniform(lo, hi, size=(n, 12))
+    state, t = x0.copy(), rng.integers(0, 299, size=n).astype(np.int32)
+    s0, t0 = state.copy(), t.copy()
+    alo, ahi = ref.action_space_low, ref.action_space_high
+    a = rng.uniform(alo - 0.1 * (ahi - alo), ahi + 0.1 * (ahi - alo), size=(n, 4))
+    rew, done = bat.step(a, state, t, x0)
+    for i in range(n):
+        ref.reset()
+        ref.state, ref.ctrl_step_counter = s0[i].copy(), int(t0[i])
+        o, r, d, info = ref.step(a[i])
+        assert bool(done[i]) == bool(d) and abs(r - rew[i]) <= 1e-12 * max(1, abs(r))
+        assert np.max(np.abs(state[i] - (x0[i] if d else ref.state))) < 1e-12
+    n = 512
+    x0 = rng.uniform(lo, hi, size=(n, 12))
+    sa, ta, sb, tb = x0.copy(), np.zeros(n, dtype=np.int32), x0.copy(), np.zeros(n, dtype=np.int32)
+    dones = 0
+    for k in range(150):
+        a = rng.uniform(alo, ahi, size=(n, 4))
+        ra, da, _, _ = port.step(a, sa, ta, x0, num_threads=2)
+        rb, db = bat.step(a, sb, tb, x0)
+        assert np.array_equal(da.astype(bool), db) and np.array_equal(ta, tb)
+        assert np.abs(sa - sb).max() < 1e-11 and np.max(np.abs(ra - rb) / np.maximum(np.abs(ra), 1)) < 1e-11
+        sb[...] = sa
+        dones += int(db.sum())
+    assert dones > n
+
+
 def test_c_port_matches_python_oracle():
     from oracle.c_port import CPort
     rng = np.random.default_rng(11)
