@@ -309,12 +309,14 @@ def cpu_baseline(args):
         from oracle.ref_batched import BatchedC4
         bat, nb = BatchedC4(ref), 1 << 16
         sb, tb = x0[:nb].copy(), np.zeros(nb, dtype=np.int32)
-        bat.step(acts[0][:nb], sb, tb, x0[:nb])
-        kb, t2 = 0, time.perf_counter()
-        while time.perf_counter() - t2 < 2.0:
-            bat.step(acts[kb % 8][:nb], sb, tb, x0[:nb])
-            kb += 1
-        np_rate = kb * nb / (time.perf_counter() - t2)
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1):                                  # one core, BLAS included
+            bat.step(acts[0][:nb], sb, tb, x0[:nb])
+            kb, t2 = 0, time.perf_counter()
+            while time.perf_counter() - t2 < 2.0:
+                bat.step(acts[kb % 8][:nb], sb, tb, x0[:nb])
+                kb += 1
+            np_rate = kb * nb / (time.perf_counter() - t2)
     out = {'value': steps * n / el, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
            'sample': 'oracle/c float64 OpenMP port, %d envs x %d steps (%.1f s) of the same workload; '
                      'python oracle 1 core: %.0f env-steps/s' % (n, steps, el, py_rate),
