@@ -431,6 +431,41 @@ def test_fresh_outputs_ping_pong_state(gpu, kw):
     env.close(); twin.close()
 
 
+def test_non_finite_actions(gpu):
+    """Edge case "nulls": +-inf action components clip to the thrust bounds exactly as np.clip does in the reference
+    (quadrotor.py:830).  A NaN component is where the engine deviates on purpose: np.clip would hand the NaN on (state and
+    reward NaN until the time limit ends the episode, since NaN compares false against every bound); the kernel's clamp is one
+    v_med3_f32, which returns the LOWER bound for a NaN operand, so the env stays finite.  Pinned here: NaN == lower bound."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    from helpers import make_pair, sync_reset, sync_step, force_state, rel_err
+    n = 64
+    env, ref, sampler = make_pair(3, n, randomized_init=True, task='traj_tracking', cost='quadratic', ctrl_freq=60, pyb_freq=240)
+    sync_reset(env, ref, sampler)
+    lo, hi = env.action_space.low.astype(np.float32), env.action_space.high.astype(np.float32)
+    rng = np.random.default_rng(2)
+    a = rng.uniform(lo, hi, size=(n, 4)).astype(np.float32)
+    a[0, 1], a[1, 0], a[2, 3], a[3, :] = np.inf, -np.inf, np.nan, np.nan
+    a_ref = a.copy()
+    a_ref[2, 3], a_ref[3, :] = lo[3], lo                      # what the kernel reads a NaN as
+    force_state(env, ref)
+    sampler.serial = env._serial
+    obs, rew, done, info = env.step(a)
+    obs_r, rew_r, done_r, _ = ref.step(a_ref.astype(np.float64))
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    assert np.array_equal(done.cpu().numpy(), done_r.astype(bool))
+    assert rel_err(obs.cpu().numpy(), obs_r) <= 1e-5 and rel_err(rew.cpu().numpy(), rew_r) <= 1e-5
+    # a non-finite STATE (set from outside) counts as out of bounds: the env ends its episode and restarts finite, where the
+    # reference would carry the NaN to the time limit (DESIGN.md section 2, "ill-conditioned lanes")
+    env.state[5, 0] = float('nan')
+    env.state[6, 7] = float('inf')
+    a2 = rng.uniform(lo, hi, size=(n, 4)).astype(np.float32)
+    obs, rew, done, info = env.step(a2)
+    assert bool(done[5]) and bool(done[6]) and torch.isfinite(obs).all()
+    assert int(env.ctrl_step_counter[5]) == 0 and int(env.ctrl_step_counter[6]) == 0
+    env.close()
+
+
 def test_rollout_is_capturable_in_a_hip_graph(gpu):
     """env.rollout() with one launch queue only enqueues kernels on the current stream, so it can be captured in a HIP graph
     (torch.cuda.graph) and replayed: the replay leaves the same buffers as the plain call.  The reset serials are kernel
