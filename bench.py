@@ -300,7 +300,7 @@ def cpu_baseline(args):
         port.step(acts[steps % 8], state, t, x0, num_threads=threads)
         steps += 1
         el = time.perf_counter() - t0
-        if el > args.cpu_seconds or steps >= 400:
+        if el > args.cpu_seconds or steps >= 4000:
             break
     # one-core Python oracle (the structure-equivalent stand-in for the reference's own step()): tiny sample
     ref.reset_sampler = lambda i, e: np.zeros(ref.nx)
