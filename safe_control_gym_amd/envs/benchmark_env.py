@@ -828,9 +828,11 @@ class BenchmarkEnv:
         ``make()``) ``obs``, ``rew`` and ``done`` are fresh tensors, as the reference's are: the usual RL loop keeps the
         previous ``obs`` until after the next ``step()`` (controllers/ppo/ppo.py:259-276).  With ``copy_outputs=False``
         (default of ``info_level='minimal'``) they are zero-copy VIEWS of the engine's planes -- valid until the next
-        ``step()`` / ``rollout()`` / ``reset()``, ``.clone()`` what must outlive it.  Fresh outputs are written by the kernel
-        itself into newly allocated tensors (+4 obs_dim bytes of stores per env-step, no copy kernel).  The tensors inside
-        ``info`` are always views of per-step buffers."""
+        ``step()`` / ``rollout()`` / ``reset()``, ``.clone()`` what must outlive it.  Fresh outputs cost no copy: the state
+        ping-pongs -- the kernel writes the new state (``scg_step_io.state_out``), reward and done straight into newly allocated
+        tensors, the state buffer IS the observation handed out and the next step's input, and nothing writes it again
+        (``_own_state``; writing ``env.state[...]`` yourself writes into the last observation).  Only an observation
+        disturbance needs an obs buffer of its own.  The tensors inside ``info`` are always views of per-step buffers."""
         self._check_initial_reset()
         act, rows = self._load_action(action)
         self._raw_action, self._raw_action_rows = act, rows
