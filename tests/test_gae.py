@@ -147,3 +147,40 @@ def test_ppo_rollout_pipeline_matches_the_oracle_pipeline(gpu):
     assert np.abs(adv.cpu().numpy() - want_adv).max() <= 5e-5 * scale
     assert np.abs(on_e.rms.mean.cpu().numpy() - on_r.rms.mean).max() <= 1e-6
     assert float(rn_e.rms.var) == pytest.approx(float(rn_r.rms.var), rel=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('use_gae', [True, False])
+def test_gae_full_size_properties(gpu, use_gae):
+    """T = 64 x 2^20 envs (the size of BASELINE config C4), size-independent properties of ppo_utils.py:428-456:
+    (i) homogeneity -- scaling rewards, values, terminal values and the bootstrap value by 2 scales returns and advantages by 2 BIT
+    for bit (a power of two commutes with every rounding); (ii) additivity to rounding; (iii) an all-zero mask cuts every
+    step off from its future: ret = rew + gamma * terminal_v, adv = ret - v; (iv) a sampled comparison with the oracle."""
+    import torch
+    from oracle import ref_ppo
+    from safe_control_gym_amd.controllers.ppo.ppo_utils import compute_returns_and_advantages as dev_gae
+    T, N = 64, 1 << 20
+    g = torch.Generator(device='cuda'); g.manual_seed(6)
+    mk = lambda: torch.randn((T, N, 1), generator=g, device='cuda')
+    r1, v1, tv1, r2, v2 = mk(), mk(), mk() * 0.1, mk(), mk()
+    masks = (torch.rand((T, N, 1), generator=g, device='cuda') > 0.05).float()
+    lv1, lv2 = torch.randn(N, generator=g, device='cuda'), torch.randn(N, generator=g, device='cuda')
+    kw = dict(gamma=0.99, use_gae=use_gae, gae_lambda=0.95)
+    ret1, adv1 = dev_gae(r1.clone(), v1, masks, tv1, lv1, **kw)
+    ret2, adv2 = dev_gae(r2.clone(), v2, masks, 0, lv2, **kw)
+    retd, advd = dev_gae(2 * r1, 2 * v1, masks, 2 * tv1, 2 * lv1, **kw)
+    assert torch.equal(retd, 2 * ret1) and torch.equal(advd, 2 * adv1)
+    rets, advs = dev_gae(r1 + r2, v1 + v2, masks, tv1, lv1 + lv2, **kw)
+    scale = ret1.abs() + ret2.abs() + 1.0
+    assert float(((rets - (ret1 + ret2)).abs() / scale).max()) < 2e-5
+    assert float(((advs - (adv1 + adv2)).abs() / (scale + adv1.abs() + adv2.abs())).max()) < 2e-5
+    zero = torch.zeros_like(masks)
+    ret0, adv0 = dev_gae(r1.clone(), v1, zero, tv1, lv1, **kw)
+    want = r1 + 0.99 * tv1
+    assert float((ret0 - want).abs().max()) < 4e-6 and float((adv0 - (want - v1)).abs().max()) < 4e-6
+    idx = np.random.default_rng(0).choice(N, 64, replace=False)
+    ti = torch.as_tensor(idx, device='cuda')
+    f64 = lambda t: t[:, ti].double().cpu().numpy()
+    rr, aa = ref_ppo.compute_returns_and_advantages(f64(r1).copy(), f64(v1), f64(masks), f64(tv1), lv1[ti].double().cpu().numpy().reshape(-1, 1), **kw)[:2]
+    assert np.abs(f64(ret1) - rr).max() / max(1.0, np.abs(rr).max()) < 1e-5
+    assert np.abs(f64(adv1) - aa).max() / max(1.0, np.abs(aa).max()) < 1e-5

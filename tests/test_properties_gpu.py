@@ -36,6 +36,35 @@ def test_hover_is_a_fixed_point_and_time_limit_truncates_at_300(gpu):
     assert int(env.ctrl_step_counter.max()) == 0                   # auto-reset
 
 
+def test_full_size_invariances_of_the_dynamics(gpu):
+    """2^20 envs, size-independent properties of the model (quadrotor.py:624-674): positions never feed back into the
+    dynamics, and the system is autonomous.  (i) Shifting every env's (x, y, z) leaves velocities, attitude and rates BIT-identical
+    over 60 steps and the positions shifted by the same amount; (ii) starting the step counter at 100 instead of 0 leaves the
+    whole state bit-identical (stabilisation: the counter only feeds the time limit)."""
+    kw = dict(quad_type=3, num_envs=N, device='cuda', seed=21, randomized_init=True, task='stabilization', cost='rl_reward',
+              task_info={'stabilization_goal': [0, 0, 1], 'stabilization_goal_tolerance': 0.05}, done_on_out_of_bound=False,
+              episode_len_sec=10, info_level='minimal')
+    a_env, b_env, c_env = scg.make('quadrotor', **kw), scg.make('quadrotor', **kw), scg.make('quadrotor', **kw)
+    a_env.reset(), b_env.reset(), c_env.reset()
+    shift = torch.tensor([0.5, -0.25, 0.125], device='cuda')
+    b_env.state[:, [0, 2, 4]] += shift
+    c_env.ctrl_step_counter.fill_(100)
+    g = torch.Generator(device='cuda'); g.manual_seed(4)
+    lo, hi = float(a_env.action_space.low[0]), float(a_env.action_space.high[0])
+    mid, half = 0.5 * (lo + hi), 0.5 * (hi - lo)
+    acts = torch.rand((6, 4, a_env.plane_stride), generator=g, device='cuda') * (0.2 * half) + (mid - 0.1 * half)   # near hover
+    for env in (a_env, b_env, c_env):
+        env.rollout(acts, steps=60)
+    torch.cuda.synchronize()
+    rest = [1, 3, 5, 6, 7, 8, 9, 10, 11]
+    assert torch.isfinite(a_env.state).all()
+    assert torch.equal(a_env.state[:, rest], b_env.state[:, rest])
+    assert float(((b_env.state[:, [0, 2, 4]] - a_env.state[:, [0, 2, 4]]) - shift).abs().max()) < 2e-5
+    assert torch.equal(a_env.state, c_env.state) and int(c_env.ctrl_step_counter.min()) == 160
+    for env in (a_env, b_env, c_env):
+        env.close()
+
+
 def test_determinism_and_shard_invariance(gpu):
     """Same seed -> bit-identical rollouts; a shard built with env_index_base reproduces the matching slice of
     the big batch bit for bit (per-env Philox streams are keyed by the GLOBAL env index)."""
