@@ -497,7 +497,9 @@ class BenchmarkEnv:
     # ------------------------------------------------------------------ views
     @property
     def state(self):
-        """[N, nx] view of the SoA state planes (zero copy)."""
+        """[N, nx] view of the SoA state planes (zero copy); None before the first reset(), as in the reference."""
+        if self._bufs is None:
+            return None
         return self._bufs['state'][:, :self.num_envs].T
 
     @property
@@ -511,11 +513,46 @@ class BenchmarkEnv:
 
     @property
     def ctrl_step_counter(self):
+        """[N] int32 view of the per-env step counter (benchmark_env.py:366,428); 0 before the first reset()."""
+        if self._bufs is None:
+            return 0
         return self._bufs['step_count'][:self.num_envs]
 
     @property
     def pyb_step_counter(self):
         return self.ctrl_step_counter * self.PYB_STEPS_PER_CTRL
+
+    @property
+    def current_preprocessed_action(self):
+        """[N, nu] the action after ``_preprocess_control`` (quadrotor.py:815-833: clipped, or mapped from the normalised space),
+        recomputed from the raw action on demand (the kernel does not store it); None before the first step()."""
+        raw = self.current_raw_input_action
+        if raw is None:
+            return None
+        lo = torch.as_tensor(self.action_space.low, device=raw.device)
+        hi = torch.as_tensor(self.action_space.high, device=raw.device)
+        a = torch.nan_to_num(raw, nan=0.0).clamp(lo, hi)
+        a = torch.where(torch.isnan(raw), lo.expand_as(raw), a)             # the kernel reads a NaN as the lower bound
+        if getattr(self, 'NORMALIZED_RL_ACTION_SPACE', False):
+            if self.NAME == 'cartpole':
+                return a * float(getattr(self, 'action_scale', 1.0))
+            return (1.0 + float(self.norm_act_scale) * a) * float(self.hover_thrust)
+        return a
+
+    @property
+    def cnstr_violation(self):
+        """benchmark_env.py:218,441-449: whether the last step violated a constraint -- [N] bool per env (False without
+        constraints or before the first step)."""
+        if self._bufs is None or 'constraint_violation' not in self._bufs:
+            return False
+        return self._bufs['constraint_violation'][:self.num_envs].bool()
+
+    @property
+    def goal_reached(self):
+        """quadrotor.py:965: [N] bool of the last step (stabilisation with the quadratic cost, info_level='full'); else False."""
+        if self._bufs is None or 'goal_reached' not in self._bufs:
+            return False
+        return self._bufs['goal_reached'][:self.num_envs]
 
     @property
     def inertial_properties(self):

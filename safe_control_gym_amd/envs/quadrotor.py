@@ -248,6 +248,21 @@ class Quadrotor(BenchmarkEnv):
         info['quadrotor_km'] = self.KM
         return info
 
+    @property
+    def OVERRIDDEN_QUAD_MASS(self):
+        """quadrotor.py:466: the mass in force since the last reset -- per env ([N] device tensor) when the inertial properties
+        are randomised, the nominal value otherwise."""
+        if self.RANDOMIZED_INERTIAL_PROP and self._engine is not None and 'inertial' in self._bufs:
+            return self.inertial_properties[:, 0]
+        return self.MASS
+
+    @property
+    def OVERRIDDEN_QUAD_INERTIA(self):
+        """quadrotor.py:467: (Ixx, Iyy, Izz) -- [N, 3] per env when randomised, the nominal list otherwise."""
+        if self.RANDOMIZED_INERTIAL_PROP and self._engine is not None and 'inertial' in self._bufs:
+            return self.inertial_properties[:, 1:4]
+        return [self.J[0, 0], self.J[1, 1], self.J[2, 2]]
+
     def _inertial_nominal(self):
         return [self.MASS, self.J[0, 0], self.J[1, 1], self.J[2, 2]]
 

@@ -460,6 +460,42 @@ def test_fresh_outputs_ping_pong_state(gpu, kw):
     env.close(); twin.close()
 
 
+def test_reference_attribute_surface_after_a_step(gpu):
+    """Attributes callers of the reference read off the env (SURVEY 8b-5 and the assignments of benchmark_env.py /
+    quadrotor.py): current_preprocessed_action (:833), cnstr_violation (:441-449), goal_reached (:965), the counters, the
+    per-env OVERRIDDEN_QUAD_MASS / _INERTIA (:466-467) -- batched, against the oracle's scalars."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    from helpers import make_pair, sync_reset, sync_step, force_state
+    n = 40
+    cons = [{'constraint_form': 'bounded_constraint', 'constrained_variable': 'state', 'active_dims': [0, 2],
+             'lower_bounds': [-0.2, 0.8], 'upper_bounds': [0.2, 1.2]}]
+    env, ref, sampler = make_pair(2, n, randomized_init=True, task='stabilization', cost='quadratic', ctrl_freq=60, pyb_freq=240,
+                                  normalized_rl_action_space=True, constraints=cons,
+                                  engine_kwargs=dict(randomized_inertial_prop=False))
+    assert env.state is None and env.ctrl_step_counter == 0 and env.current_preprocessed_action is None
+    sync_reset(env, ref, sampler)
+    rng = np.random.default_rng(8)
+    a = rng.uniform(-1.4, 1.4, size=(n, 2)).astype(np.float32)
+    force_state(env, ref)
+    sync_step(env, ref, sampler, a)
+    want = np.stack([np.asarray(r.current_preprocessed_action) for r in ref.envs])
+    assert np.abs(env.current_preprocessed_action.cpu().numpy() - want).max() <= 1e-6
+    viol = np.array([bool(r.cnstr_violation) if hasattr(r, 'cnstr_violation') else False for r in ref.envs])
+    got_v = env.cnstr_violation.cpu().numpy()
+    assert got_v.dtype == bool and got_v.shape == (n,) and got_v.any() and not got_v.all()
+    if any(hasattr(r, 'cnstr_violation') for r in ref.envs):
+        assert np.array_equal(got_v, viol)
+    assert env.goal_reached.shape == (n,) and int(env.ctrl_step_counter.max()) == 1
+    assert env.OVERRIDDEN_QUAD_MASS == env.MASS and len(env.OVERRIDDEN_QUAD_INERTIA) == 3
+    env.close()
+    env = scg.make('quadrotor', quad_type=3, num_envs=n, device='cuda', seed=1, task='traj_tracking', randomized_inertial_prop=True)
+    env.reset()
+    assert env.OVERRIDDEN_QUAD_MASS.shape == (n,) and env.OVERRIDDEN_QUAD_INERTIA.shape == (n, 3)
+    assert float(env.OVERRIDDEN_QUAD_MASS.std()) > 0
+    env.close()
+
+
 def test_non_finite_actions(gpu):
     """Edge case "nulls": +-inf action components clip to the thrust bounds exactly as np.clip does in the reference
     (quadrotor.py:830).  A NaN component is where the engine deviates on purpose: np.clip would hand the NaN on (state and
