@@ -69,6 +69,17 @@ class PPOBuffer:
             yield batch if device is None else {k: v.to(device) for k, v in batch.items()}
 
 
+def random_sample(indices, batch_size, drop_last=True):
+    """ppo_utils.py:410-426: a random permutation of ``indices`` cut into batches (the remainder kept unless ``drop_last``)."""
+    indices = torch.as_tensor(indices)
+    perm = indices[torch.randperm(indices.shape[0], device=indices.device)]
+    full = perm.shape[0] // batch_size * batch_size
+    for batch in perm[:full].reshape(-1, batch_size):
+        yield batch
+    if not drop_last and perm.shape[0] % batch_size:
+        yield perm[full:]
+
+
 def _plane(x, T, N, name):
     """(T, N, 1) / (T, N) float32 contiguous device tensor -> itself viewed as T planes of N."""
     if not (isinstance(x, torch.Tensor) and x.is_cuda):

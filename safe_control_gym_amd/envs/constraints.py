@@ -67,6 +67,15 @@ class Constraint:
         self._env = env
         self._own_list = None
 
+    def get_env_constraint_var(self, env):
+        """The env variable(s) subject to the constraint (constraints.py:160-172), batched: ``env.state`` [N, nx], the raw
+        action [N, nu], or the pair."""
+        if self.constrained_variable == ConstrainedVariableType.STATE:
+            return env.state
+        if self.constrained_variable == ConstrainedVariableType.INPUT:
+            return env.current_raw_input_action
+        return (env.state, env.current_raw_input_action)
+
     def reset(self):
         pass
 

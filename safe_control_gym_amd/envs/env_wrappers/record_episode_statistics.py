@@ -63,3 +63,8 @@ class VecRecordEpisodeStatistics(VecEnvWrapper):
                         self.queued_stats[key].extend(vals.tolist())
                     acc[idx] = 0
         return obs, reward, done, info
+
+
+# The reference also has the single-env wrapper of this name (record_episode_statistics.py:11-89); a batched env is served by
+# the one class above whatever its size.
+RecordEpisodeStatistics = VecRecordEpisodeStatistics

@@ -31,6 +31,16 @@ class VecEnv:
         self.step_async(actions)
         return self.step_wait()
 
+    def render(self, mode='human'):
+        """vec_env.py:96-112 tiles the envs' camera images; the batched engine has no renderer (as ``env.render``)."""
+        raise NotImplementedError('[ERROR] the batched engine does not render.')
+
+    def get_images(self):
+        raise NotImplementedError('[ERROR] the batched engine does not render.')
+
+    def get_viewer(self):
+        raise NotImplementedError('[ERROR] the batched engine does not render.')
+
     def close_extras(self):
         """Hook for sub-classes; runs once from close()."""
 

@@ -61,6 +61,34 @@ class RunningMeanStd:
         self._cur = 1 - self._cur
         return cur, nxt
 
+    def update(self, arr):
+        """normalization.py:34-46 on a device batch [N, *shape]: the moments kernel of the normalisers, without their output."""
+        x = torch.as_tensor(arr, device=self.device, dtype=torch.float32).reshape(-1, self.d)
+        n = x.shape[0]
+        if n == 0:
+            return
+        planes = x.T.contiguous()                                         # [d, n] SoA planes
+        scratch = torch.empty_like(planes)
+        state_in, state_out = self._records(True)
+        lib = _capi.load()
+        with torch.cuda.device(self.device):
+            _capi.check(lib.scg_mean_std_normalize(planes.data_ptr(), scratch.data_ptr(), self.d, n, n, n, state_in.data_ptr(),
+                                                   state_out.data_ptr(), self._moments.data_ptr(), 0.0, 0.0,
+                                                   _capi.current_stream(self.device)), 'scg_mean_std_normalize')
+
+    def update_from_moments(self, batch_mean, batch_var, batch_count):
+        """normalization.py:48-62 (Chan's parallel update), float64 on the device record."""
+        as64 = lambda v: torch.as_tensor(np.asarray(v.detach().cpu() if isinstance(v, torch.Tensor) else v, dtype=np.float64).reshape(-1),
+                                         device=self.device)
+        bm, bv, bc = as64(batch_mean), as64(batch_var), float(batch_count)
+        cur, nxt = self._records(True)
+        mean, var, count = cur[:self.d], cur[self.d:2 * self.d], cur[2 * self.d]
+        delta = bm - mean
+        tot = count + bc
+        nxt[:self.d] = mean + delta * bc / tot
+        nxt[self.d:2 * self.d] = (var * count + bv * bc + delta * delta * count * bc / tot) / tot
+        nxt[2 * self.d] = tot
+
     def set(self, mean=None, var=None, count=None):
         rec = self._state[self._cur]
         if mean is not None:

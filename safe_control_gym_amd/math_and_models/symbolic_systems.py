@@ -202,3 +202,7 @@ class AnalyticModel:
                 'l_xx': np.broadcast_to(Qs, lead + Qs.shape).copy(),
                 'l_uu': np.broadcast_to(Rs, lead + Rs.shape).copy(),
                 'l_xu': np.zeros(lead + (self.nx, self.nu))}
+
+
+# the reference's class name (symbolic_systems.py:8): env.symbolic is an instance of it
+SymbolicModel = AnalyticModel

@@ -84,7 +84,39 @@ def spec(id):
 
 
 def make(id, *args, **kwargs):
-    return _SPECS[id].make(*args, **kwargs)
+    return spec(id).make(*args, **kwargs)
+
+
+def load(name):
+    """``'module:attr'`` -> the attribute (registration.py:12-22)."""
+    module, attr = name.split(':')
+    return getattr(importlib.import_module(module), attr)
+
+
+class Registry:
+    """The reference's registry object (registration.py:89-135) as a view of this module's table."""
+
+    @property
+    def specs(self):
+        return _SPECS
+
+    def make(self, id, *args, **kwargs):
+        return make(id, *args, **kwargs)
+
+    def all(self):
+        return all_specs()
+
+    def spec(self, id):
+        return spec(id)
+
+    def register(self, id, **kwargs):
+        return register(id, **kwargs)
+
+    def get_config(self, id):
+        return get_config(id)
+
+
+registry = Registry()
 
 
 def get_config(id):

@@ -153,3 +153,25 @@ def test_normalizer_c_abi_validation(gpu):
     assert lib.scg_mean_std_normalize(p(x), p(x), 4, 64, 64, 0, p(st[0]), p(st[1]), p(mom), 10.0, 1e-8, None) == 0    # empty batch
     assert lib.scg_reward_normalize(p(x), None, None, p(x), 10, p(st[0]), p(st[1]), p(mom), 0.99, 10.0, 1e-8, 0, None) < 0
     assert lib.scg_reward_normalize(p(x), None, None, p(x), 10, p(st[0]), None, None, 0.99, 10.0, 1e-8, 0, None) == 0   # read-only
+
+
+@pytest.mark.gpu
+def test_running_mean_std_update_methods_match_oracle(gpu):
+    """RunningMeanStd.update / update_from_moments (normalization.py:34-62) as stand-alone calls on the device record."""
+    import torch
+    from safe_control_gym_amd.math_and_models.normalization import RunningMeanStd
+    rng = np.random.default_rng(12)
+    dev, ref = RunningMeanStd(shape=(5,)), rn.RunningMeanStd(shape=(5,))
+    for n in (1, 63, 1000):
+        x = rng.normal(size=(n, 5)) * [1, 2, 0.5, 10, 0.01] + [0, 1, -1, 5, 0]
+        dev.update(torch.as_tensor(x, dtype=torch.float32, device='cuda'))
+        ref.update(x.astype(np.float32).astype(np.float64))
+        assert np.abs(dev.mean.cpu().numpy() - ref.mean).max() <= 1e-6 * max(1.0, np.abs(ref.mean).max())
+        assert np.abs(dev.var.cpu().numpy() - ref.var).max() <= 1e-5 * max(1.0, np.abs(ref.var).max())
+        assert abs(float(dev.count) - ref.count) <= 1e-9
+    bm, bv = rng.normal(size=5), rng.uniform(0.5, 2.0, size=5)
+    dev.update_from_moments(bm, bv, 17)
+    ref.update_from_moments(bm, bv, 17)
+    assert np.abs(dev.mean.cpu().numpy() - ref.mean).max() <= 1e-6 * max(1.0, np.abs(ref.mean).max())
+    assert np.abs(dev.var.cpu().numpy() - ref.var).max() <= 1e-5 * max(1.0, np.abs(ref.var).max())
+    assert abs(float(dev.count) - ref.count) <= 1e-9
