@@ -476,6 +476,55 @@ def test_randomized_inertial_properties_parity(gpu):
     print('randomised inertial properties: worst rel err %.3e' % worst)
 
 
+@pytest.mark.parametrize('traj', ['figure8', 'circle', 'square'])
+def test_reference_tracking_config_runs_and_a_pd_loop_tracks(gpu, traj):
+    """The reference's tracking demo (tests/scripts/tracking.py:18-80 with the quadrotor_config of tests/scripts/tracking.yaml:1-31:
+    2-D quadrotor, quadratic cost, three trajectory types, a feedback controller in the loop).  The reference asserts nothing; here
+    the same config is stepped by a batched PD law (a stand-in for its PID controller, which is out of scope) against the oracle in
+    closed loop for 180 steps: the engine follows the oracle, and the vehicle follows the reference trajectory."""
+    import torch
+    cfg = dict(seed=1337, ctrl_freq=60, pyb_freq=240, physics='pyb', quad_type=2,
+               init_state={'init_x': 0, 'init_x_dot': 0, 'init_z': 1, 'init_z_dot': 0, 'init_theta': 0, 'init_theta_dot': 0},
+               randomized_init=False, task='traj_tracking',
+               task_info={'stabilization_goal': [0, 1], 'stabilization_goal_tolerance': 0.01, 'trajectory_type': traj, 'num_cycles': 1,
+                          'trajectory_plane': 'xz', 'trajectory_position_offset': [0, 1], 'trajectory_scale': 1},
+               episode_len_sec=6, cost='quadratic', done_on_out_of_bound=False)
+    n = 8
+    seed = cfg.pop('seed'); cfg.pop('quad_type')
+    env, ref, sampler = make_pair(2, n, seed=seed, engine_kwargs=dict(info_in_reset=True, randomized_inertial_prop=False), **cfg)
+    sampler.serial = env._serial
+    obs, info = env.reset()
+    obs_r, _ = ref.reset()
+    assert obs.shape == (n, 6) and set(info) >= {'x_reference', 'u_reference', 'symbolic_model', 'ctrl_timestep', 'ctrl_freq'}
+    assert info['x_reference'].shape == (360, 6) and rel_err(obs.cpu().numpy(), obs_r) <= RTOL
+    xg = np.asarray(env.X_GOAL, dtype=np.float64)
+    m, g, iyy, l = env.MASS, env.GRAVITY_ACC, env.J[1, 1], env.L
+    worst, track, dt = 0.0, 0.0, 1 / 60
+
+    def control(x, k):
+        k0 = min(k, xg.shape[0] - 2)
+        r, nxt = xg[k0], xg[k0 + 1]
+        ax = np.clip((nxt[1] - r[1]) / dt + 20.0 * (r[0] - x[:, 0]) + 8.0 * (r[1] - x[:, 1]), -5, 5)
+        az = np.clip((nxt[3] - r[3]) / dt + 20.0 * (r[2] - x[:, 2]) + 8.0 * (r[3] - x[:, 3]), -4, 6)
+        theta_des = np.clip(np.arctan2(ax, g + az), -0.5, 0.5)
+        thrust = m * (g + az) / np.cos(x[:, 4])
+        d = iyy * (200.0 * (theta_des - x[:, 4]) - 25.0 * x[:, 5]) / (l / np.sqrt(2.0))      # T2 - T1 (quadrotor.py:621)
+        return np.stack([0.5 * (thrust - d), 0.5 * (thrust + d)], axis=1).astype(np.float32)
+
+    obs_e = obs.double().cpu().numpy()
+    for k in range(180):                                                    # each side closes its own loop on its own state
+        out_e = env.step(control(obs_e, k))
+        out_r = ref.step(control(obs_r, k).astype(np.float64))
+        obs_e, obs_r = out_e[0].double().cpu().numpy(), out_r[0]
+        worst = max(worst, rel_err(obs_e, obs_r), rel_err(out_e[1].cpu().numpy(), out_r[1]))
+        assert set(out_e[3]) >= {'mse'} and out_e[0].shape == (n, 6) and out_e[1].shape == (n,) and out_e[2].shape == (n,)
+        if k >= 90:
+            track = max(track, float(np.abs(obs_r[:, [0, 2]] - xg[min(k + 1, 359)][[0, 2]]).max()))
+    print('tracking demo (%s): closed-loop worst rel err %.2e, tracking error after 1.5 s %.3f m' % (traj, worst, track))
+    assert worst <= 2e-5 and track < 0.2
+    env.close()
+
+
 def test_reference_verbose_api_config_runs(gpu):
     """The reference's own API demo (tests/scripts/verbose_api.py:16-113 with the quadrotor_config of
     tests/scripts/verbose_api.yaml:96-186): same keys in, same keys out.  It asserts nothing numerically in the
