@@ -202,21 +202,22 @@ def make_actions(env, rank, period, dev):
 class Timer:
     """Timed regions of exactly `steps` steps: barrier + synchronize on both sides, HIP events inside."""
 
-    def __init__(self, world, dev):
+    def __init__(self, world, dev, collectives=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.world, self.dev = torch, dist, world, dev
-        self.on_host = world > 1 and dist.get_backend() != 'nccl'
+        self.collectives = world > 1 if collectives is None else collectives       # a forced one-rank world runs them too
+        self.on_host = self.collectives and dist.get_backend() != 'nccl'
 
     def fence(self):
         self.torch.cuda.synchronize()
-        if self.world > 1:
+        if self.collectives:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
     def max_over_ranks(self, values):
         t = self.torch.tensor(values, dtype=self.torch.float64, device='cpu' if self.on_host else self.dev)
-        if self.world > 1:
+        if self.collectives:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return [float(v) for v in t]
 
@@ -389,7 +390,14 @@ def run_rank(args):
         raise SystemExit('--no-episode-stats is a single-GPU option (the sharded run gathers the episode returns)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    timer = Timer(world, dev)
+    # SCG_BENCH_FORCE_COLLECTIVES=1: a ONE-rank RCCL world that runs every collective of the N > 1 path (barrier, max-reduce,
+    # the asynchronous all-gather inside the timed region, the per-rank gather) -- the rehearsal a one-GPU box allows, since
+    # RCCL refuses two ranks on one device
+    forced = world == 1 and os.environ.get('SCG_BENCH_FORCE_COLLECTIVES') == '1'
+    if forced and not dist.is_initialized():
+        dist.init_process_group(backend='nccl', init_method='tcp://127.0.0.1:%d' % _free_port(), rank=0, world_size=1)
+    multi = world > 1 or forced
+    timer = Timer(world, dev, collectives=multi)
 
     n = args.envs_per_gpu
     track = not args.no_episode_stats
@@ -401,10 +409,11 @@ def run_rank(args):
     def run(steps):
         done_steps = 0
         while done_steps < steps:
-            chunk = min(GATHER_EVERY, steps - done_steps) if world > 1 else steps - done_steps
+            chunk = min(GATHER_EVERY, steps - done_steps) if multi else steps - done_steps
             # the exchange of the path: the returns as of this chunk's start travel over xGMI on RCCL's stream
             # while the chunk's step kernels run; the region ends only after the gather has landed (wait + the closing fence)
-            pending = parallel.begin_all_gather_episode_returns(env.episode_return, total_envs=n * world) if world > 1 else None
+            pending = parallel.begin_all_gather_episode_returns(env.episode_return, total_envs=n * world,
+                                                                force_collective=forced) if multi else None
             env.rollout(actions, steps=chunk)
             done_steps += chunk
             if pending is not None:
@@ -412,7 +421,7 @@ def run_rank(args):
 
     # every rank proves itself to the collective backend: a sum of ones on the device the rank computes on
     ranks_seen, backend = 1, 'none'
-    if world > 1:
+    if multi:
         backend = dist.get_backend()
         ones = torch.ones(1, device='cpu' if timer.on_host else dev)
         dist.all_reduce(ones)
@@ -422,7 +431,7 @@ def run_rank(args):
     ms_per_step = m['ms'] / args.steps
     value = n * world * args.steps / (m['ms'] * 1e-3)
     local_ms = None
-    if world > 1:
+    if multi:
         # spread of the per-rank step time: one more region, every rank's OWN event time gathered
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         timer.fence()
@@ -476,7 +485,8 @@ def run_rank(args):
             'clock': 'HIP events around exactly %d steps, max over ranks; median of %d regions' % (args.steps, m['regions']),
             'ms_per_step_min_max': [m['ms_min'] / args.steps, m['ms_max'] / args.steps],
             'wall_ms_per_step': m['wall_ms'] / args.steps,
-            'backend': backend if world > 1 else 'none (single process)', 'ranks_seen': ranks_seen,
+            'backend': backend if multi else 'none (single process)', 'ranks_seen': ranks_seen,
+            'forced_collectives': forced,
             'config': {'workload': '%s: %s%s' % (args.workload.upper(), wname,
                                                   '' if args.no_episode_stats else ' + per-env episode-return tracking'),
                        'envs_per_gpu': n, 'total_envs': n * world,
@@ -525,7 +535,7 @@ def run_rank(args):
             out['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     return 0

@@ -744,6 +744,27 @@ def test_all_gather_of_episode_returns_through_rccl(gpu):
             dist.destroy_process_group()
 
 
+def test_bench_multi_gpu_code_path_on_rccl_with_one_rank(gpu):
+    """SCG_BENCH_FORCE_COLLECTIVES=1: bench.py builds a ONE-rank RCCL world and runs every collective of its N > 1 path on the
+    device -- the barriers of the timed regions, the max-reduce of the times, the asynchronous all-gather of episode returns
+    inside the timed region, the gather of per-rank step times.  (RCCL refuses two ranks on one device, so this is as close as
+    a one-GPU box gets to the sharded run.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['SCG_BENCH_FORCE_COLLECTIVES'] = '1'
+    run = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '320', '--warmup', '5', '--repeats', '2',
+                          '--envs-per-gpu', '65536', '--no-cpu-baseline', '--no-sub-records'], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert run.returncode == 0, run.stderr[-3000:]
+    j = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith('{')][-1])
+    assert j['backend'] == 'nccl' and j['ranks_seen'] == 1 and j['forced_collectives'] is True and j['value'] > 0
+    assert len(j['per_rank_ms_per_step_min_max']) == 2
+
+
 def test_bench_launcher_runs_two_ranks_on_this_gpu(gpu):
     """`python bench.py --gpus 2` with no launcher environment: the parent (no GPU call) starts two rank processes, which here share
     the box's one GPU and exchange over gloo (SCG_SINGLE_DEVICE=1: RCCL refuses two ranks on one device); rank 0's line comes back
