@@ -18,8 +18,10 @@ values measure scaling and nothing else:
     episode-return tracking every vectorised caller of the reference has (VecRecordEpisodeStatistics).  SURVEY.md 8(d) counts
     B = 8 nx + 4 nu + 13 + 16 = 141 bytes per env-step for it; the engine MOVES 133 (under auto-reset the episode length
     is the step counter, so no ep_length plane exists) and ``roofline`` is computed on the bytes moved.
-  * N > 1 -> C5: that shard on every GPU (weak scaling, envs sharded by contiguous global index) plus one RCCL
-    all-gather of the episode returns every 300 steps (= one episode) inside the timed region.
+  * N > 1 -> C5: that shard on every GPU (weak scaling, envs sharded by contiguous global index) plus the RCCL
+    all-gather of the episode returns inside the timed region -- at least every 300 steps (= one episode) and once per region,
+    asynchronously on a snapshot, overlapping the chunk's step kernels.  ``SCG_BENCH_FORCE_COLLECTIVES=1`` with ``--gpus 1`` runs
+    this whole path (every collective, on RCCL) in a one-rank world: the rehearsal a one-GPU box allows.
   * At N = 1 the line also carries sub-records, each a few hundred ms: ``c4_without_episode_stats`` (the bare 125-byte
     step), ``precise_mode`` (the <= 1e-5-drift-over-1000-steps mode), ``c3`` and ``c2`` (BASELINE configs 3 and 2).
 Actions are i.i.d. U(a_low, a_high) float32, pre-generated on the device ([300, nu, N]) and reused cyclically; initial /
