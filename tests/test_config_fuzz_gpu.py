@@ -2,6 +2,8 @@
 (system, task, cost, tiers via info level / constraints / goal horizon / normalised actions / output ownership, physics,
 sub-steps, ragged batch sizes), each stepped teacher-forced against the float64 oracle.  The fixed lists in
 test_parity_gpu.py cover every option once; this covers their products."""
+import os
+
 import numpy as np
 import pytest
 
@@ -78,7 +80,7 @@ def draw_config(rng):
     return system, kw, engine, n
 
 
-@pytest.mark.parametrize('seed', range(96))
+@pytest.mark.parametrize('seed', range(int(os.environ.get('SCG_FUZZ_SEEDS', '96'))))
 def test_random_configuration_against_the_oracle(gpu, seed):
     rng = np.random.default_rng(9000 + seed)
     system, kw, engine, n = draw_config(rng)
@@ -115,7 +117,7 @@ def test_random_configuration_against_the_oracle(gpu, seed):
     env.close()
 
 
-@pytest.mark.parametrize('seed', range(48))
+@pytest.mark.parametrize('seed', range(int(os.environ.get('SCG_FUZZ_SEEDS', '96')) // 2))
 def test_random_configuration_rollout_equals_step_loop(gpu, seed):
     """For the same random configurations: K step() calls == scg_rollout (two launch queues forced at this size) ==
     scg_rollout_fused (where the configuration admits it; others fall back to scg_rollout), bit for bit."""
