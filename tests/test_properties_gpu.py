@@ -65,6 +65,42 @@ def test_full_size_invariances_of_the_dynamics(gpu):
         env.close()
 
 
+def test_c5_total_size_eight_shards_reproduce_the_8m_batch(gpu):
+    """BASELINE config C5 at its full TOTAL size on one GPU: the 2^23-env batch (one engine) against its eight 2^20-env shards
+    (parallel.make_sharded: env_index_base = rank * 2^20), each run in turn on this GPU -- what the eight ranks of the 8-GPU run
+    compute.  Same resets (Philox keyed by the global index), same rollout with auto-resets: states, counters and episode returns
+    of every shard equal its slice of the big batch bit for bit; the gathered returns equal the big batch's plane."""
+    from safe_control_gym_amd import parallel
+    total, world, K = 1 << 23, 8, 40
+    kw = dict(id='quadrotor', quad_type=3, device='cuda', seed=1337, ctrl_freq=60, pyb_freq=240, randomized_init=True, task='traj_tracking',
+              cost='quadratic', info_level='minimal', track_episode_stats=True, episode_len_sec=0.5)
+    full = parallel.make_sharded(scg.make, total, rank=0, world_size=1, **kw)
+    full.reset()
+    g = torch.Generator(device='cuda'); g.manual_seed(11)
+    lo, hi = float(full.action_space.low[0]), float(full.action_space.high[0])
+    acts = torch.rand((3, 4, full.plane_stride), generator=g, device='cuda') * (hi - lo) + lo
+    full.rollout(acts, steps=K)
+    state_full, t_full, ret_full = full.state_soa.clone(), full.ctrl_step_counter.clone(), full.episode_return.clone()
+    assert int((t_full < K).sum()) > total // 2                     # 30-step episodes: every env auto-reset at least once
+    full.close()
+    del full
+    gathered = []
+    for rank in range(world):
+        shard = parallel.make_sharded(scg.make, total, rank=rank, world_size=world, **kw)
+        lo_i, hi_i = parallel.shard_bounds(total, world, rank)
+        assert shard.num_envs == hi_i - lo_i == 1 << 20
+        shard.reset()
+        a = torch.zeros((3, 4, shard.plane_stride), device='cuda')
+        a[:, :, :shard.num_envs] = acts[:, :, lo_i:hi_i]
+        shard.rollout(a, steps=K)
+        assert torch.equal(shard.state_soa, state_full[:, lo_i:hi_i]), rank
+        assert torch.equal(shard.ctrl_step_counter, t_full[lo_i:hi_i]), rank
+        gathered.append(shard.episode_return.clone())
+        shard.close()
+        del shard, a
+    assert torch.equal(torch.cat(gathered), ret_full)               # what the all-gather of the 8 ranks assembles
+
+
 def test_determinism_and_shard_invariance(gpu):
     """Same seed -> bit-identical rollouts; a shard built with env_index_base reproduces the matching slice of
     the big batch bit for bit (per-env Philox streams are keyed by the GLOBAL env index)."""
