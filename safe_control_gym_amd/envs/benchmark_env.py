@@ -759,6 +759,20 @@ class BenchmarkEnv:
         self._bound = False
 
     # ------------------------------------------------------------------ reset / step
+    def extend_obs(self, obs, next_step):
+        """benchmark_env.py:406-420 for a batch: append the next ``obs_goal_horizon`` reference states (tracking; rows
+        ``min(next_step + i, T - 1)``) or the goal (stabilisation) to ``obs`` [N, nx].  ``next_step``: an int or an [N] tensor.
+        The step kernel does this itself; the method is for callers that build observations of their own."""
+        if not (self.COST == Cost.RL_REWARD and self.obs_goal_horizon > 0):
+            return obs
+        obs = torch.as_tensor(obs, dtype=torch.float32, device=self.device)
+        goal = torch.as_tensor(np.asarray(self.X_GOAL, dtype=np.float32), device=obs.device)
+        if self.TASK == Task.TRAJ_TRACKING:
+            step = torch.as_tensor(next_step, device=obs.device).reshape(-1, 1).expand(obs.shape[0], 1).long()
+            idx = (step + torch.arange(self.obs_goal_horizon, device=obs.device)[None, :]).clamp(max=goal.shape[0] - 1)
+            return torch.cat([obs, goal[idx].reshape(obs.shape[0], -1)], dim=1)
+        return torch.cat([obs, goal.reshape(1, -1).expand(obs.shape[0], -1)], dim=1)
+
     def _obs_view(self):
         src = self._bufs['obs'] if 'obs' in self._bufs else self._bufs['state']
         return src[:, :self.num_envs].T

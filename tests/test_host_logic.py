@@ -320,3 +320,27 @@ def test_reference_name_aliases_and_registry_surface():
         assert len(np.unique(flat)) == len(flat) and set(flat) <= set(range(15))
     con = scg.make('quadrotor', quad_type=2, num_envs=3, constraints=[{'constraint_form': 'default_constraint', 'constrained_variable': 'input'}]).constraints.constraints[0]
     assert con.get_env_constraint_var(env) is None                      # the raw action before the first step, as env.state is None
+
+
+def test_extend_obs_helper_matches_reference_rule():
+    """benchmark_env.py:406-420 batched: rows min(next_step + i, T - 1) for tracking, the goal for stabilisation, obs unchanged
+    otherwise (the oracle's extend_obs is pinned to the executed reference method in test_reference_pins.py)."""
+    import torch
+    from oracle.ref_env import RefEnv
+    kw = dict(task='traj_tracking', cost='rl_reward', obs_goal_horizon=3, ctrl_freq=50, pyb_freq=50)
+    env = scg.make('quadrotor', quad_type=2, num_envs=4, device='cpu', **kw)
+    ref = RefEnv(system=2, **kw)
+    rng = np.random.default_rng(0)
+    obs = rng.normal(size=(4, 6))
+    steps = np.array([0, 7, 248, 10 ** 6])
+    got = env.extend_obs(torch.as_tensor(obs, dtype=torch.float32), torch.as_tensor(steps)).numpy()
+    for i in range(4):
+        ref.state, ref.ctrl_step_counter = obs[i].copy(), int(steps[i]) - 1
+        assert np.abs(got[i] - ref._get_observation()).max() <= 1e-6
+    kw = dict(task='stabilization', cost='rl_reward', obs_goal_horizon=1)
+    env, ref = scg.make('quadrotor', quad_type=2, num_envs=4, device='cpu', **kw), RefEnv(system=2, **kw)
+    ref.state, ref.ctrl_step_counter = obs[0].copy(), 3
+    assert np.abs(env.extend_obs(torch.as_tensor(obs, dtype=torch.float32), 4).numpy()[0] - ref._get_observation()).max() <= 1e-6
+    plain = scg.make('quadrotor', quad_type=2, num_envs=4, device='cpu')
+    x = torch.zeros(4, 6)
+    assert plain.extend_obs(x, 1) is x
