@@ -185,13 +185,23 @@ __global__ __launch_bounds__(256) void scg_mean_std_apply_kernel(const float* __
     float* dst = uptr(y + (int64_t)j * ld_y);
     const double lo = -(double)clip, hi = (double)clip;
     if constexpr (VEC) {
-        const uint32_t n4 = n >> 2;
-        for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < n4; q += gridDim.x * 256u) {
-            const nf4 v4 = reinterpret_cast<const nf4*>(src)[q];      // plain load: this pass should hit the cache
-            nf4 o;
+        const uint32_t n4 = n >> 2, stride = gridDim.x * 256u;
+        // four independent 16-byte loads in flight per thread before the first use: at one per thread the 12 resident workgroups
+        // of a CU hold 49 KB in flight, less than latency x bandwidth asks for (62 KB per CU)
+        for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < n4; q += 4u * stride) {
+            nf4 v4[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = (float)fmin(fmax(((double)v4[k] - mean) * inv, lo), hi);
-            __builtin_nontemporal_store(o, reinterpret_cast<nf4*>(dst) + q);
+            for (int u = 0; u < 4; ++u)
+                if (q + u * stride < n4) v4[u] = reinterpret_cast<const nf4*>(src)[q + u * stride];   // plain load: this pass may hit the cache
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (q + u * stride < n4) {
+                    nf4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = (float)fmin(fmax(((double)v4[u][k] - mean) * inv, lo), hi);
+                    __builtin_nontemporal_store(o, reinterpret_cast<nf4*>(dst) + q + u * stride);
+                }
+            }
         }
         if (blockIdx.x == 0 && threadIdx.x < (n & 3u)) {
             const uint32_t i = (n & ~3u) + threadIdx.x;
