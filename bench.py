@@ -11,6 +11,11 @@ processes of this script (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_A
 rank 0's JSON line and exits non-zero if any child does -- the fan-out / gather of SubprocVecEnv
 (/root/reference/safe_control_gym/envs/env_wrappers/vectorized_env/subproc_vec_env.py:28-63) with processes instead of pipes.
 Under ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`` the ranks exist already and each runs the body.
+The launcher passes its own environment through and SETS exactly RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT; it also
+DEFAULTS HSA_ENABLE_IPC_MODE_LEGACY to 0 when the caller has not set it (the platform note of this pool: the host driver only
+supports dmabuf IPC, and without that setting RCCL's peer access fails with ``hipIpcGetMemHandle: invalid argument``; the
+image exports it already, so this only matters for a scrubbed environment).  Rank r computes on device LOCAL_RANK = r and owns the
+global env indices [r n, (r + 1) n) (``rank_layout``).  Every rank's stderr reaches this process's stderr with a ``[rank r]`` prefix.
 
 Workload (BASELINE.json ``configs``) -- the SAME per-GPU work at every N, so that the per-N
 values measure scaling and nothing else:
@@ -42,6 +47,7 @@ import socket
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -96,18 +102,44 @@ def must_spawn(args, environ):
     return args.gpus > 1 and 'WORLD_SIZE' not in environ
 
 
+def rank_layout(rank, local_rank, envs_per_gpu):
+    """What a rank computes on and which envs it owns: device index = LOCAL_RANK, global env indices
+    [rank * envs_per_gpu, (rank + 1) * envs_per_gpu) (the Philox streams are keyed by the global index)."""
+    return {'rank': int(rank), 'device_index': int(local_rank), 'env_index_base': int(rank) * int(envs_per_gpu),
+            'envs': int(envs_per_gpu)}
+
+
+def rank_environment(base_env, rank, world, port):
+    """The environment of rank `rank`: the caller's, plus exactly the five rendezvous variables; HSA_ENABLE_IPC_MODE_LEGACY is
+    defaulted to 0 only when the caller has not set it (module docstring)."""
+    env = dict(base_env, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(port))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return env
+
+
+def _relay_stderr(pipe, rank):
+    """Copy a rank's stderr to ours, line by line, with a rank prefix (a first real multi-GPU failure must be readable from
+    the launcher's tail)."""
+    for line in iter(pipe.readline, ''):
+        sys.stderr.write('[rank %d] %s' % (rank, line))
+        sys.stderr.flush()
+    pipe.close()
+
+
 def spawn_ranks(args, argv):
     """Start args.gpus children of this script, one per GPU; relay rank 0's JSON line; non-zero if any child fails.
     Nothing here initialises HIP (no torch import): the children are new processes, never an exec of this one."""
     world = args.gpus
     port = _free_port()
-    procs = []
+    procs, relays = [], []
     rank0_out = tempfile.TemporaryFile(mode='w+')          # a file, not a pipe: rank 0 can never block on a full pipe
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=rank0_out if r == 0 else subprocess.DEVNULL, text=True))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv),
+                                      env=rank_environment(os.environ, r, world, port),
+                                      stdout=rank0_out if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
+        relays.append(threading.Thread(target=_relay_stderr, args=(procs[-1].stderr, r), daemon=True))
+        relays[-1].start()
     deadline = time.time() + args.spawn_timeout
     failed = None
     pending = set(range(world))
@@ -134,9 +166,13 @@ def spawn_ranks(args, argv):
                 p.wait(timeout=10)
             except subprocess.TimeoutExpired:
                 p.kill()
+        for t in relays:
+            t.join(timeout=5)
         who = 'timeout after %.0f s' % args.spawn_timeout if failed[0] < 0 else 'rank %d exited with %d' % failed
         sys.stderr.write('bench.py: %s; the other ranks were stopped\n' % who)
         return failed[1] if failed[1] != 0 else 1
+    for t in relays:
+        t.join(timeout=5)
     rank0_out.seek(0)
     out = rank0_out.read()
     line = None
@@ -157,7 +193,7 @@ def build_env(args, workload, rank, n, track, extra=None):
     """-> (env, name, survey_bytes, moved_bytes) per env-step."""
     import yaml
     import safe_control_gym_amd as scg
-    common = dict(num_envs=n, device='cuda', seed=1337, env_index_base=rank * n, randomized_init=True,
+    common = dict(num_envs=n, device='cuda', seed=1337, env_index_base=rank_layout(rank, 0, n)['env_index_base'], randomized_init=True,
                   info_level='minimal', track_episode_stats=track, ctrl_freq=60, pyb_freq=240, episode_len_sec=5,
                   rollout_queues=args.queues)
     for kv in args.env_kw:
@@ -252,6 +288,8 @@ def sub_record(args, timer, workload, n, steps, track=False, extra=None, note=No
     env, name, survey, moved = build_env(args, workload, 0, n, track, extra)
     acts = make_actions(env, 0, min(args.action_period, 64), timer.dev)
     env.reset()
+    for _ in range(2):                     # small batches: scg_rollout captures this signature's hipGraph on its second sighting
+        env.rollout(acts, steps=steps)
     m = timer.measure(lambda k: env.rollout(acts, steps=k), steps, min(args.warmup, 20) + 5, 3)
     us = m['ms'] * 1e3 / steps
     rec = {'workload': '%s: %s' % (workload.upper(), name), 'envs': n, 'steps': steps, 'value': n / (us * 1e-6), 'unit': 'env-steps/s',
@@ -349,7 +387,7 @@ def dry_run_rank(args):
     import torch
     import torch.distributed as dist
     from safe_control_gym_amd import parallel
-    rank, world, _ = parallel.init_from_env(backend='gloo')
+    rank, world, local_rank = parallel.init_from_env(backend='gloo')
     fail_rank = int(os.environ.get('SCG_BENCH_DRYRUN_FAIL_RANK', '-1'))
     if rank == fail_rank:
         sys.stderr.write('dry run: rank %d fails on request\n' % rank)
@@ -363,13 +401,19 @@ def dry_run_rank(args):
     else:
         gathered = returns
     ok = bool(torch.equal(gathered, torch.arange(n * world, dtype=torch.float32)))
+    # what every rank WOULD compute on / own (the same rank_layout() the real run uses), gathered for the launcher tests
+    mine = dict(rank_layout(rank, local_rank, args.envs_per_gpu), local_rank_env=os.environ.get('LOCAL_RANK'),
+                ipc_mode_legacy=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'))
+    layout = [mine]
     if world > 1:
+        layout = [None] * world
+        dist.all_gather_object(layout, mine)
         dist.barrier()
     if rank == 0:
         print(json.dumps({'metric': 'env-steps/sec at N parallel envs, 1/2/4/8 GPUs; % HBM-BW roofline', 'value': None,
                           'dry_run': True, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                           'backend': dist.get_backend() if world > 1 else 'none', 'ranks_seen': int(ones.item()),
-                          'gather_ok': ok}))
+                          'gather_ok': ok, 'rank_layout': layout}))
         sys.stdout.flush()
     if world > 1:
         dist.barrier()
@@ -390,8 +434,9 @@ def run_rank(args):
         args.workload = 'c4' if world == 1 else 'c5'        # same env; 'c5' = sharded + all-gather
     if world > 1 and args.no_episode_stats:
         raise SystemExit('--no-episode-stats is a single-GPU option (the sharded run gathers the episode returns)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    layout = rank_layout(rank, local_rank, args.envs_per_gpu)
+    torch.cuda.set_device(layout['device_index'])
+    dev = torch.device('cuda', layout['device_index'])
     # SCG_BENCH_FORCE_COLLECTIVES=1: a ONE-rank RCCL world that runs every collective of the N > 1 path (barrier, max-reduce,
     # the asynchronous all-gather inside the timed region, the per-rank gather) -- the rehearsal a one-GPU box allows, since
     # RCCL refuses two ranks on one device
@@ -532,6 +577,13 @@ def run_rank(args):
                  '(tests/test_parity_gpu.py::test_precise_mode_open_loop_1000_step_drift)')
         out['c3'] = sub_record(args, timer, 'c3', 1 << 18, max(sub_steps, 1000))
         out['c2'] = sub_record(args, timer, 'c2', 1 << 16, max(sub_steps, 1000))
+        # the north-star's N in {1k ... 1M}: the bare C4 step at each batch size, same clock (a few ms apiece)
+        sweep = []
+        for e in range(10, 21, 2):
+            r = sub_record(args, timer, 'c4', 1 << e, max(sub_steps, 1000 if e < 18 else 300))
+            sweep.append({'envs': r['envs'], 'steps': r['steps'], 'us_per_step': r['us_per_step'], 'value': r['value'], 'frac': r['frac']})
+        out['n_sweep'] = {'workload': 'bare C4 step (125 B moved per env-step), scg_rollout; below the two-queue threshold the launches are '
+                                      'replayed from a hipGraph (scg_config.rollout_graph)', 'unit': 'env-steps/s', 'points': sweep}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SCG_ABI_VERSION 4
+#define SCG_ABI_VERSION 5
 #define SCG_MAX_NX 12        /* quadrotor.py:625  (3-D: nx = 12) */
 #define SCG_MAX_NU 4         /* quadrotor.py:625  (3-D: nu = 4)  */
 #define SCG_MAX_NV 16        /* constrained variable: [state ; raw action], constraints.py:58-63 */
@@ -132,12 +132,15 @@ typedef struct scg_config {
      *   >= rollout_split_min envs in two halves advancing on two HIP streams.
      * rollout_split_min: 0 = default (131072 envs per half).
      * ref_in_lds: stage the X_GOAL table in LDS once per workgroup instead of gathering it through L1/L2.
-     * grid_cap_per_cu: 0 = one lane per env (no grid-stride loop); > 0 caps the grid at that many workgroups per CU. */
+     * grid_cap_per_cu: 0 = one lane per env (no grid-stride loop); > 0 caps the grid at that many workgroups per CU.
+     * rollout_graph: 0 = default (on), 1 = on, -1 = off.  On: scg_rollout captures the launches of a single-queue rollout
+     *   (batches below the two-queue threshold, >= 8 steps) into a hipGraph the second time it sees the same signature
+     *   (same scg_step_io pointers, n, steps, action layout) and replays it from then on; see scg_rollout. */
     int32_t rollout_queues;
     int32_t ref_in_lds;
     int64_t rollout_split_min;
     int32_t grid_cap_per_cu;
-    int32_t reserved3;
+    int32_t rollout_graph;
 } scg_config;
 
 /* np.random.RandomState methods the reset path can draw from on the device (benchmark_env.py:297-307); u, u2 are
@@ -290,7 +293,15 @@ int scg_step(scg_handle* h, const scg_step_io* io, int64_t n, void* stream);
  * step chains are issued on `stream` and on a second, handle-owned stream (forked from and joined back into `stream` by
  * events inside this call -- on error paths too), so that one half's kernel ramp-up / drain overlaps the other half's body;
  * per env the results are bit-identical to single-stream stepping.  scg_config.rollout_queues = 1 keeps everything on
- * `stream`; scg_config.rollout_split_min moves the threshold. */
+ * `stream`; scg_config.rollout_split_min moves the threshold.
+ * Smaller batches (launch-bound: a step kernel lasts a few microseconds): the second call with the same signature -- the same
+ * scg_step_io contents apart from reset_serial, n, steps, action_stride, action_period -- captures its launches into a
+ * hipGraph on the handle's own queue, and that call and every later one with the signature replay it (forked from / joined
+ * into `stream` by events; the step serial travels through a device word, so the Philox counters are those of plain
+ * launches and the results are bit-identical).  At most 4 signatures are kept (least recently used goes); scg_set_reference /
+ * _constraints / _disturbances drop them.  Not taken when `stream` is itself being captured (the launches then join the
+ * caller's graph), when steps < 8, or with scg_config.rollout_graph = -1; a capture that fails is ended, discarded, and the
+ * handle stays on plain launches. */
 int scg_rollout(scg_handle* h, const scg_step_io* io, int64_t n, int32_t steps, int64_t action_stride,
                 int32_t action_period, void* stream);
 
@@ -366,7 +377,8 @@ int scg_quadratic_loss(scg_handle* h, const double* Q, const double* R, const fl
  * update RunningMeanStd (:34-62) with the batch of n rows, then y = clip((x - mean) / sqrt(var + epsilon), +-clip).
  * state_in / state_out are device records of 2 d + 1 doubles: mean[d], var[d], count (the caller ping-pongs two
  * records; a fresh tracker is mean 0, var 1, count 1e-4, :28-30).  state_out == NULL is the read_only normaliser
- * (:126): no update.  scratch is device memory for 2 max(64 d, 1024) doubles (per-workgroup partial sums).  y may alias x. */
+ * (:126): no update.  scratch is device memory for 2 max(64 d, 1024) doubles (per-workgroup partial sums).  y may alias x.
+ * y == NULL (with state_out) is RunningMeanStd.update(batch) alone (:34-46): the tracker moves, nothing is normalised. */
 int scg_mean_std_normalize(const float* x, float* y, int32_t d, int64_t ld_x, int64_t ld_y, int64_t n,
                            const double* state_in, double* state_out, double* scratch, float clip, double epsilon,
                            void* stream);
@@ -377,6 +389,10 @@ int scg_mean_std_normalize(const float* x, float* y, int32_t d, int64_t ld_x, in
 int scg_reward_normalize(const float* rew, const uint8_t* done, float* ret, float* out, int64_t n,
                          const double* state_in, double* state_out, double* scratch, float gamma, float clip,
                          double epsilon, int32_t legacy_index_reset, void* stream);
+
+/* Introspection of scg_rollout's hipGraph replay (tests, tuning): *cached = rollout signatures currently held as instantiated
+ * graphs (-1: a capture failed and the handle stays on plain launches), *replays = graph launches so far.  Either may be NULL. */
+int scg_rollout_graph_info(const scg_handle* h, int32_t* cached, int64_t* replays);
 
 /* Introspection */
 int scg_num_constraints(const scg_handle* h);

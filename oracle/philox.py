@@ -63,7 +63,7 @@ def draw(kind, u, u2, p, low=0.0, high=1.0):
         return -p[0] * np.log(1.0 - u)
     if kind == LAPLACE:
         d = u - 0.5
-        return p[0] - np.copysign(p[1] * np.log(max(1.0 - 2.0 * abs(d), 2.0 ** -24)), d)
+        return p[0] + np.copysign(p[1] * np.log(max(1.0 - 2.0 * abs(d), 2.0 ** -24)), d)   # the monotone inverse CDF (numpy's)
     if kind == LOGISTIC:
         return p[0] + p[1] * np.log(uo / (1.0 - uo))
     if kind == TRIANGULAR:

@@ -7,7 +7,7 @@ module raises.  Struct layouts mirror the header field for field; ``load()`` cro
 import ctypes as C
 import os
 
-SCG_ABI_VERSION = 4
+SCG_ABI_VERSION = 5
 SCG_MAX_NX = 12
 SCG_MAX_NU = 4
 SCG_MAX_NV = 16
@@ -67,7 +67,7 @@ class ScgConfig(C.Structure):
         ('init_rand_kind', _i32 * SCG_MAX_NX), ('init_rand_p', (_dbl * 3) * SCG_MAX_NX),
         ('inertial_rand_kind', _i32 * 4), ('inertial_rand_p', (_dbl * 3) * 4),
         ('rollout_queues', _i32), ('ref_in_lds', _i32), ('rollout_split_min', C.c_int64),
-        ('grid_cap_per_cu', _i32), ('reserved3', _i32),
+        ('grid_cap_per_cu', _i32), ('rollout_graph', _i32),
     ]
 
 
@@ -104,7 +104,7 @@ class ScgDisturbance(C.Structure):
 
 EXPORTS = (
     'scg_create', 'scg_destroy', 'scg_set_reference', 'scg_set_constraints', 'scg_set_disturbances', 'scg_reset', 'scg_step', 'scg_rollout', 'scg_rollout_fused',
-    'scg_eval_constraints', 'scg_gae', 'scg_normalize_advantages', 'scg_model_eval', 'scg_linearize', 'scg_fc_linear', 'scg_discretize_exact', 'scg_quadratic_loss', 'scg_mean_std_normalize', 'scg_reward_normalize', 'scg_num_constraints', 'scg_obs_dim', 'scg_kernel_info', 'scg_last_error',
+    'scg_eval_constraints', 'scg_gae', 'scg_normalize_advantages', 'scg_model_eval', 'scg_linearize', 'scg_fc_linear', 'scg_discretize_exact', 'scg_quadratic_loss', 'scg_mean_std_normalize', 'scg_reward_normalize', 'scg_num_constraints', 'scg_obs_dim', 'scg_kernel_info', 'scg_rollout_graph_info', 'scg_last_error',
     'scg_version', 'scg_sizeof_config', 'scg_sizeof_step_io', 'scg_sizeof_constraint_row', 'scg_sizeof_disturbance',
 )
 
@@ -168,6 +168,7 @@ def load():
     lib.scg_num_constraints.argtypes = [C.c_void_p]
     lib.scg_obs_dim.argtypes = [C.c_void_p]
     lib.scg_kernel_info.argtypes = [C.c_void_p, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.c_int64]
+    lib.scg_rollout_graph_info.argtypes = [C.c_void_p, C.POINTER(_i32), C.POINTER(C.c_int64)]
     for name in EXPORTS:
         if name not in ('scg_last_error',):
             getattr(lib, name).restype = C.c_int

@@ -1,8 +1,10 @@
 #!/bin/bash
 # Build libscg_rollout.so (HIP kernels + C ABI) for gfx950, in-tree.
 # -fno-slp-vectorize: the SLP vectoriser packs the RK4 stages into v_pk_fma_f32 register pairs,
-# which costs 40+ VGPRs (147 vs 103) and a wave of occupancy per SIMD for no FLOP-rate gain.
-# The translation units are compiled in parallel (scg_kernels.hip dominates: ~60 s), then linked.
+# which costs 40+ VGPRs (147 vs 103) and a wave of occupancy per SIMD for no FLOP-rate gain (the packed sin / cos of
+# scg_math.h is written with explicit two-lane vectors instead).
+# The translation units are compiled in parallel (scg_kernels.hip dominates: ~90 s), then linked.  A unit is recompiled
+# when its source, any header of this directory, the C-ABI header or the flags changed (SCG_BUILD_FORCE=1: always).
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="$here/../lib"
@@ -11,12 +13,22 @@ mkdir -p "$out" "$obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 flags=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize "$@")
 units=(scg_kernels scg_gae scg_linearize scg_normalize scg_expm scg_capi)
+stamp="$obj/flags.txt"
+if [ ! -f "$stamp" ] || [ "$(cat "$stamp")" != "${flags[*]}" ]; then rm -f "$obj"/*.o; echo "${flags[*]}" > "$stamp"; fi
 pids=()
 for u in "${units[@]}"; do
-    "$HIPCC" "${flags[@]}" -c "$here/$u.hip" -o "$obj/$u.o" &
-    pids+=($!)
+    stale=0
+    if [ "${SCG_BUILD_FORCE:-0}" = "1" ] || [ ! -f "$obj/$u.o" ]; then stale=1; else
+        for dep in "$here/$u.hip" "$here"/*.h "$here/../../include/scg_rollout.h"; do
+            if [ "$dep" -nt "$obj/$u.o" ]; then stale=1; fi
+        done
+    fi
+    if [ "$stale" = "1" ]; then
+        "$HIPCC" "${flags[@]}" -c "$here/$u.hip" -o "$obj/$u.o" &
+        pids+=($!)
+    fi
 done
-for p in "${pids[@]}"; do wait "$p"; done
+for p in ${pids[@]+"${pids[@]}"}; do wait "$p"; done
 objs=()
 for u in "${units[@]}"; do objs+=("$obj/$u.o"); done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out/libscg_rollout.so" "${objs[@]}"

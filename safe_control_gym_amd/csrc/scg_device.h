@@ -25,6 +25,7 @@ enum Flags : uint32_t {
     F_RAND_INERTIAL = 1u << 13, // per-env inertial properties re-drawn at every reset
     F_GND = 1u << 14,           // ground effect (Physics.PYB_GND)
     F_DRAG = 1u << 15,          // drag (Physics.PYB_DRAG)
+    F_W_STATE_UNIT = 1u << 17,  // every diagonal state weight of the cost is exactly 1 (Q = I / rew_state_weight = 1)
     F_RAND_GENERAL = 1u << 16,  // some reset-time quantity is drawn from a non-uniform distribution (scg_distribution)
 };
 
@@ -45,6 +46,7 @@ struct PhysT {
     T inv_nmotor_kf;            // 1 / (n_motor KF)
     T nmotor_kf;                // n_motor KF
     T pwm_scale, inv_pwm_scale, pwm_const, pwm_min, pwm_max;
+    T th_min, th_max;           // n KF (pwm_scale pwm_min + pwm_const)^2, ... pwm_max ...: the pwm clip seen from the thrust side
     // cartpole
     T cp_l, cp_m, cp_inv_Mm, cp_ml, cp_g;
 };
@@ -61,17 +63,20 @@ struct KParams {
     int32_t n_con_rows;         // total constraint rows (c_val planes)
     int32_t grid_cap_per_cu;    // host-side launch policy (scg_config.grid_cap_per_cu); not read on the device
     uint32_t oob_dims;          // bit j: state dim j has a binding out-of-bound limit (|bound| < f32max); the others are skipped
+    uint32_t oob_sym;           // bit j: that limit is symmetric (low == -high in float32): |x| <= high is the whole test
     uint32_t seed_lo, seed_hi;
     int64_t env_base;
     PhysT<float> ph;            // physical constants (fp32 copy, SGPRs)
     // action
-    float norm_act_scale, hover_thrust, action_scale;
+    float act_mul, act_add;     // preprocessed action = act_mul * clip(a) + act_add: (1, 0), or the normalised action space
+                                // (quadrotor.py:828: (norm_act_scale hover_thrust, hover_thrust); cart-pole: (action_scale, 0))
     float goal_tol2;
     float constraint_penalty;
     float cost_scale;           // -1 (rl_reward: rew = -dist) or -0.5 (quadratic: rew = -l/2 ... see w_state)
     // aero terms: gnd_k = gnd_eff_coeff (prop_radius / 4)^2, drag_* = drag_coeff * 2 pi / 60 (per rpm)
     float gnd_k, gnd_h_clip, drag_xy, drag_z;
     const DistTable* dist;   // device; null when the env has no passive disturbances
+    const uint32_t* serial_base;   // device word added to scg_step_io.reset_serial (launches replayed from a rollout graph); null otherwise
 };
 
 // Per-dimension constant vectors: live in device memory, read through a wave-uniform pointer with
@@ -149,7 +154,7 @@ struct LaunchGeom {
 
 // Kernel launchers (scg_kernels.hip)
 namespace scg {
-LaunchGeom step_geometry(const KParams& p, int system, int64_t n, int num_cus);
+LaunchGeom step_geometry(const KParams& p, int system, int comp, int64_t n, int num_cus);   // comp: 0 float state, 1 / 2 precise modes
 hipError_t launch_step(int system, const KParams& p, const scg_step_io& io, const KTables* tb,
                        const ConTable* ct, const float* ref, int64_t n, int num_cus, hipStream_t s);
 bool fused_rollout_ok(const KParams& p, const scg_step_io& io);

@@ -17,6 +17,9 @@ template <class T> struct Real;
 template <> struct Real<float> {
     static __device__ __forceinline__ float rcp(float x) { return rcp_f(x); }
     static __device__ __forceinline__ void sincos(float x, float& s, float& c) { sincos_f(x, s, c); }
+    static __device__ __forceinline__ void sincos2(float xa, float xb, float& sa, float& ca, float& sb, float& cb) {
+        sincos2_f(xa, xb, sa, ca, sb, cb);
+    }
 };
 template <> struct Real<double> {
     static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
@@ -43,6 +46,10 @@ template <> struct Real<double> {
         s = (k & 2) ? -ss : ss;
         c = ((k + 1) & 2) ? -cc : cc;
     }
+    static __device__ __forceinline__ void sincos2(double xa, double xb, double& sa, double& ca, double& sb, double& cb) {
+        sincos(xa, sa, ca);
+        sincos(xb, sb, cb);
+    }
 };
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return fma(a, b, c); }
@@ -55,7 +62,9 @@ template <class T> struct Inputs<SCG_CARTPOLE, T> { T F; };
 
 // ZOH inputs of one step.  In the precise mode the physical constants are the float-rounded kernarg values
 // widened to double -- the same constants the float path uses, so the two modes integrate the same model.
-template <int SYS, class T>
+// FORCE = false: no external force can act in this instantiation (lean / info tiers): ax = ay = 0 and az = -g are the values
+// 0 * inv_m and fma(0, inv_m, -g) take -- as literals / one SGPR instead of three VGPRs held across the whole integration.
+template <int SYS, class T, bool FORCE = true>
 __device__ __forceinline__ void make_inputs(const PhysT<T>& c, const T* u, T fx, T fy, T fz,
                                             Inputs<SYS, T>& in) {
     const T inv_m = c.inv_m, g = c.g;
@@ -63,14 +72,14 @@ __device__ __forceinline__ void make_inputs(const PhysT<T>& c, const T* u, T fx,
         in.acc = fma_t(u[0] + (T)fz, inv_m, -g);                                // quadrotor.py:602
     } else if constexpr (SYS == SCG_QUAD_2D) {
         in.Tm = (u[0] + u[1]) * inv_m;                                          // quadrotor.py:619-620
-        in.ax = (T)fx * inv_m;
-        in.az = fma_t((T)fz, inv_m, -g);
+        in.ax = FORCE ? (T)fx * inv_m : (T)0;
+        in.az = FORCE ? fma_t((T)fz, inv_m, -g) : -g;
         in.thdd = c.l_s2_iyy * (u[1] - u[0]);                                // quadrotor.py:621
     } else if constexpr (SYS == SCG_QUAD_3D) {
         in.Tm = ((u[0] + u[1]) + (u[2] + u[3])) * inv_m;                        // quadrotor.py:664
-        in.ax = (T)fx * inv_m;
-        in.ay = (T)fy * inv_m;
-        in.az = fma_t((T)fz, inv_m, -g);
+        in.ax = FORCE ? (T)fx * inv_m : (T)0;
+        in.ay = FORCE ? (T)fy * inv_m : (T)0;
+        in.az = FORCE ? fma_t((T)fz, inv_m, -g) : -g;
         in.mx = c.arm_s2 * ((u[0] + u[1]) - (u[2] + u[3])) * c.inv_ixx;   // quadrotor.py:667
         in.my = c.arm_s2 * ((u[1] + u[2]) - (u[0] + u[3])) * c.inv_iyy;   // quadrotor.py:668
         in.mz = c.gamma * ((u[0] + u[2]) - (u[1] + u[3])) * c.inv_izz;    // quadrotor.py:669
@@ -96,8 +105,7 @@ __device__ __forceinline__ void f_eval(const PhysT<T>& c, const Inputs<SYS, T>& 
         d[5] = in.thdd;
     } else if constexpr (SYS == SCG_QUAD_3D) {
         T sph, cph, sth, cth, sps, cps;
-        Real<T>::sincos(x[6], sph, cph);
-        Real<T>::sincos(x[7], sth, cth);
+        Real<T>::sincos2(x[6], x[7], sph, cph, sth, cth);
         Real<T>::sincos(x[8], sps, cps);
         const T P = x[9], Q = x[10], R = x[11];
         // third column of R = Rz(psi) Ry(theta) Rx(phi)  (transformations.py:125-182)
@@ -132,10 +140,26 @@ __device__ __forceinline__ void f_eval(const PhysT<T>& c, const Inputs<SYS, T>& 
     }
 }
 
-// One fixed step; returns the increment (so the float path can add it with its own rounding).
-template <int SYS, class T>
+// Where the BASE state of an RK4 step lives while the stages run.  It is read-only from the second stage on (xt = x + c h k,
+// x_new = x + inc), so it need not occupy registers: the 3-D float kernels park it in LDS (12 VGPRs less across the stage
+// evaluations; LDS instructions issue beside the VALU ones), everything else reads the registers it arrived in.
+template <class T, int NX>
+struct BaseInRegs {
+    const T (&x)[NX];
+    __device__ __forceinline__ T operator()(int j) const { return x[j]; }
+};
+typedef __attribute__((address_space(3))) float lds_float;
+template <int STRIDE>
+struct BaseInLds {               // plane j of this lane at p[j * STRIDE] (conflict-free: consecutive lanes, consecutive dwords)
+    lds_float* p;
+    __device__ __forceinline__ float operator()(int j) const { return p[j * STRIDE]; }
+};
+
+// One fixed step; returns the increment (so the float path can add it with its own rounding).  `x` is the state the first
+// stage is evaluated at (registers); `xb` hands out the same values for the later stages and may read them from elsewhere.
+template <int SYS, class T, class XB>
 __device__ __forceinline__ void integrate(const PhysT<T>& c, uint32_t flags, const Inputs<SYS, T>& in,
-                                          const T (&x)[Dim<SYS>::NX], T (&inc)[Dim<SYS>::NX]) {
+                                          const T (&x)[Dim<SYS>::NX], const XB& xb, T (&inc)[Dim<SYS>::NX]) {
     constexpr int NX = Dim<SYS>::NX;
     const T h = c.h;
     T k[NX];
@@ -152,29 +176,46 @@ __device__ __forceinline__ void integrate(const PhysT<T>& c, uint32_t flags, con
     for (int j = 0; j < NX; ++j) { acc[j] = k[j]; xt[j] = fma_t(hh, k[j], x[j]); }
     f_eval<SYS, T>(c, in, xt, k);
 #pragma unroll
-    for (int j = 0; j < NX; ++j) { acc[j] = fma_t((T)2, k[j], acc[j]); xt[j] = fma_t(hh, k[j], x[j]); }
+    for (int j = 0; j < NX; ++j) { acc[j] = fma_t((T)2, k[j], acc[j]); xt[j] = fma_t(hh, k[j], xb(j)); }
     f_eval<SYS, T>(c, in, xt, k);
 #pragma unroll
-    for (int j = 0; j < NX; ++j) { acc[j] = fma_t((T)2, k[j], acc[j]); xt[j] = fma_t(h, k[j], x[j]); }
+    for (int j = 0; j < NX; ++j) { acc[j] = fma_t((T)2, k[j], acc[j]); xt[j] = fma_t(h, k[j], xb(j)); }
     f_eval<SYS, T>(c, in, xt, k);
     const T h6 = h * (T)(1.0 / 6.0);
 #pragma unroll
     for (int j = 0; j < NX; ++j) inc[j] = h6 * (acc[j] + k[j]);
+}
+template <int SYS, class T>
+__device__ __forceinline__ void integrate(const PhysT<T>& c, uint32_t flags, const Inputs<SYS, T>& in,
+                                          const T (&x)[Dim<SYS>::NX], T (&inc)[Dim<SYS>::NX]) {
+    integrate<SYS, T>(c, flags, in, x, BaseInRegs<T, Dim<SYS>::NX>{x}, inc);
 }
 
 // ---- mixed-precision step of the 3-D quadrotor ("attitude" precise mode) ---------------------------------------------
 // The open-loop drift of the float32 step is born in the rotational chain (torque -> rate -> attitude) and amplified by the
 // thrust direction; the translational chain only integrates it (tools/precise_mode_study.py: float32 positions and
 // velocities + float64 attitude and rates hold 2e-6 over 1000 open-loop steps, float32 everything 2e-1).  So: attitude and
-// rates (states 6..11) in double -- hi + lo float32 planes in memory --, positions and velocities (states 0..5) in float,
-// the acceleration  R(:, 2) T/m  evaluated in double from the double attitude and rounded once.
+// rates (states 6..11) ACCUMULATE in double -- hi + lo float32 planes in memory, RK4 combination in double --, positions and
+// velocities (states 0..5) in float.
+//
+// Which arithmetic has to be double was measured too (tools/precise_mode_study.py, "derivative" rows): what integrates into
+// the drift is a CONSTANT error, and the only place one is born is the cancellation of the thrusts in the torques
+// (u0 + u1 - u2 - u3 ...) and the products of the rate equations; random rounding errors of 6e-8 in the trigonometry and the
+// Euler-angle kinematics average out (2.9e-6 at 1000 steps against 1.8e-6 with everything in double).  Hence (default,
+// SCG_ATT_FP64_TRIG = 0): inputs (T/m, torques) and the body-rate derivatives in double; sin / cos of the float32-rounded
+// stage angles, the Euler-rate kinematics and the acceleration  R(:, 2) T/m  in float32 (the packed sincos of scg_math.h),
+// converted once.  SCG_ATT_FP64_TRIG = 1 is round 2's form (12 float64 sin/cos pairs per step: 624 fp64 instructions).
+#ifndef SCG_ATT_FP64_TRIG
+#define SCG_ATT_FP64_TRIG 0
+#endif
 __device__ __forceinline__ void f_mixed3d(const PhysT<double>& c, const Inputs<SCG_QUAD_3D, double>& in, const float (&xt)[6],
                                           const double (&xa)[6], float (&dt)[6], double (&da)[6]) {
+    const double P = xa[3], Q = xa[4], R = xa[5];
+#if SCG_ATT_FP64_TRIG
     double sph, cph, sth, cth, sps, cps;
     Real<double>::sincos(xa[0], sph, cph);
     Real<double>::sincos(xa[1], sth, cth);
     Real<double>::sincos(xa[2], sps, cps);
-    const double P = xa[3], Q = xa[4], R = xa[5];
     const double sthcph = sth * cph;
     dt[0] = xt[1];
     dt[1] = (float)fma(fma(cps, sthcph, sps * sph), in.Tm, in.ax);
@@ -187,6 +228,24 @@ __device__ __forceinline__ void f_mixed3d(const PhysT<double>& c, const Inputs<S
     da[0] = fma(sth * rcth, w, P);
     da[1] = fma(cph, Q, -(sph * R));
     da[2] = w * rcth;
+#else
+    float sph, cph, sth, cth, sps, cps;
+    sincos2_f((float)xa[0], (float)xa[1], sph, cph, sth, cth);
+    sincos_f((float)xa[2], sps, cps);
+    const float Tm = (float)in.Tm, Qf = (float)Q, Rf = (float)R;
+    const float sthcph = sth * cph;
+    dt[0] = xt[1];
+    dt[1] = fmaf(fmaf(cps, sthcph, sps * sph), Tm, (float)in.ax);
+    dt[2] = xt[3];
+    dt[3] = fmaf(fmaf(sps, sthcph, -(cps * sph)), Tm, (float)in.ay);
+    dt[4] = xt[5];
+    dt[5] = fmaf(cth * cph, Tm, (float)in.az);
+    const float rcth = rcp_f(cth);
+    const float w = fmaf(sph, Qf, cph * Rf);
+    da[0] = (double)(sth * rcth * w) + P;                 // the rate itself enters in double
+    da[1] = (double)fmaf(cph, Qf, -(sph * Rf));
+    da[2] = (double)(w * rcth);
+#endif
     da[3] = fma(-c.cxx, Q * R, in.mx);
     da[4] = fma(-c.cyy, R * P, in.my);
     da[5] = fma(-c.czz, P * Q, in.mz);

@@ -43,6 +43,11 @@ namespace scg {
 #define SCG_NUM_SGPR 0         // > 0: cap the step kernel's SGPR allocation (amdgpu_num_sgpr); <= 80 admits 8 workgroups per CU
 #endif
 constexpr int kBlock = SCG_BLOCK;
+#ifndef SCG_PARK_BASE
+#define SCG_PARK_BASE 1        // 3-D float kernels: the base state of an RK4 step waits in LDS while the stages run (BaseInLds)
+#endif
+// floats of dynamic LDS at the head of the workgroup's allocation that hold the parked base state (0: not parked)
+constexpr int park_floats(int system, int comp) { return (SCG_PARK_BASE && system == SCG_QUAD_3D && comp == 0) ? 12 * kBlock : 0; }
 #ifndef SCG_COMP_WAVES
 #define SCG_COMP_WAVES 1       // waves per SIMD the register allocator must allow in the precise-mode instantiations (1 = no demand)
 #endif
@@ -168,7 +173,7 @@ __device__ __forceinline__ float draw_distribution(int kind, float u, float u2, 
         case SCG_RAND_EXPONENTIAL: return -p[0] * logf(1.0f - u);       // 1 - u in (0, 1]
         case SCG_RAND_LAPLACE: {
             const float d = u - 0.5f, a = fmaxf(1.0f - 2.0f * fabsf(d), 5.9604644775390625e-8f);
-            return p[0] - copysignf(p[1] * logf(a), d);
+            return p[0] + copysignf(p[1] * logf(a), d);               // log(a) <= 0: below loc for u < 1/2, the monotone inverse CDF
         }
         case SCG_RAND_LOGISTIC: return fmaf(p[1], logf(uo / (1.0f - uo)), p[0]);
         case SCG_RAND_TRIANGULAR: {
@@ -502,13 +507,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Measured on MI355X at 2^20 envs: the LDS fill + barrier costs ~10% more than
 // the cached gathers it saves, so the gather is the default.
 template <int NX>
-__device__ __forceinline__ void load_goal(const KParams& p, const float* __restrict__ ref_glb, int row,
+__device__ __forceinline__ void load_goal(const KParams& p, const float* __restrict__ ref_glb, const float* s_tab, int row,
                                           float (&g)[NX]) {
-    extern __shared__ __align__(16) float s_ref[];
     row = min(max(row, 0), p.ref_rows - 1);
     if (p.flags & F_REF_IN_LDS) {
 #pragma unroll
-        for (int j = 0; j < NX; ++j) g[j] = s_ref[row * NX + j];
+        for (int j = 0; j < NX; ++j) g[j] = s_tab[row * NX + j];
     } else if (NX % 4 == 0) {
         const float4* src = reinterpret_cast<const float4*>(ref_glb + row * NX);
 #pragma unroll
@@ -636,13 +640,16 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
     static_assert(COMP != 2 || SYS == SCG_QUAD_3D, "the attitude-only residual planes are defined for the 3-D quadrotor");
     constexpr int NLO = COMP == 1 ? NX : (COMP == 2 ? 6 : 1);        // residual planes
     constexpr int LO0 = COMP == 2 ? NX - 6 : 0;                       // state dim of residual plane 0
-    extern __shared__ __align__(16) float s_ref[];
+    // dynamic LDS: [parked base state (3-D float kernels) | X_GOAL table (F_REF_IN_LDS) | reset scratch] -- step_geometry()
+    extern __shared__ __align__(16) float s_dyn[];
+    constexpr int PARK = park_floats(SYS, COMP);
+    float* const s_tab = s_dyn + PARK;
 
     const bool tracking = EXTRA ? ((p.flags & F_TRACKING) != 0) : ((FT & FT_TRACK) != 0);
     const bool has_con = EXTRA ? (p.n_con_rows > 0) : ((FT & FT_CON) != 0);
 
     // per-wave LDS scratch of the cooperative reset, placed after the (16-B padded) reference table
-    float* wg_scratch = s_ref + ((tracking && (p.flags & F_REF_IN_LDS)) ? (((p.ref_rows * NX + 3) >> 2) << 2) : 0);
+    float* wg_scratch = s_tab + ((tracking && (p.flags & F_REF_IN_LDS)) ? (((p.ref_rows * NX + 3) >> 2) << 2) : 0);
     float* coop_scratch = wg_scratch + (threadIdx.x >> 6) * kCoopFloats;      // per-wave form: aliases the pooled form's scratch
     const bool pooled_reset = SCG_WG_RESET && (SCG_WG_RESET_FUSED || MODE != MODE_FUSED) && (p.flags & F_AUTO_RESET) &&
                               (p.flags & F_RAND_INIT) && !(p.flags & F_RAND_GENERAL);
@@ -654,6 +661,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
     }
 
     const int64_t ld = io.ld;
+    const uint32_t serial_base = p.serial_base ? *p.serial_base : 0u;      // a launch replayed from a rollout graph (scalar load)
     float st_rew = 0.f, st_done = 0.f, st_viol = 0.f, st_fret = 0.f, st_flen = 0.f, st_trunc = 0.f;
 
     // Per-lane inputs of one env.  With SCG_PREFETCH the next grid-stride iteration's inputs are
@@ -710,7 +718,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         // stage X_GOAL (quadrotor.py:280-325) once per workgroup; rows*NX floats, 16-B vector copies
         const int total4 = (p.ref_rows * NX + 3) >> 2;                      // buffer is padded to 16 B
         const float4* src4 = reinterpret_cast<const float4*>(ref);
-        float4* dst4 = reinterpret_cast<float4*>(s_ref);
+        float4* dst4 = reinterpret_cast<float4*>(s_tab);
         for (int e = threadIdx.x; e < total4; e += kBlock) dst4[e] = src4[e];
         __syncthreads();
     }
@@ -722,7 +730,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         LaneIn nxt;
         if (STRIDED && SCG_PREFETCH && inext < n) load_lane(nxt, inext);
         const bool last = !FUSED || (kstep + 1 >= ro.steps);         // outputs are stored after the last fused step
-        const uint32_t serial = io.reset_serial + (FUSED ? (uint32_t)kstep : 0u);
+        const uint32_t serial = io.reset_serial + serial_base + (FUSED ? (uint32_t)kstep : 0u);
         // ---- this lane's inputs (NX+NU+1 independent 256-B wave transactions were issued together)
         float x[NX], a_raw[NU], xlo[NLO];
 #pragma unroll
@@ -767,6 +775,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         //      advance: _advance_simulation replaced by fixed-step integration of the prior model.
         //      RT = float, or double in the precise mode (state = hi + lo float32 planes, fp64 constants).
         float a_clip[NU];
+        float l_act = 0.f;
         auto advance = [&](auto tag, const auto& ph_shared) {
             using RT = decltype(tag);
             auto ph = ph_shared;
@@ -777,14 +786,26 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                 ph = phys_of_env<SYS, RT>(ph_shared, tb, prop);
             }
             RT u[NU];
+            // Three instructions per actuator.  The normalised action space is one FMA, th = act_mul a + act_add
+            // ((1 + scale a) hover_thrust, quadrotor.py:828, with the product of the two constants formed on the host;
+            // act_mul = 1, act_add = 0 otherwise: exact).  The motor round trip cmd2pwm -> clip(pwm) -> pwm2rpm -> KF rpm^2
+            // (quadrotor_utils.py:38-50,66; base_aviary.py:420) is a CLAMP OF THE THRUST: every link of it is increasing, so
+            // clipping the pwm to [pwm_min, pwm_max] is clipping the thrust to [n KF (scale pwm_min + const)^2, ... pwm_max ...]
+            // (th_min / th_max, formed in double on the host) and the identity in between -- which the literal sequence only
+            // approximates (a square root and a square: ~2e-7 of float32 rounding noise, 1e-16 in the float64 reference).  A
+            // negative or NaN thrust maps to th_min, as it does through max(th, 0) and the pwm clip.
+            const bool motor_map = SYS != SCG_CARTPOLE && (p.flags & F_MOTOR_MAP);      // wave-uniform, hoisted out of the loop
 #pragma unroll
             for (int j = 0; j < NU; ++j) {
                 float a = clampf(a_raw[j], tb->act_low[j], tb->act_high[j]);
-                if (p.flags & F_NORMALIZED) {                                    // (a wave-uniform branch in every tier)
-                    if (SYS == SCG_CARTPOLE) a *= p.action_scale;
-                    else a = fmaf(p.norm_act_scale, a, 1.0f) * p.hover_thrust;   // quadrotor.py:828
-                }
+                a = fmaf(p.act_mul, a, p.act_add);
                 a_clip[j] = a;                                                   // current_preprocessed_action (:833)
+                if (!EXTRA || (p.flags & F_Q_DIAG)) {
+                    // the action term of the cost (quadrotor.py:907-908 / :682), summed here so that one register instead of
+                    // nu crosses the integration
+                    const float ea = a - tb->u_goal[j];
+                    l_act = fmaf(tb->w_act[j] * ea, ea, l_act);
+                }
                 RT th = (RT)a;
                 if (sizeof(RT) == 8 && !(p.flags & F_NORMALIZED)) {
                     // the float32-typed bounds are exact in both precisions; clip in double all the same
@@ -793,14 +814,9 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                 }
                 if (EXTRA && io.action_disturbance) th += (RT)ldp(PL(io.action_disturbance, j), i4);   // :835-838
                 if (DIST) th += (RT)act_noise[j];
-                if (SYS != SCG_CARTPOLE && (p.flags & F_MOTOR_MAP)) {
-                    // cmd2pwm / pwm2rpm / KF rpm^2  (quadrotor_utils.py:38-50,66; base_aviary.py:420)
-                    RT pwm;
-                    if (sizeof(RT) == 8) pwm = (RT)((sqrt((double)(th > (RT)0 ? th : (RT)0) * (double)ph.inv_nmotor_kf) - (double)ph.pwm_const) * (double)ph.inv_pwm_scale);
-                    else pwm = (RT)((sqrt_f(fmaxf((float)th, 0.0f) * (float)ph.inv_nmotor_kf) - (float)ph.pwm_const) * (float)ph.inv_pwm_scale);
-                    pwm = pwm < ph.pwm_min ? ph.pwm_min : (pwm > ph.pwm_max ? ph.pwm_max : pwm);
-                    const RT rpm = fma_t(ph.pwm_scale, pwm, ph.pwm_const);
-                    th = ph.nmotor_kf * rpm * rpm;
+                if (motor_map) {
+                    if constexpr (sizeof(RT) == 8) th = th > ph.th_min ? (th < ph.th_max ? th : ph.th_max) : ph.th_min;   // (NaN -> th_min)
+                    else th = (RT)clampf((float)th, (float)ph.th_min, (float)ph.th_max);
                 }
                 u[j] = th;
             }
@@ -818,7 +834,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                     make_inputs<SYS, RT>(ph, u, efx, efy, efz, in);
                 }
             };
-            if (!aero) make_inputs<SYS, RT>(ph, u, efx, efy, efz, in);
+            if (!aero) make_inputs<SYS, RT, DIST>(ph, u, efx, efy, efz, in);     // forces exist from the disturbance tier on
             if constexpr (COMP == 2) {
                 // attitude precise mode: float translational chain, double rotational chain (no aero terms in this mode)
                 float xt[6];
@@ -865,9 +881,24 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                 for (int s = 0; s < p.substeps; ++s) {
                     RT inc[NX];
                     if (aero) substep_inputs(xs);
-                    integrate<SYS, RT>(ph, p.flags, in, xs, inc);
+                    if constexpr (PARK != 0 && sizeof(RT) == 4) {
+                        // the base state waits in LDS (plane j of this lane at [j][threadIdx.x]) from the second stage on.
+                        // The address is laundered so that the compiler cannot forward the stored registers to the loads
+                        // (which would keep the 12 values live -- the very thing this avoids).
+                        lds_float* park = (lds_float*)s_dyn + threadIdx.x;
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) xs[j] += inc[j];
+                        for (int j = 0; j < NX; ++j) park[j * kBlock] = (float)xs[j];
+                        uint32_t addr = (uint32_t)(uintptr_t)park;
+                        asm volatile("" : "+v"(addr));
+                        const BaseInLds<kBlock> xb{(lds_float*)(uintptr_t)addr};
+                        integrate<SYS, RT>(ph, p.flags, in, xs, xb, inc);
+#pragma unroll
+                        for (int j = 0; j < NX; ++j) xs[j] = (RT)xb(j) + inc[j];
+                    } else {
+                        integrate<SYS, RT>(ph, p.flags, in, xs, inc);
+#pragma unroll
+                        for (int j = 0; j < NX; ++j) xs[j] += inc[j];
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < NX; ++j) x[j] = (float)xs[j];
@@ -875,13 +906,14 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         };
         if constexpr (COMP != 0) advance(double{}, tb->phd);
         else advance(float{}, p.ph);
+        asm volatile("" : "+v"(l_act));            // keeps the action cost where it was computed (the compiler would sink it past the integration)
 
         // ---- error to the goal of this step: X_GOAL (stabilisation) or X_GOAL[min(t, T-1)]
         //      (quadrotor.py:905,1021; the quadratic cost's unclamped X_GOAL[t] (:926) is the same row
         //      because t < CTRL_STEPS <= rows)
         float e[NX];
         if (tracking) {
-            load_goal<NX>(p, ref, t, e);
+            load_goal<NX>(p, ref, s_tab, t, e);
 #pragma unroll
             for (int j = 0; j < NX; ++j) e[j] = x[j] - e[j];
         } else {
@@ -909,8 +941,11 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         if (p.flags & F_DONE_OOB) {
             bool inb = true;                                                // NaN compares false -> out of bounds
 #pragma unroll
-            for (int j = 0; j < NX; ++j)
-                if (!SCG_OOB_MASK || (p.oob_dims & (1u << j))) inb &= (x[j] >= tb->oob_low[j]) & (x[j] <= tb->oob_high[j]);   // wave-uniform skip
+            for (int j = 0; j < NX; ++j) {
+                if (SCG_OOB_MASK && !(p.oob_dims & (1u << j))) continue;                                     // wave-uniform skip
+                if (SCG_OOB_MASK && (p.oob_sym & (1u << j))) inb &= fabsf(x[j]) <= tb->oob_high[j];           // low == -high: one compare
+                else inb &= (x[j] >= tb->oob_low[j]) & (x[j] <= tb->oob_high[j]);
+            }
             done |= !inb;
         }
         if (INFO && io.goal_reached) stp(io.goal_reached, i, (uint8_t)(goal_reached ? 1 : 0));
@@ -918,17 +953,21 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         // ---- _get_reward (quadrotor.py:886-930)
         float rew;
         {
-            float ea[NU];
-#pragma unroll
-            for (int j = 0; j < NU; ++j) ea[j] = a_clip[j] - tb->u_goal[j];
             float l = 0.f;
             if (!EXTRA || (p.flags & F_Q_DIAG)) {
                 // rl_reward: sum w_s e^2 + sum w_a ea^2 (:902-908); quadratic with diagonal Q, R (:682)
+                l = l_act;
+                if (p.flags & F_W_STATE_UNIT) {                             // Q = I (the default cost): 1 * e is e
 #pragma unroll
-                for (int j = 0; j < NX; ++j) l = fmaf(tb->w_state[j] * e[j], e[j], l);
+                    for (int j = 0; j < NX; ++j) l = fmaf(e[j], e[j], l);
+                } else {
 #pragma unroll
-                for (int j = 0; j < NU; ++j) l = fmaf(tb->w_act[j] * ea[j], ea[j], l);
+                    for (int j = 0; j < NX; ++j) l = fmaf(tb->w_state[j] * e[j], e[j], l);
+                }
             } else {
+                float ea[NU];
+#pragma unroll
+                for (int j = 0; j < NU; ++j) ea[j] = a_clip[j] - tb->u_goal[j];
 #pragma unroll
                 for (int a = 0; a < NX; ++a) {
                     float tq = 0.f;
@@ -945,7 +984,10 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                 }
             }
             rew = p.cost_scale * l;                                         // -dist (:909) or -l/2 (:682,918-930)
-            if (!(p.flags & F_QUADRATIC) && (p.flags & F_REW_EXP)) rew = expf(rew);   // :911-912
+            if (!(p.flags & F_QUADRATIC) && (p.flags & F_REW_EXP)) {       // :911-912
+                asm volatile("" ::: "memory");                              // a real (wave-uniform) branch: ~14 instructions not worth speculating
+                rew = expf(rew);
+            }
         }
 
         // ---- after_step (benchmark_env.py:422-463)
@@ -1004,7 +1046,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                         if (tracking) {
                             for (int k = 0; k < p.obs_goal_horizon; ++k) {
                                 float g[NX];
-                                load_goal<NX>(p, ref, t + 1 + k, g);
+                                load_goal<NX>(p, ref, s_tab, t + 1 + k, g);
 #pragma unroll
                                 for (int j = 0; j < NX; ++j) rec[NX * (1 + k) + j] = g[j];
                             }
@@ -1093,7 +1135,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                     const int base = (done && (p.flags & F_AUTO_RESET)) ? 1 : t + 1;
                     for (int k = 0; k < p.obs_goal_horizon; ++k) {
                         float g[NX];
-                        load_goal<NX>(p, ref, base + k, g);
+                        load_goal<NX>(p, ref, s_tab, base + k, g);
 #pragma unroll
                         for (int j = 0; j < NX; ++j) stp(PL(io.obs, NX * (1 + k) + j), i4, g[j]);
                     }
@@ -1265,6 +1307,7 @@ __global__ __launch_bounds__(kBlock) void scg_constraints_kernel(const ConTable*
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+#ifndef SCG_NO_LAUNCHERS       // tools/dev_kernel.hip compiles single instantiations of the kernels above (ISA studies)
 static int nx_of(int system) {
     switch (system) {
         case SCG_QUAD_1D: return 2;
@@ -1274,11 +1317,11 @@ static int nx_of(int system) {
     }
 }
 
-LaunchGeom step_geometry(const KParams& p, int system, int64_t n, int num_cus) {
+LaunchGeom step_geometry(const KParams& p, int system, int comp, int64_t n, int num_cus) {
     LaunchGeom g;
     g.block = kBlock;
     int64_t blocks = (n + kBlock - 1) / kBlock;
-    g.lds_bytes = 0;
+    g.lds_bytes = park_floats(system, comp) * (int)sizeof(float);
     if ((p.flags & F_AUTO_RESET) && (p.flags & F_RAND_INIT))
         g.lds_bytes += ((kBlock / 64) * kCoopFloats > kWgResetFloats ? (kBlock / 64) * kCoopFloats : kWgResetFloats) *
                        (int)sizeof(float);                                  // reset scratch (pooled form / per-wave form)
@@ -1382,7 +1425,7 @@ static void launch_fused_sys(const KParams& p, const scg_step_io& io, const KTab
 hipError_t launch_rollout_fused(int system, const KParams& p, const scg_step_io& io, const KTables* tb,
                                 const ConTable* ct, const float* ref, int64_t n, int32_t steps, int64_t stride,
                                 int32_t period, int num_cus, hipStream_t s) {
-    const LaunchGeom g = step_geometry(p, system, n, num_cus);
+    const LaunchGeom g = step_geometry(p, system, 0, n, num_cus);
     const RolloutArgs ro{steps, period, stride};
     switch (system) {
         case SCG_QUAD_1D: launch_fused_sys<SCG_QUAD_1D>(p, io, tb, ct, ref, (uint32_t)n, ro, g.lds_bytes, s); break;
@@ -1396,7 +1439,7 @@ hipError_t launch_rollout_fused(int system, const KParams& p, const scg_step_io&
 
 hipError_t launch_step(int system, const KParams& p, const scg_step_io& io, const KTables* tb,
                        const ConTable* ct, const float* ref, int64_t n, int num_cus, hipStream_t s) {
-    const LaunchGeom g = step_geometry(p, system, n, num_cus);
+    const LaunchGeom g = step_geometry(p, system, io.state_lo ? (io.state_lo_kind == 1 ? 2 : 1) : 0, n, num_cus);
     bool ok = false;
     switch (system) {
         case SCG_QUAD_1D: ok = launch_step_sys<SCG_QUAD_1D>(g, p, io, tb, ct, ref, (uint32_t)n, num_cus, s); break;
@@ -1479,5 +1522,6 @@ hipError_t launch_model_eval(int system, const KParams& p, const KTables* tb, co
     }
     return hipGetLastError();
 }
+#endif  // SCG_NO_LAUNCHERS
 
 }  // namespace scg

@@ -180,6 +180,7 @@ __global__ __launch_bounds__(256) void scg_mean_std_apply_kernel(const float* __
             if (j == 0) state_out[2 * d] = u.count;
         }
     }
+    if (!y) return;                                             // RunningMeanStd.update(): the tracker moves, nothing is normalised
     const double inv = 1.0 / sqrt(var + epsilon);               // :131-133
     const float* src = uptr(x + (int64_t)j * ld_x);
     float* dst = uptr(y + (int64_t)j * ld_y);
@@ -267,7 +268,7 @@ hipError_t launch_mean_std_normalize(const float* x, float* y, int d, int64_t ld
         if (vec) hipLaunchKernelGGL(scg_moments_kernel<true>, grid, block, 0, s, x, ld_x, (uint32_t)n, state_in, d, partials);
         else hipLaunchKernelGGL(scg_moments_kernel<false>, grid, block, 0, s, x, ld_x, (uint32_t)n, state_in, d, partials);
     }
-    const dim3 grid(apply_blocks(n, d), (unsigned)d), block(256);
+    const dim3 grid(y ? apply_blocks(n, d) : 1u, (unsigned)d), block(256);      // y == null: one workgroup per dim writes state_out
     const bool vec2 = ((reinterpret_cast<uintptr_t>(x) | (uintptr_t)(ld_x * 4) | reinterpret_cast<uintptr_t>(y) |
                         (uintptr_t)(ld_y * 4)) & 15u) == 0;
     if (vec2) hipLaunchKernelGGL(scg_mean_std_apply_kernel<true>, grid, block, 0, s, x, y, ld_x, ld_y, (uint32_t)n, d,

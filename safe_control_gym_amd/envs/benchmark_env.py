@@ -112,7 +112,7 @@ class BenchmarkEnv:
                  # ---- batched-engine arguments (new) ----
                  num_envs=1, device='cuda', physics='rk4', integration_substeps=1, motor_map=True,
                  auto_reset=True, info_level='full', compensated_state=False, track_episode_stats=True,
-                 env_index_base=0, rollout_queues=None, rollout_split_min=None, ref_in_lds=None, grid_cap_per_cu=None,
+                 env_index_base=0, rollout_queues=None, rollout_split_min=None, ref_in_lds=None, grid_cap_per_cu=None, rollout_graph=None,
                  plane_pad=None, copy_outputs=None,
                  **kwargs):
         self.id = self.__class__._count
@@ -181,6 +181,7 @@ class BenchmarkEnv:
         self.ROLLOUT_SPLIT_MIN = _knob(rollout_split_min, 'SCG_ROLLOUT_SPLIT_MIN', 0)
         self.REF_IN_LDS = _knob(ref_in_lds, 'SCG_REF_IN_LDS', 0)
         self.GRID_CAP_PER_CU = _knob(grid_cap_per_cu, 'SCG_GRID_CAP_PER_CU', 0)
+        self.ROLLOUT_GRAPH = _knob(rollout_graph, 'SCG_ROLLOUT_GRAPH', 0)           # 0 / 1: hipGraph replay of small-batch rollouts; -1 off
         self.PLANE_PAD = _knob(plane_pad, 'SCG_LD_PAD', 17)                         # units of 64 lanes (256 B)
         # initial state / randomisation
         self.INIT_STATE = init_state
@@ -403,6 +404,7 @@ class BenchmarkEnv:
         cfg.rollout_split_min = self.ROLLOUT_SPLIT_MIN
         cfg.ref_in_lds = self.REF_IN_LDS
         cfg.grid_cap_per_cu = self.GRID_CAP_PER_CU
+        cfg.rollout_graph = self.ROLLOUT_GRAPH
         self._fill_system_config(cfg)
         return Engine(cfg, x_goal_table=self._x_goal_table(), constraint_list=constraint_list, device=self.device,
                       disturbances=[e for mode, dl in self.disturbances.items() for e in dl.compile(mode)])
@@ -778,16 +780,22 @@ class BenchmarkEnv:
         return src[:, :self.num_envs].T
 
     def _own_state(self):
-        """Ping-pong mode: the current state buffer is the observation the last ``step()`` / ``reset()`` handed out.  Whoever
-        is about to write the state IN PLACE (reset, rollout, load_state_dict) first gives the engine a private copy."""
-        if not self._pingpong:
+        """Fresh-output mode (``copy_outputs=True``): whoever is about to write the engine's buffers IN PLACE (reset, rollout,
+        load_state_dict) first gives the engine private copies of everything the last ``step()`` / ``reset()`` handed out --
+        the state buffer in ping-pong mode (it IS the last observation), a kernel-written observation buffer (observation
+        disturbance), and the reward / done tensors -- so that a tensor, once returned, is never written again."""
+        if not self._fresh_outputs:
             return
         b = self._bufs
-        if 'obs' in b:
+        if self._pingpong:
+            if 'obs' in b:
+                b['obs'] = b['obs'].clone()
+                b['state'] = b['obs'][:self.state_dim]
+            else:
+                b['state'] = b['state'].clone()
+        elif 'obs' in b:
             b['obs'] = b['obs'].clone()
-            b['state'] = b['obs'][:self.state_dim]
-        else:
-            b['state'] = b['state'].clone()
+        b['reward'], b['done'] = b['reward'].clone(), b['done'].clone()
         self._bound = False
 
     def reset(self, mask=None):

@@ -197,6 +197,12 @@ class Engine:
                         'scg_quadratic_loss')
         return l, l_x, l_u
 
+    def rollout_graph_info(self):
+        """(signatures held as instantiated hipGraphs [-1: capture failed, plain launches], graph launches so far)."""
+        c, r = C.c_int32(), C.c_int64()
+        _capi.check(self.lib.scg_rollout_graph_info(self.handle, C.byref(c), C.byref(r)), 'scg_rollout_graph_info')
+        return c.value, r.value
+
     def kernel_info(self, n):
         b, g, l = C.c_int32(), C.c_int32(), C.c_int32()
         _capi.check(self.lib.scg_kernel_info(self.handle, C.byref(b), C.byref(g), C.byref(l), n), 'scg_kernel_info')

@@ -62,25 +62,34 @@ class RunningMeanStd:
         return cur, nxt
 
     def update(self, arr):
-        """normalization.py:34-46 on a device batch [N, *shape]: the moments kernel of the normalisers, without their output."""
-        x = torch.as_tensor(arr, device=self.device, dtype=torch.float32).reshape(-1, self.d)
+        """normalization.py:34-46 on a device batch [N, *shape]: the moments pass of the normalisers alone (``y == NULL``:
+        no scratch output, no apply pass).  An [N, d] view of SoA planes (``env.step()``'s obs) is read in place."""
+        x = torch.as_tensor(arr, device=self.device)
+        if x.dtype != torch.float32:
+            x = x.to(torch.float32)
+        x = x.reshape(-1, self.d)
         n = x.shape[0]
         if n == 0:
             return
-        planes = x.T.contiguous()                                         # [d, n] SoA planes
-        scratch = torch.empty_like(planes)
+        if x.stride(0) == 1 and (self.d == 1 or x.stride(1) >= n):
+            planes, ld = x, (x.stride(1) if self.d > 1 else n)             # already [d][ld] planes underneath: zero copy
+        else:
+            planes, ld = x.T.contiguous(), n                                # [d, n] SoA planes
         state_in, state_out = self._records(True)
         lib = _capi.load()
         with torch.cuda.device(self.device):
-            _capi.check(lib.scg_mean_std_normalize(planes.data_ptr(), scratch.data_ptr(), self.d, n, n, n, state_in.data_ptr(),
+            _capi.check(lib.scg_mean_std_normalize(planes.data_ptr(), 0, self.d, ld, 0, n, state_in.data_ptr(),
                                                    state_out.data_ptr(), self._moments.data_ptr(), 0.0, 0.0,
                                                    _capi.current_stream(self.device)), 'scg_mean_std_normalize')
 
     def update_from_moments(self, batch_mean, batch_var, batch_count):
-        """normalization.py:48-62 (Chan's parallel update), float64 on the device record."""
-        as64 = lambda v: torch.as_tensor(np.asarray(v.detach().cpu() if isinstance(v, torch.Tensor) else v, dtype=np.float64).reshape(-1),
-                                         device=self.device)
-        bm, bv, bc = as64(batch_mean), as64(batch_var), float(batch_count)
+        """normalization.py:48-62 (Chan's parallel update), float64 on the device record; device tensors stay on the device."""
+        def as64(v):
+            if isinstance(v, torch.Tensor):
+                return v.detach().to(device=self.device, dtype=torch.float64).reshape(-1)
+            return torch.as_tensor(np.asarray(v, dtype=np.float64).reshape(-1), device=self.device)
+        bm, bv = as64(batch_mean), as64(batch_var)
+        bc = batch_count.detach().to(device=self.device, dtype=torch.float64) if isinstance(batch_count, torch.Tensor) else float(batch_count)
         cur, nxt = self._records(True)
         mean, var, count = cur[:self.d], cur[self.d:2 * self.d], cur[2 * self.d]
         delta = bm - mean

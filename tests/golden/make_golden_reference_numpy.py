@@ -556,6 +556,77 @@ def gen_step_glue(rng):
              'TimeLimit.truncated (-1: key absent).  counter = ctrl_step_counter before after_step increments it.')
 
 
+# ---- step glue on states the engine can reach ------------------------------------------------------------------------
+def gen_step_glue_device(rng):
+    """The same executed reference methods as gen_step_glue, but the state handed to them is one control step of the prior
+    model away from a stored (x0, action): x = rk4(x0, thrust(action)) with the oracle's float64 RK4 and the thrusts the
+    REFERENCE's before_step / _preprocess_control produced (rpm -> KF rpm^2).  A device test can therefore start the HIP env at
+    x0, step it with the action and compare reward / done / truncation / violation / constraint values / observation with
+    what the reference's own _get_done / _get_reward / after_step say about that step -- a direct pin of the fused kernel's
+    glue instead of a transitive one.  Samples within 1e-3 of any decision boundary (out-of-bound box, constraint rows and their
+    tolerances, time limit is exact) are rejected, so that a 1e-6 difference of the state cannot flip a recorded flag."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import ref_model as rm
+    dt = 1.0 / 60
+    for c in GLUE_CASES:
+        h = glue_env(c)
+        nx, nu = h.state_dim, h.action_dim
+        f = rm.F_BY_SYSTEM[c['quad_type']]
+        params = rm.QuadParams()
+        rec = {k: [] for k in ('state0', 'action', 'counter', 'state', 'obs', 'mse', 'rew', 'done', 'violation', 'truncated', 'cvals',
+                               'goal_reached')}
+        tracking = h.TASK == NS['Task'].TRAJ_TRACKING
+        lo, hi = h.state_space.low.astype(float), h.state_space.high.astype(float)
+        kept = tries = 0
+        while kept < 32:
+            tries += 1
+            assert tries < 4000, c['name']
+            counter = int(rng.choice([0, 1, 7, 150, 297, 298, 299])) if kept % 3 else int(rng.integers(0, 299))
+            goal = h.X_GOAL[min(counter, h.X_GOAL.shape[0] - 1)] if tracking else h.X_GOAL
+            spread = [0.02, 0.3, 1.5][kept % 3]
+            x0 = (goal + spread * rng.normal(size=nx)).astype(np.float32).astype(float)      # what the device will hold
+            al, ah = h.action_space.low.astype(float), h.action_space.high.astype(float)
+            a = rng.uniform(al - 0.4 * (ah - al), ah + 0.4 * (ah - al)).astype(np.float32).astype(float)
+            h.ctrl_step_counter, h.pyb_step_counter = counter, 4 * counter
+            rpm = h.before_step(a.copy())
+            kf = CF['KF'] * np.asarray(rpm, dtype=float) ** 2                                # base_aviary.py:420, per motor
+            thrust = [kf.sum()] if nu == 1 else ([kf[0] + kf[3], kf[1] + kf[2]] if nu == 2 else list(kf))
+            x = np.array(rm.rk4_step(f, list(x0), thrust, params, dt))
+            if not np.all(np.isfinite(x)) or np.any(np.abs(x - lo) < 1e-3) or np.any(np.abs(x - hi) < 1e-3):
+                continue
+            if c['quad_type'] == 3 and abs(x[7]) > 1.3:                                      # the Euler-rate matrix is ill-conditioned there
+                continue
+            h.state = x.copy()
+            obs = h.extend_obs(deepcopy(h.state), h.ctrl_step_counter + 1)
+            info = h.info_mse_part()
+            done = h._get_done()
+            goal_reached = bool(getattr(h, 'goal_reached', False))
+            if c['cost'] == 'quadratic' and not tracking and abs(np.linalg.norm(x - goal) - h.TASK_INFO['stabilization_goal_tolerance']) < 1e-3:
+                continue
+            rew = h._get_reward() if h.COST == NS['Cost'].RL_REWARD else float('nan')
+            obs2, rew2, done2, info2 = h.after_step(obs, rew if rew == rew else 0.0, done, dict(info))
+            cv = np.asarray(info2.get('constraint_values', np.zeros(0)), dtype=float)
+            if cv.size and (np.any(np.abs(cv) < 1e-3) or
+                            (h.use_constraint_penalty and np.any(np.abs(cv + np.concatenate([np.atleast_1d(con.tolerance if con.tolerance is not None else np.full(con.num_constraints, np.inf))
+                                                                                     for con in h.constraints.constraints])) < 1e-3))):
+                continue
+            rec['state0'].append(x0); rec['action'].append(a); rec['counter'].append(counter); rec['state'].append(x)
+            rec['obs'].append(obs2); rec['mse'].append(info['mse']); rec['goal_reached'].append(goal_reached)
+            rec['rew'].append(rew2 if rew == rew else float('nan')); rec['done'].append(done2)
+            rec['violation'].append(info2.get('constraint_violation', -1))
+            rec['truncated'].append({True: 1, False: 0}.get(info2.get('TimeLimit.truncated'), -1))
+            rec['cvals'].append(cv)
+            kept += 1
+        for k, v in rec.items():
+            put('step_glue_device/%s/%s' % (c['name'], k), v)
+    MANIFEST['groups']['step_glue_device'] = dict(
+        cases=GLUE_CASES, dt=dt,
+        note='per sample: state0, action (both float32-representable), counter; state = oracle float64 RK4 step of state0 under the '
+             'thrusts KF rpm^2 of the reference-executed before_step(action) (the one ingredient that is not the reference: the '
+             'dynamics are CasADi, parity unpinned); then the reference-executed extend_obs / mse statements / _get_done / '
+             '_get_reward (rl) / after_step on that state, as in step_glue.  Samples within 1e-3 of a decision boundary were rejected.')
+
+
 # ---- GAE and normalisers ---------------------------------------------------------------------------------------------
 def gen_gae(rng):
     cases = []
@@ -734,6 +805,7 @@ def main():
     gen_x_goal()
     gen_constraints(rng)
     gen_step_glue(rng)
+    gen_step_glue_device(np.random.default_rng(20261004))      # its own stream: the earlier groups keep their recorded values
     gen_gae(rng)
     gen_normalization(rng)
     gen_discretize(rng)        # (appended: earlier groups keep the random stream they were first written with)

@@ -233,6 +233,78 @@ static void check_step_and_rollout() {
     EXPECT(scg_destroy(h) == SCG_OK);
 }
 
+// hipGraph replay of small-batch rollouts: first sighting plain, second captured + replayed, later ones replayed; every way a
+// capture can fail ends the capture, destroys what was built and falls back to plain launches.
+static void check_rollout_graphs() {
+    scg_config c = base_config(SCG_QUAD_2D);
+    scg_handle* h = nullptr;
+    const int64_t n = 4096;
+    Buffers b(n), b2(n);
+    EXPECT(scg_create(&c, &h) == SCG_OK);
+    shim_reset();
+    b.io.reset_serial = 100;
+    EXPECT(scg_rollout(h, &b.io, n, 16, 16, 2, nullptr) == SCG_OK);                       // first sighting
+    EXPECT(g_shim.step_launches_main == 16 && g_shim.graph_launches == 0 && g_shim.captured_nodes == 0);
+    b.io.reset_serial = 116;
+    EXPECT(scg_rollout(h, &b.io, n, 16, 16, 2, nullptr) == SCG_OK);                       // second: captured, replayed
+    EXPECT(g_shim.step_launches_main == 16 && g_shim.captured_nodes == 16 && g_shim.graph_launches == 1 && g_shim.graph_nodes_replayed == 16);
+    EXPECT(g_shim.captures_open == 0 && g_shim.graphs_live == 0 && g_shim.execs_live == 1 && g_shim.aux_streams_open == 0);
+    EXPECT(g_shim.last_serial == 116 && g_shim.serial_memsets == 1);
+    b.io.reset_serial = 132;
+    EXPECT(scg_rollout(h, &b.io, n, 16, 16, 2, nullptr) == SCG_OK);                       // third: replay only
+    EXPECT(g_shim.captured_nodes == 16 && g_shim.graph_launches == 2 && g_shim.last_serial == 132 && g_shim.aux_streams_open == 0);
+    // a different signature (steps) starts over; the first one is still cached
+    EXPECT(scg_rollout(h, &b.io, n, 12, 16, 2, nullptr) == SCG_OK && g_shim.graph_launches == 2);
+    EXPECT(scg_rollout(h, &b.io, n, 12, 16, 2, nullptr) == SCG_OK && g_shim.graph_launches == 3 && g_shim.execs_live == 2);
+    EXPECT(scg_rollout(h, &b.io, n, 16, 16, 2, nullptr) == SCG_OK && g_shim.graph_launches == 4 && g_shim.execs_live == 2);
+    // at most 4 signatures are kept
+    for (int steps = 20; steps < 26; ++steps) {
+        EXPECT(scg_rollout(h, &b.io, n, steps, 16, 2, nullptr) == SCG_OK);
+        EXPECT(scg_rollout(h, &b.io, n, steps, 16, 2, nullptr) == SCG_OK);
+    }
+    EXPECT(g_shim.execs_live == 4 && g_shim.captures_open == 0 && g_shim.graphs_live == 0);
+    // another buffer set is another signature
+    const int64_t before = g_shim.graph_launches;
+    EXPECT(scg_rollout(h, &b2.io, n, 25, 16, 2, nullptr) == SCG_OK && g_shim.graph_launches == before);
+    // short rollouts and a caller that is capturing itself are never graphed
+    EXPECT(scg_rollout(h, &b.io, n, 7, 16, 2, nullptr) == SCG_OK && scg_rollout(h, &b.io, n, 7, 16, 2, nullptr) == SCG_OK && g_shim.graph_launches == before);
+    g_shim.caller_stream_capturing = 1;
+    EXPECT(scg_rollout(h, &b.io, n, 25, 16, 2, nullptr) == SCG_OK && g_shim.graph_launches == before);
+    g_shim.caller_stream_capturing = 0;
+    // whatever re-points the handle's tables drops the graphs
+    EXPECT(scg_set_constraints(h, nullptr, 0, nullptr, 0) == SCG_OK && g_shim.execs_live == 0);
+    EXPECT(scg_destroy(h) == SCG_OK);
+
+    // capture failures: (a) a launch fails inside the capture, (b) instantiation fails, (c) the capture cannot begin
+    for (int mode = 0; mode < 3; ++mode) {
+        EXPECT(scg_create(&c, &h) == SCG_OK);
+        shim_reset();
+        EXPECT(scg_rollout(h, &b.io, n, 16, 16, 2, nullptr) == SCG_OK && g_shim.step_launches_main == 16);
+        if (mode == 0) g_shim.fail_launch_after = 16 + 5;                                 // the 6th captured launch fails
+        if (mode == 1) g_shim.fail_instantiate = 1;
+        if (mode == 2) g_shim.fail_begin_capture = 1;
+        const int rc = scg_rollout(h, &b.io, n, 16, 16, 2, nullptr);
+        EXPECT(g_shim.captures_open == 0 && g_shim.graphs_live == 0 && g_shim.execs_live == 0 && g_shim.aux_streams_open == 0);
+        EXPECT(g_shim.graph_launches == 0);
+        if (mode == 0) EXPECT(rc == SCG_ERR_HIP);                                         // the fallback's plain launches hit the same injected failure
+        else EXPECT(rc == SCG_OK && g_shim.step_launches_main == 32);                     // fallback: plain launches
+        g_shim.fail_launch_after = -1; g_shim.fail_instantiate = 0; g_shim.fail_begin_capture = 0;
+        const int64_t plain = g_shim.step_launches_main;
+        EXPECT(scg_rollout(h, &b.io, n, 16, 16, 2, nullptr) == SCG_OK && scg_rollout(h, &b.io, n, 16, 16, 2, nullptr) == SCG_OK);
+        EXPECT(g_shim.step_launches_main == plain + 32 && g_shim.graph_launches == 0);    // the handle stays on plain launches
+        EXPECT(scg_destroy(h) == SCG_OK);
+    }
+    // switched off in the configuration
+    c.rollout_graph = -1;
+    EXPECT(scg_create(&c, &h) == SCG_OK);
+    shim_reset();
+    EXPECT(scg_rollout(h, &b.io, n, 16, 16, 2, nullptr) == SCG_OK && scg_rollout(h, &b.io, n, 16, 16, 2, nullptr) == SCG_OK);
+    EXPECT(g_shim.step_launches_main == 32 && g_shim.graph_launches == 0 && g_shim.captured_nodes == 0);
+    EXPECT(scg_destroy(h) == SCG_OK);
+    { scg_config d = c; d.rollout_graph = 2; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    EXPECT(g_shim.execs_live == 0 && g_shim.graphs_live == 0);
+}
+
 static void check_next_row_entry_points() {
     std::vector<float> f(64);
     std::vector<double> d(64);
@@ -274,6 +346,7 @@ int main() {
     check_create_validation();
     for (int system = SCG_QUAD_1D; system <= SCG_CARTPOLE; ++system) check_tables(system);
     check_step_and_rollout();
+    check_rollout_graphs();
     check_next_row_entry_points();
     EXPECT(g_shim.live_allocations == 0);
     std::printf(g_fail ? "capi sanitize driver: %d expectation(s) FAILED\n" : "capi sanitize driver: ok\n", g_fail);

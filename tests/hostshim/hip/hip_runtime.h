@@ -16,11 +16,11 @@
 #define __forceinline__ inline
 
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorLaunchFailure = 719 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorLaunchFailure = 719, hipErrorUnknown = 999 };
 enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2 };
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 
-struct ihipStream_t { int id; int pending; };
+struct ihipStream_t { int id; int pending; int capturing; int captured_nodes; };
 struct ihipEvent_t { int id; ihipStream_t* recorded_on; };
 typedef ihipStream_t* hipStream_t;
 typedef ihipEvent_t* hipEvent_t;
@@ -31,6 +31,8 @@ const char* hipGetErrorString(hipError_t e);
 hipError_t hipGetLastError(void);
 hipError_t hipGetDevice(int* dev);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int dev);
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+hipError_t hipDeviceGetAttribute(int* value, hipDeviceAttribute_t attr, int dev);
 hipError_t hipMalloc(void** p, size_t bytes);
 hipError_t hipFree(void* p);
 hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
@@ -42,5 +44,22 @@ hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
+
+// stream capture / graphs (scg_rollout's replay of small-batch rollouts): a graph is a node count
+struct ihipGraph_t { int nodes; };
+struct ihipGraphExec_t { int nodes; };
+typedef ihipGraph_t* hipGraph_t;
+typedef ihipGraphExec_t* hipGraphExec_t;
+typedef void* hipDeviceptr_t;
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1 };
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1 };
+hipError_t hipStreamIsCapturing(hipStream_t s, hipStreamCaptureStatus* status);
+hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode mode);
+hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* graph);
+hipError_t hipGraphInstantiate(hipGraphExec_t* exec, hipGraph_t graph, void* error_node, char* log, size_t log_size);
+hipError_t hipGraphDestroy(hipGraph_t graph);
+hipError_t hipGraphExecDestroy(hipGraphExec_t exec);
+hipError_t hipGraphLaunch(hipGraphExec_t exec, hipStream_t s);
+hipError_t hipMemsetD32Async(hipDeviceptr_t dst, int value, size_t count, hipStream_t s);
 
 template <class T> hipError_t hipMalloc(T** p, size_t bytes) { return hipMalloc(reinterpret_cast<void**>(p), bytes); }

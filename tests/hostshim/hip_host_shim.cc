@@ -18,11 +18,47 @@ const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success"
 hipError_t hipGetLastError(void) { hipError_t e = g_last; g_last = hipSuccess; return e; }
 hipError_t hipGetDevice(int* dev) { *dev = 0; return hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 256; p->sharedMemPerBlock = 65536; return hipSuccess; }
+hipError_t hipDeviceGetAttribute(int* value, hipDeviceAttribute_t, int) { *value = 256; return hipSuccess; }
 hipError_t hipMalloc(void** p, size_t bytes) { *p = std::malloc(bytes ? bytes : 1); if (!*p) return hipErrorOutOfMemory; ++g_shim.live_allocations; return hipSuccess; }
 hipError_t hipFree(void* p) { if (p) { std::free(p); --g_shim.live_allocations; } return hipSuccess; }
 hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind) { std::memcpy(dst, src, bytes); return hipSuccess; }
 hipError_t hipMemset(void* dst, int value, size_t bytes) { std::memset(dst, value, bytes); return hipSuccess; }
-hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new ihipStream_t{g_next_id++, 0}; return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new ihipStream_t{g_next_id++, 0, 0, 0}; return hipSuccess; }
+hipError_t hipStreamIsCapturing(hipStream_t s, hipStreamCaptureStatus* status) {
+    *status = (s ? s->capturing : g_shim.caller_stream_capturing) ? hipStreamCaptureStatusActive : hipStreamCaptureStatusNone;
+    return hipSuccess;
+}
+hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode) {
+    if (!s || g_shim.fail_begin_capture) return hipErrorInvalidValue;      // the legacy default stream cannot be captured
+    s->capturing = 1; s->captured_nodes = 0; ++g_shim.captures_open;
+    return hipSuccess;
+}
+hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* graph) {
+    *graph = nullptr;
+    if (!s || !s->capturing) return hipErrorInvalidValue;
+    s->capturing = 0; --g_shim.captures_open;
+    *graph = new ihipGraph_t{s->captured_nodes}; ++g_shim.graphs_live;
+    return hipSuccess;
+}
+hipError_t hipGraphInstantiate(hipGraphExec_t* exec, hipGraph_t graph, void*, char*, size_t) {
+    *exec = nullptr;
+    if (g_shim.fail_instantiate) return hipErrorOutOfMemory;
+    *exec = new ihipGraphExec_t{graph->nodes}; ++g_shim.execs_live;
+    return hipSuccess;
+}
+hipError_t hipGraphDestroy(hipGraph_t graph) { delete graph; --g_shim.graphs_live; return hipSuccess; }
+hipError_t hipGraphExecDestroy(hipGraphExec_t exec) { delete exec; --g_shim.execs_live; return hipSuccess; }
+hipError_t hipGraphLaunch(hipGraphExec_t exec, hipStream_t s) {
+    ++g_shim.graph_launches; g_shim.graph_nodes_replayed += exec->nodes;
+    if (s && !s->pending) { s->pending = 1; ++g_shim.aux_streams_open; }
+    return hipSuccess;
+}
+hipError_t hipMemsetD32Async(hipDeviceptr_t dst, int value, size_t count, hipStream_t s) {
+    for (size_t q = 0; q < count; ++q) static_cast<int*>(dst)[q] = value;
+    ++g_shim.serial_memsets; g_shim.last_serial = (uint32_t)value;
+    if (s && !s->pending) { s->pending = 1; ++g_shim.aux_streams_open; }
+    return hipSuccess;
+}
 hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t s) { ++g_shim.stream_syncs; if (s && s->pending) { s->pending = 0; --g_shim.aux_streams_open; } return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new ihipEvent_t{g_next_id++, nullptr}; return hipSuccess; }
@@ -41,13 +77,14 @@ hipError_t hipStreamWaitEvent(hipStream_t waiter, hipEvent_t e, unsigned) {
 }
 
 namespace scg {
-LaunchGeom step_geometry(const KParams& p, int, int64_t n, int num_cus) {
+LaunchGeom step_geometry(const KParams& p, int, int, int64_t n, int num_cus) {
     LaunchGeom g; g.block = 256; int64_t b = (n + 255) / 256;
     if (p.grid_cap_per_cu > 0 && b > (int64_t)num_cus * p.grid_cap_per_cu) b = (int64_t)num_cus * p.grid_cap_per_cu;
     g.grid = (int32_t)(b < 1 ? 1 : b); g.lds_bytes = 0; return g;
 }
 hipError_t launch_step(int, const KParams& p, const scg_step_io&, const KTables*, const ConTable*, const float*, int64_t n, int, hipStream_t s) {
-    if (g_shim.fail_launch_after >= 0 && g_shim.step_launches_main + g_shim.step_launches_aux >= g_shim.fail_launch_after) return hipErrorLaunchFailure;
+    if (g_shim.fail_launch_after >= 0 && g_shim.step_launches_main + g_shim.step_launches_aux + g_shim.captured_nodes >= g_shim.fail_launch_after) return hipErrorLaunchFailure;
+    if (s && s->capturing) { ++s->captured_nodes; ++g_shim.captured_nodes; g_shim.last_n = n; return hipSuccess; }   // recorded, not executed
     ++g_shim.launches; g_shim.last_n = n; g_shim.last_env_base = p.env_base;
     if (s) { ++g_shim.step_launches_aux; if (!s->pending) { s->pending = 1; ++g_shim.aux_streams_open; } } else ++g_shim.step_launches_main;
     return hipSuccess;

@@ -11,6 +11,14 @@ struct ShimState {
     int aux_streams_open;           // work recorded on an aux stream that has not been joined (waited on / synchronised)
     int64_t last_n;                 // n of the last launch_step
     int64_t last_env_base;
+    // stream capture / graphs
+    int captures_open;              // hipStreamBeginCapture - hipStreamEndCapture: must be 0 whenever the layer returns
+    int graphs_live, execs_live;    // hipGraph_t / hipGraphExec_t objects alive
+    int64_t captured_nodes;         // launch_step calls recorded into a capture (not executed)
+    int64_t graph_launches, graph_nodes_replayed, serial_memsets;
+    int64_t last_serial;            // value of the last hipMemsetD32Async
+    int fail_begin_capture, fail_instantiate;       // != 0: that call fails
+    int caller_stream_capturing;    // != 0: hipStreamIsCapturing(null stream) reports an active capture
 };
 extern ShimState g_shim;
 void shim_reset(void);

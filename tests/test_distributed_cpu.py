@@ -104,7 +104,7 @@ def test_bench_dispatch_decision():
     import ast
     tree = ast.parse(open(BENCH).read())
     parent_path = [n for n in tree.body if not isinstance(n, (ast.FunctionDef, ast.ClassDef))]
-    parent_path += [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ('parse_args', '_free_port', 'must_spawn', 'spawn_ranks')]
+    parent_path += [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ('parse_args', '_free_port', 'must_spawn', 'spawn_ranks', 'rank_environment', 'rank_layout', '_relay_stderr')]
     assert any(isinstance(n, ast.FunctionDef) and n.name == 'spawn_ranks' for n in parent_path)
     for top in parent_path:
         for node in ast.walk(top):
@@ -127,6 +127,33 @@ def test_bench_spawns_its_own_ranks_and_relays_rank0_line(world):
     j = json.loads(lines[0])
     assert j['dry_run'] is True and j['n_gpus'] == world and j['ranks_seen'] == world and j['backend'] == 'gloo'
     assert j['gather_ok'] is True and j['steps'] == 20 and j['warmup'] == 5
+    # every rank would compute on device LOCAL_RANK = rank and own the envs [rank n, (rank + 1) n) -- the same rank_layout()
+    # the real run feeds to torch.cuda.set_device / make(env_index_base=...)
+    n = 1 << 20
+    lay = sorted(j['rank_layout'], key=lambda d: d['rank'])
+    assert [d['rank'] for d in lay] == list(range(world))
+    for r, d in enumerate(lay):
+        assert d['device_index'] == r and d['local_rank_env'] == str(r) and d['env_index_base'] == r * n and d['envs'] == n
+        assert d['ipc_mode_legacy'] == os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+
+def test_bench_launcher_environment_and_stderr_relay():
+    """The launcher sets exactly the five rendezvous variables, defaults HSA_ENABLE_IPC_MODE_LEGACY to 0 only when the caller
+    has not set it (the platform's dmabuf-IPC note) and passes everything else through; a rank's stderr comes back with a
+    rank prefix."""
+    sys.path.insert(0, ROOT)
+    import bench
+    base = {'PATH': '/usr/bin', 'FOO': 'bar'}
+    e = bench.rank_environment(base, 3, 8, 4242)
+    assert {k: v for k, v in e.items() if k not in base} == {'RANK': '3', 'LOCAL_RANK': '3', 'WORLD_SIZE': '8', 'MASTER_ADDR': '127.0.0.1',
+                                                             'MASTER_PORT': '4242', 'HSA_ENABLE_IPC_MODE_LEGACY': '0'}
+    assert all(e[k] == v for k, v in base.items()) and 'RANK' not in base
+    assert bench.rank_environment(dict(base, HSA_ENABLE_IPC_MODE_LEGACY='1'), 0, 2, 1)['HSA_ENABLE_IPC_MODE_LEGACY'] == '1'
+    assert bench.rank_layout(5, 5, 1 << 20) == {'rank': 5, 'device_index': 5, 'env_index_base': 5 << 20, 'envs': 1 << 20}
+    run = subprocess.run([sys.executable, BENCH, '--gpus', '4', '--dry-run'],
+                         env=_clean_env(SCG_BENCH_DRYRUN_FAIL_RANK='2'), capture_output=True, text=True, timeout=600)
+    assert run.returncode == 3
+    assert '[rank 2] dry run: rank 2 fails on request' in run.stderr, run.stderr[-2000:]
 
 
 def test_bench_launcher_propagates_a_failing_rank():

@@ -227,6 +227,27 @@ def test_c_abi_header_matches_library_and_binding():
         assert int(re.search(r'#define %s (\d+)' % macro, header).group(1)) == val
 
 
+def test_library_override_is_explicit_and_fails_loudly(monkeypatch, tmp_path):
+    """SCG_ROLLOUT_LIB (read by the Python binding, never by the library) points the binding at another build of the SAME ABI --
+    the A/B switch of tools/tune.py.  It is the only such switch: a missing file raises (no fallback to the in-tree library), a
+    library of another ABI version is refused by load()."""
+    default = _capi.library_path()
+    assert default == os.path.join(ROOT, 'safe_control_gym_amd', 'lib', 'libscg_rollout.so')
+    monkeypatch.setenv('SCG_ROLLOUT_LIB', str(tmp_path / 'absent.so'))
+    assert _capi.library_path() == str(tmp_path / 'absent.so')
+    monkeypatch.setattr(_capi, '_LIB', None)
+    with pytest.raises(_capi.ScgError, match='missing'):
+        _capi.load()
+    # the same file under another name loads and is the library that answers
+    import shutil
+    shutil.copy(default, tmp_path / 'copy.so')
+    monkeypatch.setenv('SCG_ROLLOUT_LIB', str(tmp_path / 'copy.so'))
+    monkeypatch.setattr(_capi, '_LIB', None)
+    lib = _capi.load()
+    assert lib._name == str(tmp_path / 'copy.so') and lib.scg_version() == _capi.SCG_ABI_VERSION
+    monkeypatch.setattr(_capi, '_LIB', None)
+
+
 def test_c_abi_rejects_bad_arguments_without_gpu_work():
     lib = _capi.load()
     h = ctypes.c_void_p()

@@ -356,29 +356,46 @@ def test_constraint_api_on_explicit_state(gpu):
             ref.envs, [r.constraints.constraints[env.constraints.constraints.index(con_e)] for r in ref.envs])]))
 
 
-def test_precise_mode_open_loop_1000_step_drift(gpu):
+@pytest.mark.parametrize('scenario', ['hover', 'c4_circle'])
+def test_precise_mode_open_loop_1000_step_drift(gpu, scenario):
     """BASELINE north-star: "<= 1e-5 state drift vs CasADi over 1000 steps" on an identical action sequence.
     Replaying a recorded sequence open loop on this marginally stable plant integrates any 1e-7 evaluation
     error four times (torque -> rate -> attitude -> velocity -> position, ~t^4), so float32 arithmetic cannot
     meet it (measured below); compensated_state=True integrates in float64 on hi + lo float32 state planes
-    with float64 constants and does."""
-    n = 16
-    kw = dict(task='stabilization', task_info=GOAL3, cost='rl_reward', ctrl_freq=60, pyb_freq=240,
-              done_on_out_of_bound=False, episode_len_sec=20)
-    rng = np.random.default_rng(5)
-    x0 = np.zeros((n, 12))
-    x0[:, [0, 2, 4]] = [0.2, -0.1, 1.0]
-    x0 = (x0 + rng.normal(size=(n, 12)) * 0.05).astype(np.float32).astype(np.float64)
+    with float64 constants and does; 'attitude' keeps residual planes and double accumulation for the rotational chain only.
+    Two scenarios: a PD-stabilised hover (16 envs), and the BENCHMARKED workload -- C4, circle tracking with the quadratic
+    cost, 64 envs under a PD tracking law, auto-reset off."""
+    if scenario == 'hover':
+        n = 16
+        kw = dict(task='stabilization', task_info=GOAL3, cost='rl_reward', ctrl_freq=60, pyb_freq=240,
+                  done_on_out_of_bound=False, episode_len_sec=20)
+        rng = np.random.default_rng(5)
+        x0 = np.zeros((n, 12))
+        x0[:, [0, 2, 4]] = [0.2, -0.1, 1.0]
+        x0 = (x0 + rng.normal(size=(n, 12)) * 0.05).astype(np.float32).astype(np.float64)
+    else:
+        n = 64
+        kw = dict(task='traj_tracking', cost='quadratic', ctrl_freq=60, pyb_freq=240, done_on_out_of_bound=False, episode_len_sec=20)
+        rng = np.random.default_rng(6)
+        x0 = None
     errs = {}
     for comp in (False, True, 'attitude'):
         env, ref, sampler = make_pair(3, n, randomized_init=False, init_states=x0,
                                       engine_kwargs=dict(compensated_state=comp), **kw)
         sync_reset(env, ref, sampler)
         hover = ref.envs[0].U_GOAL
+        if scenario == 'c4_circle':
+            # start ON the reference, every env a little off it (the same float32-representable offsets on both sides)
+            xg = np.asarray(ref.envs[0].X_GOAL, dtype=np.float64)
+            start = (xg[0][None, :] + np.random.default_rng(6).normal(size=(n, 12)) * 0.03).astype(np.float32).astype(np.float64)
+            for r, xi in zip(ref.envs, start):
+                r.state = xi.copy()
+            force_state(env, ref)
         worst, at = 0.0, {}
         for k in range(1000):
             # feedback evaluated on the ORACLE state, then the same float32 actions replayed on the engine
-            f = _pd_controller(np.stack([r.state for r in ref.envs]), hover)
+            xs = np.stack([r.state for r in ref.envs])
+            f = _pd_controller(xs, hover) if scenario == 'hover' else _pd_tracking(xs, xg[min(k, xg.shape[0] - 1)], hover)
             out_e, out_r = sync_step(env, ref, sampler, f)
             assert not bool(out_e[2].any()) and not out_r[2].any()
             xe = env.state.double()
@@ -391,13 +408,33 @@ def test_precise_mode_open_loop_1000_step_drift(gpu):
                 at[k + 1] = worst
         errs[comp] = at
         xs = np.stack([r.state for r in ref.envs])
-        assert np.abs(xs[:, [0, 2, 4]] - [0.2, -0.1, 1.0]).max() < 0.02, 'controller did not converge'
-    print('open-loop replay drift  float32: %s   precise (fp64 integration): %s   attitude-only residuals: %s'
-          % tuple({k: '%.1e' % v for k, v in errs[c].items()} for c in (False, True, 'attitude')))
+        if scenario == 'hover':
+            assert np.abs(xs[:, [0, 2, 4]] - [0.2, -0.1, 1.0]).max() < 0.02, 'controller did not converge'
+        else:
+            assert np.abs(xs[:, [0, 2, 4]] - xg[999][[0, 2, 4]]).max() < 0.6, 'controller does not track'      # (the reference's velocity rows carry its position offset: a standing lag)
+        env.close()
+    print('open-loop replay drift (%s)  float32: %s   precise (fp64 integration): %s   attitude-only residuals: %s'
+          % ((scenario,) + tuple({k: '%.1e' % v for k, v in errs[c].items()} for c in (False, True, 'attitude'))))
     assert errs[True][1000] <= 1e-5
     assert errs[True][1000] < errs[False][1000]
-    # float64 attitude / rates with residual planes, float32 positions / velocities: same bound at 48 B per env-step less
+    # double accumulation of attitude / rates on residual planes, float32 positions / velocities: same bound at 48 B per env-step less
     assert errs['attitude'][1000] <= 1e-5 and errs['attitude'][1000] < errs[False][1000]
+
+
+def _pd_tracking(xs, goal, hover):
+    """The PD law of _pd_controller around a MOVING set point: `goal` is the reference row X_GOAL[k] (positions and velocities)."""
+    k_arm = 0.0397 / np.sqrt(2)
+    gamma = 7.94e-12 / 3.16e-10
+    th_des = np.clip(-0.25 * (xs[:, 0] - goal[0]) - 0.35 * (xs[:, 1] - goal[1]), -0.3, 0.3)
+    ph_des = np.clip(0.25 * (xs[:, 2] - goal[2]) + 0.35 * (xs[:, 3] - goal[3]), -0.3, 0.3)
+    thrust = hover[0] * 4 * (1 + 1.5 * (goal[4] - xs[:, 4]) - 0.8 * (xs[:, 5] - goal[5]))
+    mx = 2e-3 * (ph_des - xs[:, 6]) - 4e-4 * xs[:, 9]
+    my = 2e-3 * (th_des - xs[:, 7]) - 4e-4 * xs[:, 10]
+    mz = -1e-3 * xs[:, 8] - 3e-4 * xs[:, 11]
+    return np.stack([thrust / 4 + mx / (4 * k_arm) - my / (4 * k_arm) + mz / (4 * gamma),
+                     thrust / 4 + mx / (4 * k_arm) + my / (4 * k_arm) - mz / (4 * gamma),
+                     thrust / 4 - mx / (4 * k_arm) + my / (4 * k_arm) + mz / (4 * gamma),
+                     thrust / 4 - mx / (4 * k_arm) - my / (4 * k_arm) - mz / (4 * gamma)], axis=1)
 
 
 def _pd_controller(xs, hover):

@@ -496,6 +496,48 @@ def test_fresh_outputs_ping_pong_state(gpu, kw):
     env.close(); twin.close()
 
 
+def test_fresh_outputs_survive_in_place_writers_with_an_observation_disturbance(gpu):
+    """copy_outputs=True WITH an observation disturbance (no ping-pong: the kernel writes a separate obs buffer): obs, rew and
+    done of a step are fresh tensors, and none of them is written again by reset(mask), reset(), rollout() or
+    load_state_dict() (they used to stay bound in the engine's buffer table)."""
+    n = 2048
+    env = scg.make('quadrotor', quad_type=2, num_envs=n, device='cuda', seed=5, randomized_init=True, episode_len_sec=0.4,
+                   ctrl_freq=50, pyb_freq=50, copy_outputs=True,
+                   disturbances={'observation': [{'disturbance_func': 'white_noise', 'std': 0.05}]})
+    env.reset()
+    assert env._fresh_outputs and not env._pingpong
+    g = torch.Generator(device='cuda'); g.manual_seed(3)
+    lo = torch.as_tensor(env.action_space.low, device='cuda'); hi = torch.as_tensor(env.action_space.high, device='cuda')
+    ld = env.plane_stride
+    acts = torch.rand((4, env.action_dim, ld), generator=g, device='cuda') * (hi - lo)[None, :, None] + lo[None, :, None]
+    sd = None
+
+    def stepped():
+        a = torch.rand((n, env.action_dim), generator=g, device='cuda') * (hi - lo) + lo
+        obs, rew, done, _ = env.step(a)
+        return [(t, t.clone()) for t in (obs, rew, done)]
+
+    held = []
+    for writer in ('masked reset', 'full reset', 'rollout', 'checkpoint load', 'step'):
+        for _ in range(3):
+            got = stepped()
+        held += got
+        if writer == 'masked reset':
+            mask = torch.zeros(n, dtype=torch.bool); mask[::2] = True
+            sd = env.state_dict()
+            env.reset(mask=mask)
+        elif writer == 'full reset':
+            env.reset()
+        elif writer == 'rollout':
+            env.rollout(acts)
+        elif writer == 'checkpoint load':
+            env.load_state_dict(sd)
+        for tensor, snapshot in held:
+            assert torch.equal(tensor, snapshot), writer
+    assert len({t.data_ptr() for t, _ in held}) == len(held)
+    env.close()
+
+
 def test_reference_attribute_surface_after_a_step(gpu):
     """Attributes callers of the reference read off the env (SURVEY 8b-5 and the assignments of benchmark_env.py /
     quadrotor.py): current_preprocessed_action (:833), cnstr_violation (:441-449), goal_reached (:965), the counters, the
@@ -595,6 +637,53 @@ def test_rollout_is_capturable_in_a_hip_graph(gpu):
     for key in ('state', 'step_count', 'ep_return', 'reward', 'done'):
         assert torch.equal(a._bufs[key], b._bufs[key]), key
     a.close(), b.close()
+
+
+@pytest.mark.parametrize('system', ['cartpole', 2, 3])
+def test_rollout_graph_replay_is_bit_identical_to_plain_launches(gpu, system):
+    """Small batches: scg_rollout captures the launches of a signature it sees for the second time into a hipGraph and replays it
+    (scg_config.rollout_graph).  The step serial travels through a device word, so the Philox reset draws are those of plain
+    launches: state, counters, returns, reward, done equal a twin env with rollout_graph=-1 bit for bit after every call --
+    first sighting (plain), capture + replay, replays, a second signature, a reset in between, a changed action tensor."""
+    n = 5000
+    kw = dict(num_envs=n, device='cuda', seed=21, randomized_init=True, ctrl_freq=50, pyb_freq=50, episode_len_sec=0.3,
+              info_level='minimal', track_episode_stats=True)
+    if system == 'cartpole':
+        mk = lambda **e: scg.make('cartpole', task='stabilization', cost='quadratic', **kw, **e)
+    else:
+        mk = lambda **e: scg.make('quadrotor', quad_type=system, task='traj_tracking', cost='rl_reward', **kw, **e)
+    plain, graphed = mk(rollout_graph=-1), mk()
+    plain.reset(), graphed.reset()
+    g = torch.Generator(device='cuda'); g.manual_seed(4)
+    lo = torch.as_tensor(plain.action_space.low, device='cuda')[None, :, None]
+    hi = torch.as_tensor(plain.action_space.high, device='cuda')[None, :, None]
+    acts = torch.rand((9, plain.action_dim, plain.plane_stride), generator=g, device='cuda') * (hi - lo) + lo
+    acts2 = acts.flip(0).contiguous()
+
+    def same(tag):
+        torch.cuda.synchronize()
+        for key in ('state', 'step_count', 'ep_return', 'reward', 'done'):
+            assert torch.equal(plain._bufs[key], graphed._bufs[key]), (tag, key)
+
+    for call in range(4):                                  # plain, capture + replay, replay, replay
+        plain.rollout(acts, steps=24), graphed.rollout(acts, steps=24)
+        same('call %d' % call)
+    cached, replays = graphed._engine.rollout_graph_info()
+    assert cached == 1 and replays == 3 and plain._engine.rollout_graph_info() == (0, 0)
+    for call in range(3):                                  # a second signature (steps), the first stays cached
+        plain.rollout(acts, steps=10), graphed.rollout(acts, steps=10)
+        same('steps 10, call %d' % call)
+    assert graphed._engine.rollout_graph_info() == (2, 5)
+    plain.reset(), graphed.reset()                         # reset() moves the serial; the cached graph picks the new one up
+    plain.rollout(acts, steps=24), graphed.rollout(acts, steps=24)
+    same('after reset')
+    assert graphed._engine.rollout_graph_info() == (2, 6)
+    for call in range(2):                                  # another action tensor is another signature
+        plain.rollout(acts2, steps=24), graphed.rollout(acts2, steps=24)
+        same('other actions, call %d' % call)
+    assert graphed._engine.rollout_graph_info() == (3, 7)
+    assert int(graphed._bufs['done'].sum()) > 0 or int(graphed.ctrl_step_counter.min()) < 24      # auto-resets happened on the way
+    plain.close(), graphed.close()
 
 
 def test_state_out_through_the_c_abi(gpu):

@@ -279,6 +279,30 @@ def test_oracle_step_glue_matches_reference_methods(name):
             assert np.max(np.abs(info2['constraint_values'] - G[key + 'cvals'][i])) <= 1e-8
 
 
+@pytest.mark.parametrize('name', [c['name'] for c in GROUPS['step_glue_device']['cases']])
+def test_oracle_step_matches_reference_glue_on_reachable_states(name):
+    """step_glue_device: a whole oracle step() from (state0, action, counter) lands on the recorded state, and everything the
+    reference's executed _get_done / _get_reward / after_step / extend_obs said about that state comes out of it."""
+    c = [g for g in GROUPS['step_glue_device']['cases'] if g['name'] == name][0]
+    ref, _ = _glue_ref_env(c)
+    ref.reset_sampler = lambda i, e: np.zeros(ref.nx)
+    ref.reset()
+    key = 'step_glue_device/%s/' % name
+    for i in range(G[key + 'state0'].shape[0]):
+        ref.state = G[key + 'state0'][i].copy()
+        ref.ctrl_step_counter, ref.pyb_step_counter = int(G[key + 'counter'][i]), 4 * int(G[key + 'counter'][i])
+        obs, rew, done, info = ref.step(G[key + 'action'][i].copy())
+        assert rel_err(ref.state, G[key + 'state'][i]) <= TIGHT, i
+        assert rel_err(obs, G[key + 'obs'][i]) <= TIGHT and rel_err(info['mse'], G[key + 'mse'][i]) <= TIGHT
+        assert bool(done) == bool(G[key + 'done'][i]), i
+        if c['cost'] == 'rl_reward':
+            assert rel_err(rew, G[key + 'rew'][i]) <= TIGHT, i
+        assert info.get('constraint_violation', -1) == int(G[key + 'violation'][i])
+        assert {True: 1, False: 0}.get(info.get('TimeLimit.truncated'), -1) == int(G[key + 'truncated'][i])
+        if ref.constraints is not None:
+            assert np.max(np.abs(info['constraint_values'] - G[key + 'cvals'][i])) <= 1e-8
+
+
 @pytest.mark.parametrize('k', range(len(GROUPS['gae']['cases'])))
 def test_oracle_gae_matches_reference_function(k):
     from oracle.ref_ppo import compute_returns_and_advantages
@@ -415,6 +439,50 @@ def test_device_constraint_rows_match_reference_classes(gpu, name):
         vs = env.constraints.get_values(env, only_state=True).double().cpu().numpy()
         ws = G[key + 'values_only_state']
         assert np.max(np.abs(vs - ws) / (np.maximum(np.abs(ws), 1.0) + np.abs(xs).max())) <= RTOL
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('info_level', ['full', 'minimal'])
+@pytest.mark.parametrize('name', [c['name'] for c in GROUPS['step_glue_device']['cases']])
+def test_device_step_matches_reference_glue(gpu, name, info_level):
+    """The fused kernel's own after_step / _get_done / _get_reward / extend_obs against the REFERENCE's executed methods
+    (benchmark_env.py:422-463, quadrotor.py:886-1002): the HIP env starts at the recorded state0 and counter, takes ONE step with
+    the recorded raw action, and its reward / done / truncation / violation / constraint values / mse / extended observation are
+    compared with what the reference said about that step (tolerance 1e-5, flags exact; the recorded samples keep 1e-3 of
+    margin to every decision boundary).  Both kernel tiers: info_level='full' (FT_INFO / FT_DIST) and 'minimal' (lean)."""
+    import torch
+    import safe_control_gym_amd as scg
+    c = [g for g in GROUPS['step_glue_device']['cases'] if g['name'] == name][0]
+    _, kw = _glue_ref_env(c)
+    key = 'step_glue_device/%s/' % name
+    x0, acts, counters = G[key + 'state0'], G[key + 'action'], G[key + 'counter'].astype(np.int32)
+    n = x0.shape[0]
+    env = scg.make('quadrotor', quad_type=c['quad_type'], num_envs=n, device='cuda', randomized_init=False, auto_reset=False,
+                   info_level=info_level, copy_outputs=False, **kw)
+    env.reset()
+    env.state_soa.copy_(torch.as_tensor(x0.astype(np.float32).T, device='cuda'))
+    env.ctrl_step_counter.copy_(torch.as_tensor(counters, device='cuda'))
+    obs, rew, done, info = env.step(torch.as_tensor(acts.astype(np.float32), device='cuda'))
+    nx = x0.shape[1]
+    got_obs = obs.double().cpu().numpy()
+    assert rel_err(got_obs[:, :nx], G[key + 'state'][:, :nx]) <= RTOL, name
+    assert rel_err(got_obs, G[key + 'obs']) <= RTOL, name                       # the goal rows behind the state: extend_obs
+    assert np.array_equal(done.cpu().numpy().astype(bool), G[key + 'done'].astype(bool)), name
+    if c['cost'] == 'rl_reward':
+        assert rel_err(rew.double().cpu().numpy(), G[key + 'rew']) <= RTOL, name
+    if kw.get('constraints'):
+        assert np.array_equal(info['constraint_violation'].cpu().numpy().astype(int), G[key + 'violation'].astype(int))
+        cv, want = info['constraint_values'].double().cpu().numpy(), G[key + 'cvals']
+        assert np.max(np.abs(cv - want) / (np.maximum(np.abs(want), 1.0) + np.abs(x0).max())) <= RTOL
+    else:
+        assert np.all(G[key + 'violation'] == -1) and 'constraint_violation' not in info
+    if info_level == 'full':
+        assert rel_err(info['mse'].double().cpu().numpy(), G[key + 'mse']) <= RTOL
+        trunc = G[key + 'truncated']                                            # -1: the reference sets the key only at the time limit
+        assert np.array_equal(info['TimeLimit.truncated'].cpu().numpy().astype(int), np.maximum(trunc, 0).astype(int))
+        if c['cost'] == 'quadratic' and c['task'] == 'stabilization':
+            assert np.array_equal(info['goal_reached'].cpu().numpy().astype(bool), G[key + 'goal_reached'].astype(bool))
     env.close()
 
 

@@ -9,7 +9,7 @@ src="$root/safe_control_gym_amd/csrc"
 obj="$root/safe_control_gym_amd/lib/obj"
 out="$root/safe_control_gym_amd/lib/variants"
 mkdir -p "$out"
-rm -f "$out"/*.so "$out"/*.o
+rm -f "$out"/*.o        # arms already in lib/variants stay (e.g. a copy of an earlier round's library)
 build() { # name, extra flags...
   local name="$1"; shift
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c "$src/scg_kernels.hip" -o "$out/$name.o" &&
