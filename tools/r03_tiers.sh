@@ -7,9 +7,9 @@ root="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 out="$root/gpurun_out/r03/$tag"
 mkdir -p "$out"
 cd "$root"
-T="timeout -k 10 600 python tools/tune.py --rounds ${ROUNDS:-2} ${ARMS:+--arms $ARMS} ${ABI:+--abi $ABI}"
+T="timeout -k 10 600 python tools/tune.py --rounds ${ROUNDS:-2} ${ARMS:+--arms $ARMS} ${ABI:+--abi $ABI} ${TREE:+--tree $TREE}"
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
-  echo "== GPU suite (shipped library)"; timeout -k 10 900 python -m pytest tests -m gpu -q -x > "$out/gpu_tests.log" 2>&1; tail -3 "$out/gpu_tests.log"
+  echo "== GPU suite (shipped library)"; timeout -k 10 900 python -m pytest tests -m gpu -q > "$out/gpu_tests.log" 2>&1; grep -E "^(FAILED|ERROR)|passed|failed" "$out/gpu_tests.log" | tail -15
 fi
 echo "== headline, two queues"; $T --steps 1500 2>&1 | tee "$out/tune_headline.log" | grep -A20 "^----"
 echo "== fused rollout"; $T --steps 600 --field fused_rollout.us_per_step -- --fused 2>&1 | tee "$out/tune_fused.log" | grep -A20 "^----"

@@ -13,12 +13,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(lib, env_extra, steps, extra_args, abi=None):
+def run(lib, env_extra, steps, extra_args, abi=None, tree=None):
     env = dict(os.environ)
     if lib:
         env['SCG_ROLLOUT_LIB'] = lib
     env.update(env_extra)
-    bench = os.path.join(ROOT, 'bench.py')
+    bench = os.path.join(tree or ROOT, 'bench.py')
     argv = ['--steps', str(steps), '--warmup', '100', '--no-cpu-baseline', '--no-sub-records'] + extra_args
     if abi is None:
         cmd = [sys.executable, bench] + argv
@@ -42,6 +42,7 @@ def main():
     ap.add_argument('--arms', default='')
     ap.add_argument('--field', default='roofline.kernel_us_per_launch', help='dotted path of the number to compare (us; lower is better)')
     ap.add_argument('--abi', default='', help='arm=version[,arm=version]: arms built for an earlier, layout-compatible ABI version')
+    ap.add_argument('--tree', default='', help='arm=path[,arm=path]: an exported tree of an earlier round (git archive + its library)')
     ap.add_argument('bench_args', nargs='*')
     a = ap.parse_args()
     vdir = os.path.join(ROOT, 'safe_control_gym_amd', 'lib', 'variants')
@@ -53,10 +54,15 @@ def main():
         keep = set(a.arms.split(','))
         arms = [x for x in arms if x[0] in keep]
     abis = dict(kv.split('=') for kv in a.abi.split(',') if kv)
+    # whole source trees of earlier rounds (their own package, bench.py and library): arm `name` runs <path>/bench.py
+    trees = dict(kv.split('=') for kv in a.tree.split(',') if kv)
+    for name, path in trees.items():
+        if not a.arms or name in a.arms.split(','):
+            arms.append((name, None, {}))
     res = {name: [] for name, _, _ in arms}
     for r in range(a.rounds):
         for name, lib, envx in arms:
-            j = run(lib, envx, a.steps, a.bench_args, abi=abis.get(name))
+            j = run(lib, envx, a.steps, a.bench_args, abi=abis.get(name), tree=os.path.join(ROOT, trees[name]) if name in trees else None)
             us = j
             for part in a.field.split('.'):
                 us = us.get(part) if isinstance(us, dict) else None
