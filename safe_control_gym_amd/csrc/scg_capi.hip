@@ -989,7 +989,7 @@ int scg_rollout_graph_info(const scg_handle* h, int32_t* cached, int64_t* replay
 
 int scg_kernel_info(const scg_handle* h, int32_t* block, int32_t* grid_for_n, int32_t* lds_bytes, int64_t n) {
     if (!h) return fail(SCG_ERR_INVALID, "scg_kernel_info: null handle");
-    LaunchGeom g = step_geometry(h->kp, h->system, 0, n, h->num_cus);
+    LaunchGeom g = step_geometry(h->kp, h->system, n, h->num_cus);
     if (block) *block = g.block;
     if (grid_for_n) *grid_for_n = g.grid;
     if (lds_bytes) *lds_bytes = g.lds_bytes;

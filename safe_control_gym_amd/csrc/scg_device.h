@@ -154,7 +154,7 @@ struct LaunchGeom {
 
 // Kernel launchers (scg_kernels.hip)
 namespace scg {
-LaunchGeom step_geometry(const KParams& p, int system, int comp, int64_t n, int num_cus);   // comp: 0 float state, 1 / 2 precise modes
+LaunchGeom step_geometry(const KParams& p, int system, int64_t n, int num_cus);
 hipError_t launch_step(int system, const KParams& p, const scg_step_io& io, const KTables* tb,
                        const ConTable* ct, const float* ref, int64_t n, int num_cus, hipStream_t s);
 bool fused_rollout_ok(const KParams& p, const scg_step_io& io);

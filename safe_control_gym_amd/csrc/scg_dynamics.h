@@ -17,9 +17,6 @@ template <class T> struct Real;
 template <> struct Real<float> {
     static __device__ __forceinline__ float rcp(float x) { return rcp_f(x); }
     static __device__ __forceinline__ void sincos(float x, float& s, float& c) { sincos_f(x, s, c); }
-    static __device__ __forceinline__ void sincos2(float xa, float xb, float& sa, float& ca, float& sb, float& cb) {
-        sincos2_f(xa, xb, sa, ca, sb, cb);
-    }
 };
 template <> struct Real<double> {
     static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
@@ -45,10 +42,6 @@ template <> struct Real<double> {
         const double ss = (k & 1) ? cr : sr, cc = (k & 1) ? sr : cr;
         s = (k & 2) ? -ss : ss;
         c = ((k + 1) & 2) ? -cc : cc;
-    }
-    static __device__ __forceinline__ void sincos2(double xa, double xb, double& sa, double& ca, double& sb, double& cb) {
-        sincos(xa, sa, ca);
-        sincos(xb, sb, cb);
     }
 };
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return fmaf(a, b, c); }
@@ -105,7 +98,8 @@ __device__ __forceinline__ void f_eval(const PhysT<T>& c, const Inputs<SYS, T>& 
         d[5] = in.thdd;
     } else if constexpr (SYS == SCG_QUAD_3D) {
         T sph, cph, sth, cth, sps, cps;
-        Real<T>::sincos2(x[6], x[7], sph, cph, sth, cth);
+        Real<T>::sincos(x[6], sph, cph);
+        Real<T>::sincos(x[7], sth, cth);
         Real<T>::sincos(x[8], sps, cps);
         const T P = x[9], Q = x[10], R = x[11];
         // third column of R = Rz(psi) Ry(theta) Rx(phi)  (transformations.py:125-182)
@@ -140,26 +134,10 @@ __device__ __forceinline__ void f_eval(const PhysT<T>& c, const Inputs<SYS, T>& 
     }
 }
 
-// Where the BASE state of an RK4 step lives while the stages run.  It is read-only from the second stage on (xt = x + c h k,
-// x_new = x + inc), so it need not occupy registers: the 3-D float kernels park it in LDS (12 VGPRs less across the stage
-// evaluations; LDS instructions issue beside the VALU ones), everything else reads the registers it arrived in.
-template <class T, int NX>
-struct BaseInRegs {
-    const T (&x)[NX];
-    __device__ __forceinline__ T operator()(int j) const { return x[j]; }
-};
-typedef __attribute__((address_space(3))) float lds_float;
-template <int STRIDE>
-struct BaseInLds {               // plane j of this lane at p[j * STRIDE] (conflict-free: consecutive lanes, consecutive dwords)
-    lds_float* p;
-    __device__ __forceinline__ float operator()(int j) const { return p[j * STRIDE]; }
-};
-
-// One fixed step; returns the increment (so the float path can add it with its own rounding).  `x` is the state the first
-// stage is evaluated at (registers); `xb` hands out the same values for the later stages and may read them from elsewhere.
-template <int SYS, class T, class XB>
+// One fixed step; returns the increment (so the float path can add it with its own rounding).
+template <int SYS, class T>
 __device__ __forceinline__ void integrate(const PhysT<T>& c, uint32_t flags, const Inputs<SYS, T>& in,
-                                          const T (&x)[Dim<SYS>::NX], const XB& xb, T (&inc)[Dim<SYS>::NX]) {
+                                          const T (&x)[Dim<SYS>::NX], T (&inc)[Dim<SYS>::NX]) {
     constexpr int NX = Dim<SYS>::NX;
     const T h = c.h;
     T k[NX];
@@ -176,19 +154,14 @@ __device__ __forceinline__ void integrate(const PhysT<T>& c, uint32_t flags, con
     for (int j = 0; j < NX; ++j) { acc[j] = k[j]; xt[j] = fma_t(hh, k[j], x[j]); }
     f_eval<SYS, T>(c, in, xt, k);
 #pragma unroll
-    for (int j = 0; j < NX; ++j) { acc[j] = fma_t((T)2, k[j], acc[j]); xt[j] = fma_t(hh, k[j], xb(j)); }
+    for (int j = 0; j < NX; ++j) { acc[j] = fma_t((T)2, k[j], acc[j]); xt[j] = fma_t(hh, k[j], x[j]); }
     f_eval<SYS, T>(c, in, xt, k);
 #pragma unroll
-    for (int j = 0; j < NX; ++j) { acc[j] = fma_t((T)2, k[j], acc[j]); xt[j] = fma_t(h, k[j], xb(j)); }
+    for (int j = 0; j < NX; ++j) { acc[j] = fma_t((T)2, k[j], acc[j]); xt[j] = fma_t(h, k[j], x[j]); }
     f_eval<SYS, T>(c, in, xt, k);
     const T h6 = h * (T)(1.0 / 6.0);
 #pragma unroll
     for (int j = 0; j < NX; ++j) inc[j] = h6 * (acc[j] + k[j]);
-}
-template <int SYS, class T>
-__device__ __forceinline__ void integrate(const PhysT<T>& c, uint32_t flags, const Inputs<SYS, T>& in,
-                                          const T (&x)[Dim<SYS>::NX], T (&inc)[Dim<SYS>::NX]) {
-    integrate<SYS, T>(c, flags, in, x, BaseInRegs<T, Dim<SYS>::NX>{x}, inc);
 }
 
 // ---- mixed-precision step of the 3-D quadrotor ("attitude" precise mode) ---------------------------------------------
@@ -198,13 +171,14 @@ __device__ __forceinline__ void integrate(const PhysT<T>& c, uint32_t flags, con
 // rates (states 6..11) ACCUMULATE in double -- hi + lo float32 planes in memory, RK4 combination in double --, positions and
 // velocities (states 0..5) in float.
 //
-// Which arithmetic has to be double was measured too (tools/precise_mode_study.py, "derivative" rows): what integrates into
-// the drift is a CONSTANT error, and the only place one is born is the cancellation of the thrusts in the torques
-// (u0 + u1 - u2 - u3 ...) and the products of the rate equations; random rounding errors of 6e-8 in the trigonometry and the
-// Euler-angle kinematics average out (2.9e-6 at 1000 steps against 1.8e-6 with everything in double).  Hence (default,
-// SCG_ATT_FP64_TRIG = 0): inputs (T/m, torques) and the body-rate derivatives in double; sin / cos of the float32-rounded
-// stage angles, the Euler-rate kinematics and the acceleration  R(:, 2) T/m  in float32 (the packed sincos of scg_math.h),
-// converted once.  SCG_ATT_FP64_TRIG = 1 is round 2's form (12 float64 sin/cos pairs per step: 624 fp64 instructions).
+// Which arithmetic has to be double was measured too (tools/precise_mode_study.py, "arithmetic" rows, on the hover and on the
+// circle-tracking scenario): what integrates into the drift is a BIASED error -- the cancellation of the thrusts in the torques
+// (u0 + u1 - u2 - u3 ...), the products of the rate equations, and the products  R(:, 2) T/m - g  of the acceleration (in
+// float32: 3.2e-5 at 1000 steps of circle tracking) --, while the rounding of sin / cos themselves and of the Euler-rate
+// kinematics to float32 averages out (3.4e-6 against 2.9e-6 with everything in double).  Hence (default,
+// SCG_ATT_FP64_TRIG = 0): inputs (T/m, torques), the body-rate derivatives and the acceleration products in double; sin / cos
+// of the float32-rounded stage angles and the Euler-rate kinematics in float32 (sincos_f of scg_math.h: 22 instead of ~40
+// instructions per pair), converted once.  SCG_ATT_FP64_TRIG = 1 is round 2's form (12 float64 sin/cos pairs per step).
 #ifndef SCG_ATT_FP64_TRIG
 #define SCG_ATT_FP64_TRIG 0
 #endif
@@ -230,16 +204,20 @@ __device__ __forceinline__ void f_mixed3d(const PhysT<double>& c, const Inputs<S
     da[2] = w * rcth;
 #else
     float sph, cph, sth, cth, sps, cps;
-    sincos2_f((float)xa[0], (float)xa[1], sph, cph, sth, cth);
+    sincos_f((float)xa[0], sph, cph);
+    sincos_f((float)xa[1], sth, cth);
     sincos_f((float)xa[2], sps, cps);
-    const float Tm = (float)in.Tm, Qf = (float)Q, Rf = (float)R;
-    const float sthcph = sth * cph;
-    dt[0] = xt[1];
-    dt[1] = fmaf(fmaf(cps, sthcph, sps * sph), Tm, (float)in.ax);
-    dt[2] = xt[3];
-    dt[3] = fmaf(fmaf(sps, sthcph, -(cps * sph)), Tm, (float)in.ay);
-    dt[4] = xt[5];
-    dt[5] = fmaf(cth * cph, Tm, (float)in.az);
+    const float Qf = (float)Q, Rf = (float)R;
+    {
+        const double dsph = sph, dcph = cph, dsth = sth, dcth = cth, dsps = sps, dcps = cps;
+        const double sthcph = dsth * dcph;
+        dt[0] = xt[1];
+        dt[1] = (float)fma(fma(dcps, sthcph, dsps * dsph), in.Tm, in.ax);
+        dt[2] = xt[3];
+        dt[3] = (float)fma(fma(dsps, sthcph, -(dcps * dsph)), in.Tm, in.ay);
+        dt[4] = xt[5];
+        dt[5] = (float)fma(dcth * dcph, in.Tm, in.az);
+    }
     const float rcth = rcp_f(cth);
     const float w = fmaf(sph, Qf, cph * Rf);
     da[0] = (double)(sth * rcth * w) + P;                 // the rate itself enters in double

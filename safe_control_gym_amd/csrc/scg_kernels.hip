@@ -43,24 +43,19 @@ namespace scg {
 #define SCG_NUM_SGPR 0         // > 0: cap the step kernel's SGPR allocation (amdgpu_num_sgpr); <= 80 admits 8 workgroups per CU
 #endif
 constexpr int kBlock = SCG_BLOCK;
-#ifndef SCG_PARK_BASE
-#define SCG_PARK_BASE 1        // 3-D float kernels: the base state of an RK4 step waits in LDS while the stages run (BaseInLds)
-#endif
-// floats of dynamic LDS at the head of the workgroup's allocation that hold the parked base state (0: not parked)
-constexpr int park_floats(int system, int comp) { return (SCG_PARK_BASE && system == SCG_QUAD_3D && comp == 0) ? 12 * kBlock : 0; }
 #ifndef SCG_COMP_WAVES
-#define SCG_COMP_WAVES 1       // waves per SIMD the register allocator must allow in the precise-mode instantiations (1 = no demand)
+#define SCG_COMP_WAVES 1       // waves per SIMD the register allocator must allow in the full precise-mode instantiations (1 = no demand;
+                               // 5 / 6 spill: DESIGN.md section 6)
+#endif
+#ifndef SCG_ATT_WAVES
+#define SCG_ATT_WAVES 5        // ... in the attitude precise mode: 94 VGPRs without a spill (left alone the scheduler takes 118: 4 waves)
 #endif
 #if SCG_NUM_SGPR > 0
 #define SCG_SGPR_CAP __attribute__((amdgpu_num_sgpr(SCG_NUM_SGPR)))
 #else
 #define SCG_SGPR_CAP
 #endif
-#if SCG_MIN_WAVES > 0
-#define SCG_BOUNDS __launch_bounds__(kBlock, (COMP != 0 ? SCG_COMP_WAVES : SCG_MIN_WAVES)) SCG_SGPR_CAP
-#else
-#define SCG_BOUNDS __launch_bounds__(kBlock, (COMP != 0 ? SCG_COMP_WAVES : 1)) SCG_SGPR_CAP
-#endif
+#define SCG_BOUNDS __launch_bounds__(kBlock, (COMP == 2 ? SCG_ATT_WAVES : (COMP == 1 ? SCG_COMP_WAVES : (SCG_MIN_WAVES > 0 ? SCG_MIN_WAVES : 1)))) SCG_SGPR_CAP
 
 // Philox4x32-10 (Salmon et al., SC'11).  Counter layout shared with oracle/philox.py.
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
@@ -605,6 +600,9 @@ enum Feat : uint32_t {
                      // observation noise, per-episode offsets) and the goal horizon appended to the observation
                      // (benchmark_env.py:406-420) -- the usual RL configurations without the run-time branches of the catch-all
                      // tier.  Normalised actions are a wave-uniform run-time branch of EVERY tier.
+    FT_GOAL = 32u,   // FT_INFO + an obs buffer WITHOUT any disturbance: the noise-free goal-horizon observation of the usual RL
+                     // configuration (rl_reward, obs_goal_horizon >= 1).  Its own tier because the disturbance tier carries the
+                     // Philox / Box-Muller code and 30 more VGPRs although this configuration draws nothing (36.0 -> 3x.x us at 2^20 envs).
     FT_INFO = 8u,    // the per-step info outputs of the default API (info_level='full'): mse / goal_reached /
                      // truncated / terminal_record (terminal obs = the state: obs aliases it in this tier).  A tier of its
                      // own because it is what make() gives by default: 43 us in the EXTRA tier at 2^20 envs.
@@ -631,8 +629,9 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                                                           const RolloutArgs ro) {
     constexpr int NX = Dim<SYS>::NX, NU = Dim<SYS>::NU, NV = NX + NU;
     constexpr bool EXTRA = (FT & FT_EXTRA) != 0;
-    constexpr bool DIST = (FT & (FT_EXTRA | FT_DIST)) != 0;
-    constexpr bool INFO = (FT & (FT_EXTRA | FT_INFO | FT_DIST)) != 0;
+    constexpr bool DIST = (FT & (FT_EXTRA | FT_DIST)) != 0;                     // in-kernel disturbances
+    constexpr bool OBS = (FT & (FT_EXTRA | FT_DIST | FT_GOAL)) != 0;            // an obs buffer (goal horizon and / or observation noise)
+    constexpr bool INFO = (FT & (FT_EXTRA | FT_INFO | FT_DIST | FT_GOAL)) != 0;
     constexpr bool STRIDED = MODE == MODE_STRIDED, FUSED = MODE == MODE_FUSED;
     // COMP: 0 float state; 1 precise mode, every state as hi + lo float32 planes, float64 integration; 2 "attitude" precise
     // mode (3-D quadrotor): residual planes for the rotational chain only (states 6..11 <-> state_lo planes 0..5), see
@@ -640,10 +639,8 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
     static_assert(COMP != 2 || SYS == SCG_QUAD_3D, "the attitude-only residual planes are defined for the 3-D quadrotor");
     constexpr int NLO = COMP == 1 ? NX : (COMP == 2 ? 6 : 1);        // residual planes
     constexpr int LO0 = COMP == 2 ? NX - 6 : 0;                       // state dim of residual plane 0
-    // dynamic LDS: [parked base state (3-D float kernels) | X_GOAL table (F_REF_IN_LDS) | reset scratch] -- step_geometry()
-    extern __shared__ __align__(16) float s_dyn[];
-    constexpr int PARK = park_floats(SYS, COMP);
-    float* const s_tab = s_dyn + PARK;
+    // dynamic LDS: [X_GOAL table (F_REF_IN_LDS) | reset scratch] -- step_geometry()
+    extern __shared__ __align__(16) float s_tab[];
 
     const bool tracking = EXTRA ? ((p.flags & F_TRACKING) != 0) : ((FT & FT_TRACK) != 0);
     const bool has_con = EXTRA ? (p.n_con_rows > 0) : ((FT & FT_CON) != 0);
@@ -881,24 +878,9 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                 for (int s = 0; s < p.substeps; ++s) {
                     RT inc[NX];
                     if (aero) substep_inputs(xs);
-                    if constexpr (PARK != 0 && sizeof(RT) == 4) {
-                        // the base state waits in LDS (plane j of this lane at [j][threadIdx.x]) from the second stage on.
-                        // The address is laundered so that the compiler cannot forward the stored registers to the loads
-                        // (which would keep the 12 values live -- the very thing this avoids).
-                        lds_float* park = (lds_float*)s_dyn + threadIdx.x;
+                    integrate<SYS, RT>(ph, p.flags, in, xs, inc);
 #pragma unroll
-                        for (int j = 0; j < NX; ++j) park[j * kBlock] = (float)xs[j];
-                        uint32_t addr = (uint32_t)(uintptr_t)park;
-                        asm volatile("" : "+v"(addr));
-                        const BaseInLds<kBlock> xb{(lds_float*)(uintptr_t)addr};
-                        integrate<SYS, RT>(ph, p.flags, in, xs, xb, inc);
-#pragma unroll
-                        for (int j = 0; j < NX; ++j) xs[j] = (RT)xb(j) + inc[j];
-                    } else {
-                        integrate<SYS, RT>(ph, p.flags, in, xs, inc);
-#pragma unroll
-                        for (int j = 0; j < NX; ++j) xs[j] += inc[j];
-                    }
+                    for (int j = 0; j < NX; ++j) xs[j] += inc[j];
                 }
 #pragma unroll
                 for (int j = 0; j < NX; ++j) x[j] = (float)xs[j];
@@ -1042,7 +1024,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                         if (EXTRA && io.obs_noise) o += ldp(PL(io.obs_noise, j), i4);
                         rec[j] = o;
                     }
-                    if (DIST && p.obs_goal_horizon > 0) {
+                    if (OBS && p.obs_goal_horizon > 0) {
                         if (tracking) {
                             for (int k = 0; k < p.obs_goal_horizon; ++k) {
                                 float g[NX];
@@ -1117,17 +1099,17 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         }
 
         // ---- _get_observation + extend_obs (quadrotor.py:878-884, benchmark_env.py:406-420)
-        if (DIST && io.obs) {
+        if (OBS && io.obs) {
             // obs == the state written above (noise-free goal-horizon observation): the state planes ARE the first nx obs planes
             if (reinterpret_cast<const void*>(io.obs) != reinterpret_cast<const void*>(io.state_out ? io.state_out : io.state)) {
 #pragma unroll
                 for (int j = 0; j < NX; ++j) {
-                    float o = x[j] + obs_noise[j];
+                    float o = DIST ? x[j] + obs_noise[j] : x[j];
                     if (EXTRA && io.obs_noise) o += ldp(PL(io.obs_noise, j), i4);
                     stp(PL(io.obs, j), i4, o);
                 }
             }
-            if (DIST && p.obs_goal_horizon > 0) {
+            if (OBS && p.obs_goal_horizon > 0) {
                 if (tracking) {
                     // extend_obs(obs, ctrl_step_counter + 1) is evaluated before the counter increment:
                     // rows min(t + 1 + k, T-1); a lane that auto-reset reports the reset observation, whose
@@ -1317,11 +1299,11 @@ static int nx_of(int system) {
     }
 }
 
-LaunchGeom step_geometry(const KParams& p, int system, int comp, int64_t n, int num_cus) {
+LaunchGeom step_geometry(const KParams& p, int system, int64_t n, int num_cus) {
     LaunchGeom g;
     g.block = kBlock;
     int64_t blocks = (n + kBlock - 1) / kBlock;
-    g.lds_bytes = park_floats(system, comp) * (int)sizeof(float);
+    g.lds_bytes = 0;
     if ((p.flags & F_AUTO_RESET) && (p.flags & F_RAND_INIT))
         g.lds_bytes += ((kBlock / 64) * kCoopFloats > kWgResetFloats ? (kBlock / 64) * kCoopFloats : kWgResetFloats) *
                        (int)sizeof(float);                                  // reset scratch (pooled form / per-wave form)
@@ -1345,7 +1327,8 @@ static uint32_t features_needed(const KParams& p, const scg_step_io& io) {
                        (p.flags & (F_GND | F_DRAG | F_RAND_GENERAL)) || !(p.flags & F_Q_DIAG);
     if (extra) return FT_TRACK | FT_CON | FT_EXTRA;
     uint32_t ft = 0;
-    if (p.dist || io.obs || io.episode_id) ft |= FT_DIST;                 // in-kernel disturbances only: their own tier
+    if (p.dist || io.episode_id) ft |= FT_DIST;                           // in-kernel disturbances only: their own tier
+    else if (io.obs) ft |= FT_GOAL;                                       // an obs buffer without them (goal horizon)
     else if (io.truncated || io.goal_reached || io.mse || io.terminal_record) ft |= FT_INFO;
     if (p.flags & F_TRACKING) ft |= FT_TRACK;
     if (p.n_con_rows > 0) ft |= FT_CON;
@@ -1374,7 +1357,11 @@ static bool launch_step_ft(uint32_t ft, const LaunchGeom& g, const KParams& p, c
         case FT_INFO | FT_TRACK: SCG_LAUNCH(FT_INFO | FT_TRACK); break;
         case FT_INFO | FT_CON: SCG_LAUNCH(FT_INFO | FT_CON); break;
         case FT_INFO | FT_TRACK | FT_CON: SCG_LAUNCH(FT_INFO | FT_TRACK | FT_CON); break;
-        // the disturbance tier exists for the float state only (the precise mode takes the catch-all tier: fewer kernels to build)
+        // the obs-buffer tiers exist for the float state only (the precise modes take the catch-all tier: fewer kernels to build)
+        case FT_GOAL: if constexpr (COMP == 0) { SCG_LAUNCH(FT_GOAL); break; }
+        case FT_GOAL | FT_TRACK: if constexpr (COMP == 0) { SCG_LAUNCH(FT_GOAL | FT_TRACK); break; }
+        case FT_GOAL | FT_CON: if constexpr (COMP == 0) { SCG_LAUNCH(FT_GOAL | FT_CON); break; }
+        case FT_GOAL | FT_TRACK | FT_CON: if constexpr (COMP == 0) { SCG_LAUNCH(FT_GOAL | FT_TRACK | FT_CON); break; }
         case FT_DIST: if constexpr (COMP == 0) { SCG_LAUNCH(FT_DIST); break; }
         case FT_DIST | FT_TRACK: if constexpr (COMP == 0) { SCG_LAUNCH(FT_DIST | FT_TRACK); break; }
         case FT_DIST | FT_CON: if constexpr (COMP == 0) { SCG_LAUNCH(FT_DIST | FT_CON); break; }
@@ -1403,7 +1390,7 @@ static bool launch_step_sys(LaunchGeom g, const KParams& p, const scg_step_io& i
 
 // Fused multi-step rollout: lean tiers, float state, table gathered from global memory, exact-cover grid.
 bool fused_rollout_ok(const KParams& p, const scg_step_io& io) {
-    return !(features_needed(p, io) & (FT_EXTRA | FT_INFO | FT_DIST)) && !io.state_lo && !(p.flags & F_REF_IN_LDS);
+    return !(features_needed(p, io) & (FT_EXTRA | FT_INFO | FT_DIST | FT_GOAL)) && !io.state_lo && !(p.flags & F_REF_IN_LDS);
 }
 
 template <int SYS>
@@ -1425,7 +1412,7 @@ static void launch_fused_sys(const KParams& p, const scg_step_io& io, const KTab
 hipError_t launch_rollout_fused(int system, const KParams& p, const scg_step_io& io, const KTables* tb,
                                 const ConTable* ct, const float* ref, int64_t n, int32_t steps, int64_t stride,
                                 int32_t period, int num_cus, hipStream_t s) {
-    const LaunchGeom g = step_geometry(p, system, 0, n, num_cus);
+    const LaunchGeom g = step_geometry(p, system, n, num_cus);
     const RolloutArgs ro{steps, period, stride};
     switch (system) {
         case SCG_QUAD_1D: launch_fused_sys<SCG_QUAD_1D>(p, io, tb, ct, ref, (uint32_t)n, ro, g.lds_bytes, s); break;
@@ -1439,7 +1426,7 @@ hipError_t launch_rollout_fused(int system, const KParams& p, const scg_step_io&
 
 hipError_t launch_step(int system, const KParams& p, const scg_step_io& io, const KTables* tb,
                        const ConTable* ct, const float* ref, int64_t n, int num_cus, hipStream_t s) {
-    const LaunchGeom g = step_geometry(p, system, io.state_lo ? (io.state_lo_kind == 1 ? 2 : 1) : 0, n, num_cus);
+    const LaunchGeom g = step_geometry(p, system, n, num_cus);
     bool ok = false;
     switch (system) {
         case SCG_QUAD_1D: ok = launch_step_sys<SCG_QUAD_1D>(g, p, io, tb, ct, ref, (uint32_t)n, num_cus, s); break;

@@ -77,7 +77,7 @@ hipError_t hipStreamWaitEvent(hipStream_t waiter, hipEvent_t e, unsigned) {
 }
 
 namespace scg {
-LaunchGeom step_geometry(const KParams& p, int, int, int64_t n, int num_cus) {
+LaunchGeom step_geometry(const KParams& p, int, int64_t n, int num_cus) {
     LaunchGeom g; g.block = 256; int64_t b = (n + 255) / 256;
     if (p.grid_cap_per_cu > 0 && b > (int64_t)num_cus * p.grid_cap_per_cu) b = (int64_t)num_cus * p.grid_cap_per_cu;
     g.grid = (int32_t)(b < 1 ? 1 : b); g.lds_bytes = 0; return g;
