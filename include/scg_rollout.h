@@ -296,8 +296,8 @@ int scg_step(scg_handle* h, const scg_step_io* io, int64_t n, void* stream);
  * `stream`; scg_config.rollout_split_min moves the threshold.
  * Smaller batches (launch-bound: a step kernel lasts a few microseconds): the second call with the same signature -- the same
  * scg_step_io contents apart from reset_serial, n, steps, action_stride, action_period -- captures its launches into a
- * hipGraph on the handle's own queue, and that call and every later one with the signature replay it (forked from / joined
- * into `stream` by events; the step serial travels through a device word, so the Philox counters are those of plain
+ * hipGraph (captured on the handle's own queue: nothing runs during a capture), and that call and every later one with the
+ * signature replay it on `stream` (the step serial travels through a device word, so the Philox counters are those of plain
  * launches and the results are bit-identical).  At most 4 signatures are kept (least recently used goes); scg_set_reference /
  * _constraints / _disturbances drop them.  Not taken when `stream` is itself being captured (the launches then join the
  * caller's graph), when steps < 8, or with scg_config.rollout_graph = -1; a capture that fails is ended, discarded, and the
