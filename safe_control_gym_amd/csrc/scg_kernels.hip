@@ -1021,30 +1021,47 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                     // extend_obs(obs, t + 1)), then the finished episode's return and length
                     float* rec = io.terminal_record + (int64_t)i * io.terminal_stride;
                     int od = NX;
+                    float ov[NX];
 #pragma unroll
                     for (int j = 0; j < NX; ++j) {
                         float o = x[j];
                         if (DIST) o += obs_noise[j];
                         if (EXTRA && io.obs_noise) o += ldp(PL(io.obs_noise, j), i4);
-                        rec[j] = o;
+                        ov[j] = o;
                     }
-                    if (OBS && p.obs_goal_horizon > 0) {
-                        if (tracking) {
-                            for (int k = 0; k < p.obs_goal_horizon; ++k) {
-                                float g[NX];
-                                load_goal<NX>(p, ref, s_tab, t + 1 + k, g);
+                    // without a goal horizon the record is [obs | return | length]: whole 16-byte stores (4 instead of 14 for the
+                    // 3-D quadrotor; the few finishing lanes of a wave pay one store instruction each way, but so does the wave)
+                    const bool packed_record = !(OBS && p.obs_goal_horizon > 0) && (reinterpret_cast<uintptr_t>(io.terminal_record) & 15u) == 0;
+                    if (packed_record) {
+                        typedef float v4 __attribute__((ext_vector_type(4)));
+                        constexpr int W4 = (NX + 2 + 3) / 4;
+                        float buf[4 * W4];
 #pragma unroll
-                                for (int j = 0; j < NX; ++j) rec[NX * (1 + k) + j] = g[j];
+                        for (int j = 0; j < 4 * W4; ++j) buf[j] = j < NX ? ov[j] : (j == NX ? epr : (j == NX + 1 ? __int_as_float(epl) : 0.f));
+#pragma unroll
+                        for (int q = 0; q < W4; ++q)
+                            reinterpret_cast<v4*>(rec)[q] = v4{buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]};
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NX; ++j) rec[j] = ov[j];
+                        if (OBS && p.obs_goal_horizon > 0) {
+                            if (tracking) {
+                                for (int k = 0; k < p.obs_goal_horizon; ++k) {
+                                    float g[NX];
+                                    load_goal<NX>(p, ref, s_tab, t + 1 + k, g);
+#pragma unroll
+                                    for (int j = 0; j < NX; ++j) rec[NX * (1 + k) + j] = g[j];
+                                }
+                                od = NX * (1 + p.obs_goal_horizon);
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < NX; ++j) rec[NX + j] = tb->x_goal[j];
+                                od = 2 * NX;
                             }
-                            od = NX * (1 + p.obs_goal_horizon);
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < NX; ++j) rec[NX + j] = tb->x_goal[j];
-                            od = 2 * NX;
                         }
+                        rec[od] = epr;
+                        rec[od + 1] = __int_as_float(epl);
                     }
-                    rec[od] = epr;
-                    rec[od + 1] = __int_as_float(epl);
                 }
             }
         }
