@@ -166,12 +166,12 @@ __device__ __forceinline__ void integrate(const PhysT<T>& c, uint32_t flags, con
 
 // ---- mixed-precision step of the 3-D quadrotor ("attitude" precise mode) ---------------------------------------------
 // The open-loop drift of the float32 step is born in the rotational chain (torque -> rate -> attitude) and amplified by the
-// thrust direction; the translational chain only integrates it (tools/precise_mode_study.py: float32 positions and
+// thrust direction; the translational chain only integrates it (tests/studies/precise_mode_study.py: float32 positions and
 // velocities + float64 attitude and rates hold 2e-6 over 1000 open-loop steps, float32 everything 2e-1).  So: attitude and
 // rates (states 6..11) ACCUMULATE in double -- hi + lo float32 planes in memory, RK4 combination in double --, positions and
 // velocities (states 0..5) in float.
 //
-// Which arithmetic has to be double was measured too (tools/precise_mode_study.py, "arithmetic" rows, on the hover and on the
+// Which arithmetic has to be double was measured too (tests/studies/precise_mode_study.py, "arithmetic" rows, on the hover and on the
 // circle-tracking scenario): what integrates into the drift is a BIASED error -- the cancellation of the thrusts in the torques
 // (u0 + u1 - u2 - u3 ...), the products of the rate equations, and the products  R(:, 2) T/m - g  of the acceleration (in
 // float32: 3.2e-5 at 1000 steps of circle tracking) --, while the rounding of sin / cos themselves and of the Euler-rate

@@ -15,8 +15,8 @@
 // episode publish their env index, every lane evaluates one Philox block for one (env, block) job,
 // the uniforms return through LDS.  Batch reductions (reward sum, done / violation counts,
 // finished-episode returns) use wavefront shuffles and one atomic per wave.  No MFMA: a 12-state ODE
-// per lane has no contraction worth a matrix core; the kernel is co-bound by HBM bandwidth and VALU
-// issue.
+// per lane has no contraction worth a matrix core; the kernel is bound by HBM bandwidth (696 VALU
+// instructions per env-step leave the issue floor 4 us under the memory floor: DESIGN.md section 4).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -602,7 +602,7 @@ enum Feat : uint32_t {
                      // tier.  Normalised actions are a wave-uniform run-time branch of EVERY tier.
     FT_GOAL = 32u,   // FT_INFO + an obs buffer WITHOUT any disturbance: the noise-free goal-horizon observation of the usual RL
                      // configuration (rl_reward, obs_goal_horizon >= 1).  Its own tier because the disturbance tier carries the
-                     // Philox / Box-Muller code and 30 more VGPRs although this configuration draws nothing (36.0 -> 3x.x us at 2^20 envs).
+                     // Philox / Box-Muller code and 32 more VGPRs (93 vs 61) although this configuration draws nothing.
     FT_INFO = 8u,    // the per-step info outputs of the default API (info_level='full'): mse / goal_reached /
                      // truncated / terminal_record (terminal obs = the state: obs aliases it in this tier).  A tier of its
                      // own because it is what make() gives by default: 43 us in the EXTRA tier at 2^20 envs.

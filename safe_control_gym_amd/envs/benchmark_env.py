@@ -179,7 +179,7 @@ class BenchmarkEnv:
             return int(os.environ.get(env_name, default)) if value is None else int(value)
         self.ROLLOUT_QUEUES = _knob(rollout_queues, 'SCG_ROLLOUT_QUEUES', 0)        # 0 = library default (2)
         self.ROLLOUT_SPLIT_MIN = _knob(rollout_split_min, 'SCG_ROLLOUT_SPLIT_MIN', 0)
-        self.REF_IN_LDS = _knob(ref_in_lds, 'SCG_REF_IN_LDS', -1)                   # -1: by configuration (_make_engine), 0 / 1: forced
+        self.REF_IN_LDS = _knob(ref_in_lds, 'SCG_REF_IN_LDS', 0)
         self.GRID_CAP_PER_CU = _knob(grid_cap_per_cu, 'SCG_GRID_CAP_PER_CU', 0)
         self.ROLLOUT_GRAPH = _knob(rollout_graph, 'SCG_ROLLOUT_GRAPH', 0)           # 0 / 1: hipGraph replay of small-batch rollouts; -1 off
         self.PLANE_PAD = _knob(plane_pad, 'SCG_LD_PAD', 17)                         # units of 64 lanes (256 B)
@@ -402,10 +402,7 @@ class BenchmarkEnv:
         cfg.env_index_base = self.ENV_INDEX_BASE
         cfg.rollout_queues = self.ROLLOUT_QUEUES
         cfg.rollout_split_min = self.ROLLOUT_SPLIT_MIN
-        # X_GOAL staged in LDS pays when every lane gathers TWO sets of rows per step (the error row and the goal-horizon rows of the
-        # observation): 36.0 -> 34.0 us at 2^20 envs; with the error row alone the cached gather is faster
-        cfg.ref_in_lds = self.REF_IN_LDS if self.REF_IN_LDS >= 0 else int(
-            self.TASK == Task.TRAJ_TRACKING and self.COST == Cost.RL_REWARD and self.obs_goal_horizon > 0)
+        cfg.ref_in_lds = self.REF_IN_LDS
         cfg.grid_cap_per_cu = self.GRID_CAP_PER_CU
         cfg.rollout_graph = self.ROLLOUT_GRAPH
         self._fill_system_config(cfg)

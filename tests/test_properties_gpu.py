@@ -609,6 +609,26 @@ def test_non_finite_actions(gpu):
     env.close()
 
 
+@pytest.mark.parametrize('physics', ['pyb', 'euler'])
+def test_non_finite_velocity_ends_the_episode_in_the_same_step(gpu, physics):
+    """The reference bounds velocities and rates with +-float32 max (quadrotor.py:742-791): only a non-finite value violates them
+    (inf > f32max).  The RK4 kernel skips those compares because a non-finite velocity reaches the bounded position within the
+    same step; explicit Euler advances the position with the OLD velocity, so there every dim keeps its compare: in
+    both integrators the env whose velocity is set to inf is done after THIS step, as in the reference."""
+    n = 256
+    env = scg.make('quadrotor', quad_type=3, num_envs=n, device='cuda', seed=3, randomized_init=True, task='traj_tracking',
+                   cost='quadratic', physics=physics, info_level='minimal')
+    env.reset()
+    hover = torch.as_tensor(np.tile(np.asarray(env.U_GOAL, dtype=np.float32), (n, 1)), device='cuda')
+    env.state[3, 1] = float('inf')           # x velocity
+    env.state[4, 11] = float('-inf')         # yaw rate
+    env.state[5, 5] = float('nan')           # z velocity
+    obs, rew, done, _ = env.step(hover)
+    assert bool(done[3]) and bool(done[4]) and bool(done[5])
+    assert int(done.sum()) == 3 and torch.isfinite(obs).all()
+    env.close()
+
+
 def test_rollout_is_capturable_in_a_hip_graph(gpu):
     """env.rollout() with one launch queue only enqueues kernels on the current stream, so it can be captured in a HIP graph
     (torch.cuda.graph) and replayed: the replay leaves the same buffers as the plain call.  The reset serials are kernel
