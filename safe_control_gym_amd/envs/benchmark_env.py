@@ -159,6 +159,7 @@ class BenchmarkEnv:
         # (an obs buffer apart from the state planes: +4 obs_dim bytes of stores per env-step, no copy kernel); the precise
         # modes, whose kernels are not built with a separate obs buffer, clone the views instead
         self._fresh_outputs = False          # decided in _alloc_buffers
+        self._handed_out = False             # fresh-output mode: a tensor of the engine's buffer table went out through step() / reset()
         self._pingpong = False
         # precise mode: state kept as hi + lo float32 planes and integrated in float64.  True / 'full':
         # every state; 'attitude' (3-D quadrotor): residual planes and float64 arithmetic for the rotational chain only
@@ -784,8 +785,9 @@ class BenchmarkEnv:
         load_state_dict) first gives the engine private copies of everything the last ``step()`` / ``reset()`` handed out --
         the state buffer in ping-pong mode (it IS the last observation), a kernel-written observation buffer (observation
         disturbance), and the reward / done tensors -- so that a tensor, once returned, is never written again."""
-        if not self._fresh_outputs:
-            return
+        if not self._fresh_outputs or not self._handed_out:
+            return                      # nothing of the engine's buffers is in a caller's hands (e.g. rollout() after rollout())
+        self._handed_out = False
         b = self._bufs
         if self._pingpong:
             if 'obs' in b:
@@ -829,6 +831,7 @@ class BenchmarkEnv:
         self._engine.reset(rb, m, self._reset_state_buf, self._serial, self.num_envs, self._ld)
         self._bound = False
         self._serial += 1
+        self._handed_out = True
         obs = self._obs_view()
         if self.COPY_OUTPUTS and not self._pingpong:          # ping-pong: nobody writes this buffer again (_own_state)
             obs = obs.clone()
@@ -934,6 +937,7 @@ class BenchmarkEnv:
                 self._bound = True
             self._engine.step_bound(act, self.num_envs, self._serial, action_rows=rows, outs=outs, state_out=new_state)
         self._serial += 1
+        self._handed_out = True
         if new_state is not None:
             if 'obs' in b:
                 b['obs'] = new_state

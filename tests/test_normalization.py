@@ -151,6 +151,8 @@ def test_normalizer_c_abi_validation(gpu):
     assert lib.scg_mean_std_normalize(p(x), p(x), 4, 64, 64, 10, p(st[0]), p(st[1]), None, 10.0, 1e-8, None) < 0      # no scratch
     assert lib.scg_mean_std_normalize(p(x), p(x), 0, 64, 64, 10, p(st[0]), p(st[1]), p(mom), 10.0, 1e-8, None) < 0
     assert lib.scg_mean_std_normalize(p(x), p(x), 4, 64, 64, 0, p(st[0]), p(st[1]), p(mom), 10.0, 1e-8, None) == 0    # empty batch
+    assert lib.scg_mean_std_normalize(p(x), None, 4, 64, 0, 10, p(st[0]), p(st[1]), p(mom), 0.0, 0.0, None) == 0        # y == NULL: moments only
+    assert lib.scg_mean_std_normalize(p(x), None, 4, 64, 0, 10, p(st[0]), None, None, 0.0, 0.0, None) < 0              # ... needs state_out
     assert lib.scg_reward_normalize(p(x), None, None, p(x), 10, p(st[0]), p(st[1]), p(mom), 0.99, 10.0, 1e-8, 0, None) < 0
     assert lib.scg_reward_normalize(p(x), None, None, p(x), 10, p(st[0]), None, None, 0.99, 10.0, 1e-8, 0, None) == 0   # read-only
 
@@ -169,7 +171,18 @@ def test_running_mean_std_update_methods_match_oracle(gpu):
         assert np.abs(dev.mean.cpu().numpy() - ref.mean).max() <= 1e-6 * max(1.0, np.abs(ref.mean).max())
         assert np.abs(dev.var.cpu().numpy() - ref.var).max() <= 1e-5 * max(1.0, np.abs(ref.var).max())
         assert abs(float(dev.count) - ref.count) <= 1e-9
+    # an [N, d] view of SoA planes (what env.step() hands out) is read in place: same statistics as the row-major copy
+    planes = torch.as_tensor((rng.normal(size=(5, 4096 + 64)) * 3 + 1).astype(np.float32), device='cuda')
+    view = planes[:, :4000].T
+    assert view.stride(0) == 1
+    dev.update(view)
+    ref.update(view.cpu().numpy().astype(np.float64))
+    assert np.abs(dev.mean.cpu().numpy() - ref.mean).max() <= 1e-6 * max(1.0, np.abs(ref.mean).max())
+    assert np.abs(dev.var.cpu().numpy() - ref.var).max() <= 1e-5 * max(1.0, np.abs(ref.var).max())
     bm, bv = rng.normal(size=5), rng.uniform(0.5, 2.0, size=5)
+    dev.update_from_moments(torch.as_tensor(bm, device='cuda'), torch.as_tensor(bv, device='cuda'), torch.tensor(17.0, device='cuda'))   # stays on the device
+    ref.update_from_moments(bm, bv, 17)
+    assert np.abs(dev.mean.cpu().numpy() - ref.mean).max() <= 1e-6 * max(1.0, np.abs(ref.mean).max())
     dev.update_from_moments(bm, bv, 17)
     ref.update_from_moments(bm, bv, 17)
     assert np.abs(dev.mean.cpu().numpy() - ref.mean).max() <= 1e-6 * max(1.0, np.abs(ref.mean).max())

@@ -659,7 +659,7 @@ def test_rollout_is_capturable_in_a_hip_graph(gpu):
     a.close(), b.close()
 
 
-@pytest.mark.parametrize('system', ['cartpole', 2, 3])
+@pytest.mark.parametrize('system', ['cartpole', 2, 3, 'noisy'])
 def test_rollout_graph_replay_is_bit_identical_to_plain_launches(gpu, system):
     """Small batches: scg_rollout captures the launches of a signature it sees for the second time into a hipGraph and replays it
     (scg_config.rollout_graph).  The step serial travels through a device word, so the Philox reset draws are those of plain
@@ -670,6 +670,13 @@ def test_rollout_graph_replay_is_bit_identical_to_plain_launches(gpu, system):
               info_level='minimal', track_episode_stats=True)
     if system == 'cartpole':
         mk = lambda **e: scg.make('cartpole', task='stabilization', cost='quadratic', **kw, **e)
+    elif system == 'noisy':
+        # the disturbance tier draws its noise from Philox streams keyed by the step serial BEFORE the state advance: the serial
+        # word of a replayed launch must be there in time (plus a per-episode impulse offset: episode ids = reset serials)
+        dist = {'action': [{'disturbance_func': 'white_noise', 'std': 0.002}],
+                'observation': [{'disturbance_func': 'white_noise', 'std': 0.01}],
+                'dynamics': [{'disturbance_func': 'impulse', 'magnitude': 0.01, 'step_offset': None, 'duration': 3, 'decay_rate': 0.8}]}
+        mk = lambda **e: scg.make('quadrotor', quad_type=2, task='stabilization', cost='rl_reward', disturbances=dist, **kw, **e)
     else:
         mk = lambda **e: scg.make('quadrotor', quad_type=system, task='traj_tracking', cost='rl_reward', **kw, **e)
     plain, graphed = mk(rollout_graph=-1), mk()
@@ -682,8 +689,9 @@ def test_rollout_graph_replay_is_bit_identical_to_plain_launches(gpu, system):
 
     def same(tag):
         torch.cuda.synchronize()
-        for key in ('state', 'step_count', 'ep_return', 'reward', 'done'):
-            assert torch.equal(plain._bufs[key], graphed._bufs[key]), (tag, key)
+        for key in ('state', 'step_count', 'ep_return', 'reward', 'done', 'obs', 'episode_id'):
+            if key in plain._bufs:
+                assert torch.equal(plain._bufs[key], graphed._bufs[key]), (tag, key)
 
     for call in range(4):                                  # plain, capture + replay, replay, replay
         plain.rollout(acts, steps=24), graphed.rollout(acts, steps=24)
