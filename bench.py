@@ -216,9 +216,9 @@ def build_env(args, workload, rank, n, track, extra=None):
     survey = 8 * nx + 4 * nu + 13                            # read state, action, t; write state, rew, done, t
     moved = survey
     if env.COMPENSATED_STATE:
-        n_lo = 6 if env.COMPENSATED_STATE == 'attitude' else nx
-        survey += 8 * n_lo                                   # residual planes ("Kahan residual +8 nx")
-        moved += 8 * n_lo
+        lo = env.residual_planes                             # [nx | 6][ld] float32, or int16 in the attitude mode
+        survey += 8 * lo.shape[0]                            # residual planes ("Kahan residual +8 nx")
+        moved += 2 * lo.element_size() * lo.shape[0]
     if track:
         survey += 16                                         # ep_return + ep_length read-modify-write (141 B for C5)
         moved += 8                                           # the engine has no ep_length plane under auto-reset
@@ -572,8 +572,8 @@ def run_rank(args):
                  'mode that meets <= 1e-5 state drift over 1000 open-loop steps (tests/test_parity_gpu.py::test_precise_mode_open_loop_1000_step_drift)')
         out['precise_mode_attitude'] = sub_record(
             args, timer, 'c4', n, sub_steps, extra={'compensated_state': 'attitude'},
-            note="compensated_state='attitude': residual planes and float64 arithmetic for attitude + body rates only (states "
-                 '6..11), float32 positions / velocities; same drift bound '
+            note="compensated_state='attitude': int16 residual planes (40 significant bits) and double accumulation for attitude + body "
+                 'rates only (states 6..11), float32 sin / cos and positions / velocities; same drift bound, measured on hover and on this workload '
                  '(tests/test_parity_gpu.py::test_precise_mode_open_loop_1000_step_drift)')
         out['c3'] = sub_record(args, timer, 'c3', 1 << 18, max(sub_steps, 1000))
         out['c2'] = sub_record(args, timer, 'c2', 1 << 16, max(sub_steps, 1000))

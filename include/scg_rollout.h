@@ -224,10 +224,13 @@ typedef struct scg_step_io {
                                         0 sum reward, 1 #done, 2 #violation, 3 sum finished returns,
                                         4 sum finished lengths, 5 #truncated, 6-7 reserved */
     uint32_t reset_serial;           /* Philox counter word for resets happening in this call */
-    uint32_t state_lo_kind;          /* which states state_lo holds residuals for: 0 = all nx (planes [nx][ld]); 1 = the
-                                        rotational chain of the 3-D quadrotor only, states 6..11 as planes [6][ld] -- positions
-                                        and velocities are then integrated in float32, attitude and rates in float64
-                                        ("attitude" precise mode: 48 B per env-step less; lean and info tiers only) */
+    uint32_t state_lo_kind;          /* which states state_lo holds residuals for: 0 = all nx (float planes [nx][ld]); 1 = the
+                                        rotational chain of the 3-D quadrotor only, states 6..11 as float planes [6][ld] -- positions
+                                        and velocities are then kept in float32, attitude and rates accumulate in float64
+                                        ("attitude" precise mode: 48 B per env-step less; lean and info tiers only); 2 = the same
+                                        with the residuals as int16 planes ((int16_t*)state_lo, [6][ld], 2-byte aligned): state =
+                                        hi + lo 2^(e - 40) where hi = f 2^e, f in [1/2, 1), i.e. lo counts 2^-16 ulp(hi) -- 40
+                                        significant bits, 24 B per env-step less again */
 } scg_step_io;
 
 /* One entry of a DisturbanceList (envs/disturbances.py:46-84), evaluated inside the step kernel.

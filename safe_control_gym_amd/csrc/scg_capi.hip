@@ -625,13 +625,15 @@ int scg_step(scg_handle* h, const scg_step_io* io, int64_t n, void* stream) {
     if (io->action_rows > 1 || (io->action_rows && (reinterpret_cast<uintptr_t>(io->action) % (4u * h->nu)) != 0))
         return fail(SCG_ERR_INVALID, "scg_step: row-major actions must be %d-byte aligned (action_rows in {0, 1})", 4 * h->nu);
     if (int rc = check_dist_io(h, io, "scg_step")) return rc;
-    if (io->state_lo_kind > 1) return fail(SCG_ERR_INVALID, "scg_step: state_lo_kind must be 0 or 1");
-    if (io->state_lo && io->state_lo_kind == 1) {
+    if (io->state_lo_kind > 2) return fail(SCG_ERR_INVALID, "scg_step: state_lo_kind must be 0, 1 or 2");
+    if (io->state_lo && io->state_lo_kind == 2 && (reinterpret_cast<uintptr_t>(io->state_lo) & 1u))
+        return fail(SCG_ERR_INVALID, "scg_step: int16 residual planes (state_lo_kind = 2) must be 2-byte aligned");
+    if (io->state_lo && io->state_lo_kind >= 1) {
         if (h->system != SCG_QUAD_3D)
-            return fail(SCG_ERR_UNSUPPORTED, "scg_step: attitude-only residual planes (state_lo_kind = 1) are defined for the 3-D quadrotor");
+            return fail(SCG_ERR_UNSUPPORTED, "scg_step: attitude-only residual planes (state_lo_kind = 1, 2) are defined for the 3-D quadrotor");
         if (h->kp.dist || io->obs || io->inertial || io->action_disturbance || io->dynamics_force || io->stats || io->episode_id ||
             (h->kp.flags & (F_GND | F_DRAG | F_RAND_GENERAL)) || !(h->kp.flags & F_Q_DIAG))
-            return fail(SCG_ERR_UNSUPPORTED, "scg_step: state_lo_kind = 1 supports the lean and info configurations only "
+            return fail(SCG_ERR_UNSUPPORTED, "scg_step: state_lo_kind = 1 / 2 supports the lean and info configurations only "
                                              "(no disturbances, aero terms, per-env inertia, full Q / R, obs buffer)");
     }
     if (n == 0) return SCG_OK;
@@ -653,6 +655,8 @@ static scg_step_io shifted_io(const scg_step_io& io, int64_t first) {
     s.inertial = const_cast<float*>(f32(io.inertial));
     s.state = const_cast<float*>(f32(io.state));
     s.state_lo = const_cast<float*>(f32(io.state_lo));
+    if (io.state_lo && io.state_lo_kind == 2)                            // int16 planes: `first` elements are 2 bytes each
+        s.state_lo = reinterpret_cast<float*>(reinterpret_cast<int16_t*>(io.state_lo) + first);
     s.step_count = io.step_count ? io.step_count + first : nullptr;
     s.ep_return = const_cast<float*>(f32(io.ep_return));
     s.ep_length = io.ep_length ? io.ep_length + first : nullptr;

@@ -173,17 +173,31 @@ __device__ __forceinline__ void integrate(const PhysT<T>& c, uint32_t flags, con
 //
 // Which arithmetic has to be double was measured too (tests/studies/precise_mode_study.py, "arithmetic" rows, on the hover and on the
 // circle-tracking scenario): what integrates into the drift is a BIASED error -- the cancellation of the thrusts in the torques
-// (u0 + u1 - u2 - u3 ...), the products of the rate equations, and the products  R(:, 2) T/m - g  of the acceleration (in
-// float32: 3.2e-5 at 1000 steps of circle tracking) --, while the rounding of sin / cos themselves and of the Euler-rate
-// kinematics to float32 averages out (3.4e-6 against 2.9e-6 with everything in double).  Hence (default,
-// SCG_ATT_FP64_TRIG = 0): inputs (T/m, torques), the body-rate derivatives and the acceleration products in double; sin / cos
-// of the float32-rounded stage angles and the Euler-rate kinematics in float32 (sincos_f of scg_math.h: 22 instead of ~40
-// instructions per pair), converted once.  SCG_ATT_FP64_TRIG = 1 is round 2's form (12 float64 sin/cos pairs per step).
+// (u0 + u1 - u2 - u3 ...), the products of the rate equations, and the vertical acceleration  c_theta c_phi T/m - g  with T/m and
+// g ROUNDED to float32 (3.2e-5 at 1000 steps of circle tracking) --, while the rounding of sin / cos themselves, of their
+// products and of the Euler-rate kinematics to float32 averages out (3.3e-6 against 2.9e-6 with everything in double).  Hence
+// (default, SCG_ATT_FP64_TRIG = 0): inputs (T/m, torques) and the body-rate derivatives in double; sin / cos of the
+// float32-rounded stage angles, the Euler-rate kinematics and the acceleration in float32 (sincos_f of scg_math.h: 22 instead
+// of ~40 instructions per pair), with T/m and Fz/m - g entering the vertical channel as double-float pairs (MixedInputs).  SCG_ATT_FP64_TRIG = 1 is round 2's form (12 float64 sin/cos pairs per step).
 #ifndef SCG_ATT_FP64_TRIG
 #define SCG_ATT_FP64_TRIG 0
 #endif
-__device__ __forceinline__ void f_mixed3d(const PhysT<double>& c, const Inputs<SCG_QUAD_3D, double>& in, const float (&xt)[6],
-                                          const double (&xa)[6], float (&dt)[6], double (&da)[6]) {
+// float32 images of the double inputs the float32 part of f_mixed3d needs, formed once per (sub-)step: the specific thrust and
+// the vertical offset  Fz/m - g  as double-float pairs (hi + lo) -- the vertical channel is where a constant rounding error would
+// be born (c_theta c_phi T/m - g with T/m ~ g) --, the horizontal offsets as plain floats.
+struct MixedInputs {
+    float Tm_hi, Tm_lo, az_hi, az_lo, ax, ay;
+};
+__device__ __forceinline__ MixedInputs mixed_inputs(const Inputs<SCG_QUAD_3D, double>& in) {
+    MixedInputs m;
+    m.Tm_hi = (float)in.Tm; m.Tm_lo = (float)(in.Tm - (double)m.Tm_hi);
+    m.az_hi = (float)in.az; m.az_lo = (float)(in.az - (double)m.az_hi);
+    m.ax = (float)in.ax; m.ay = (float)in.ay;
+    return m;
+}
+
+__device__ __forceinline__ void f_mixed3d(const PhysT<double>& c, const Inputs<SCG_QUAD_3D, double>& in, const MixedInputs& mi,
+                                          const float (&xt)[6], const double (&xa)[6], float (&dt)[6], double (&da)[6]) {
     const double P = xa[3], Q = xa[4], R = xa[5];
 #if SCG_ATT_FP64_TRIG
     double sph, cph, sth, cth, sps, cps;
@@ -208,16 +222,14 @@ __device__ __forceinline__ void f_mixed3d(const PhysT<double>& c, const Inputs<S
     sincos_f((float)xa[1], sth, cth);
     sincos_f((float)xa[2], sps, cps);
     const float Qf = (float)Q, Rf = (float)R;
-    {
-        const double dsph = sph, dcph = cph, dsth = sth, dcth = cth, dsps = sps, dcps = cps;
-        const double sthcph = dsth * dcph;
-        dt[0] = xt[1];
-        dt[1] = (float)fma(fma(dcps, sthcph, dsps * dsph), in.Tm, in.ax);
-        dt[2] = xt[3];
-        dt[3] = (float)fma(fma(dsps, sthcph, -(dcps * dsph)), in.Tm, in.ay);
-        dt[4] = xt[5];
-        dt[5] = (float)fma(dcth * dcph, in.Tm, in.az);
-    }
+    const float sthcph = sth * cph, cthcph = cth * cph;
+    dt[0] = xt[1];
+    dt[1] = fmaf(fmaf(cps, sthcph, sps * sph), mi.Tm_hi, mi.ax);
+    dt[2] = xt[3];
+    dt[3] = fmaf(fmaf(sps, sthcph, -(cps * sph)), mi.Tm_hi, mi.ay);
+    dt[4] = xt[5];
+    // the vertical channel:  c_theta c_phi (Tm_hi + Tm_lo) + (az_hi + az_lo), each FMA rounding a SMALL result once
+    dt[5] = fmaf(cthcph, mi.Tm_hi, mi.az_hi) + fmaf(cthcph, mi.Tm_lo, mi.az_lo);
     const float rcth = rcp_f(cth);
     const float w = fmaf(sph, Qf, cph * Rf);
     da[0] = (double)(sth * rcth * w) + P;                 // the rate itself enters in double
@@ -233,9 +245,10 @@ __device__ __forceinline__ void integrate_mixed3d(const PhysT<double>& c, uint32
                                                   float (&xt)[6], double (&xa)[6]) {
     const double h = c.h;
     const float hf = (float)h;
+    const MixedInputs mi = mixed_inputs(in);
     float kt[6];
     double ka[6];
-    f_mixed3d(c, in, xt, xa, kt, ka);
+    f_mixed3d(c, in, mi, xt, xa, kt, ka);
     if (flags & F_EULER) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) { xt[j] = fmaf(hf, kt[j], xt[j]); xa[j] = fma(h, ka[j], xa[j]); }
@@ -247,13 +260,13 @@ __device__ __forceinline__ void integrate_mixed3d(const PhysT<double>& c, uint32
     const float hhf = 0.5f * hf;
 #pragma unroll
     for (int j = 0; j < 6; ++j) { at[j] = kt[j]; aa[j] = ka[j]; st[j] = fmaf(hhf, kt[j], xt[j]); sa[j] = fma(hh, ka[j], xa[j]); }
-    f_mixed3d(c, in, st, sa, kt, ka);
+    f_mixed3d(c, in, mi, st, sa, kt, ka);
 #pragma unroll
     for (int j = 0; j < 6; ++j) { at[j] = fmaf(2.0f, kt[j], at[j]); aa[j] = fma(2.0, ka[j], aa[j]); st[j] = fmaf(hhf, kt[j], xt[j]); sa[j] = fma(hh, ka[j], xa[j]); }
-    f_mixed3d(c, in, st, sa, kt, ka);
+    f_mixed3d(c, in, mi, st, sa, kt, ka);
 #pragma unroll
     for (int j = 0; j < 6; ++j) { at[j] = fmaf(2.0f, kt[j], at[j]); aa[j] = fma(2.0, ka[j], aa[j]); st[j] = fmaf(hf, kt[j], xt[j]); sa[j] = fma(h, ka[j], xa[j]); }
-    f_mixed3d(c, in, st, sa, kt, ka);
+    f_mixed3d(c, in, mi, st, sa, kt, ka);
     const double h6 = h * (1.0 / 6.0);
     const float h6f = (float)h6;
 #pragma unroll

@@ -658,6 +658,9 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
     }
 
     const int64_t ld = io.ld;
+    // attitude precise mode: the residuals travel as float32 planes (state_lo_kind = 1) or as int16 planes in units of 2^-16 ulp(hi)
+    // (kind 2: 40 significant bits per state, 24 B instead of 48 B per env-step; wave-uniform choice)
+    const bool lo16 = COMP == 2 && io.state_lo_kind == 2u;
     float st_rew = 0.f, st_done = 0.f, st_viol = 0.f, st_fret = 0.f, st_flen = 0.f, st_trunc = 0.f;
 
     // Per-lane inputs of one env.  With SCG_PREFETCH the next grid-stride iteration's inputs are
@@ -691,7 +694,15 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         L.t = ldp(io.step_count, b4);                                       // ctrl_step_counter (pre-increment)
         if (COMP) {
 #pragma unroll
-            for (int j = 0; j < NLO; ++j) L.xlo[j] = ldp(PL(io.state_lo, j), b4);
+            for (int j = 0; j < NLO; ++j) {
+                if (COMP == 2 && lo16) {
+                    // int16 residual planes (state_lo_kind = 2): plane j at (int16_t*)state_lo + j * ld, lane offset 2 i
+                    const int16_t* base = uptr(reinterpret_cast<const int16_t*>(io.state_lo) + (int64_t)j * ld);
+                    L.xlo[j] = __int_as_float((int)ldp(base, idx * 2u));          // the integer count, carried in the float slot
+                } else {
+                    L.xlo[j] = ldp(PL(io.state_lo, j), b4);
+                }
+            }
         }
         L.epr = 0.f; L.epl = 0;
         if (io.ep_return) L.epr = ldp(io.ep_return, b4);
@@ -841,13 +852,32 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                 float xt[6];
                 double xa[6];
 #pragma unroll
-                for (int j = 0; j < 6; ++j) { xt[j] = x[j]; xa[j] = (double)x[LO0 + j] + (double)xlo[j]; }
+                for (int j = 0; j < 6; ++j) {
+                    xt[j] = x[j];
+                    // hi + lo: lo is a float, or an integer count of 2^(e - 40) where hi = f 2^e, f in [1/2, 1)  (ulp(hi) = 2^(e - 24))
+                    // (the unit 2^(e - 40) is assembled from its exponent field: v_ldexp_f64 / v_rndne_f64 are slow paths)
+                    if (lo16) {
+                        const int e = __builtin_amdgcn_frexp_expf(x[LO0 + j]);
+                        xa[j] = fma((double)__float_as_int(xlo[j]), __hiloint2double((e - 40 + 1023) << 20, 0), (double)x[LO0 + j]);
+                    } else {
+                        xa[j] = (double)x[LO0 + j] + (double)xlo[j];
+                    }
+                }
                 for (int s = 0; s < p.substeps; ++s) integrate_mixed3d(ph, p.flags, in, xt, xa);
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
                     x[j] = xt[j];
                     x[LO0 + j] = (float)xa[j];
-                    xlo[j] = (float)(xa[j] - (double)x[LO0 + j]);
+                    const double d = xa[j] - (double)x[LO0 + j];                  // exact; |d| <= ulp(hi) / 2
+                    if (lo16) {
+                        // q = rint(d 2^(40 - e)), |q| <= 2^15: the product is exact, adding 1.5 2^52 rounds it to an integer whose
+                        // two's complement sits in the low word of the sum
+                        const int e = __builtin_amdgcn_frexp_expf(x[LO0 + j]);
+                        const int q = __double2loint(fma(d, __hiloint2double((40 - e + 1023) << 20, 0), 6755399441055744.0));
+                        xlo[j] = __int_as_float(min(max(q, -32768), 32767));                               // (a non-finite state is out of bounds anyway)
+                    } else {
+                        xlo[j] = (float)d;
+                    }
                 }
             } else if (sizeof(RT) == 8) {
                 RT xd[NX];
@@ -1108,7 +1138,14 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
             for (int j = 0; j < NX; ++j) stp(PLS(io.state_out ? io.state_out : io.state, j), i4, x[j]);   // in place or ping-pong
             if (COMP) {
 #pragma unroll
-                for (int j = 0; j < NLO; ++j) stp(PLS(io.state_lo, j), i4, xlo[j]);
+                for (int j = 0; j < NLO; ++j) {
+                    if (COMP == 2 && lo16) {
+                        int16_t* base = uptr(reinterpret_cast<int16_t*>(io.state_lo) + (int64_t)j * opaque_s(ld));
+                        stp(base, i * 2u, (int16_t)__float_as_int(xlo[j]));
+                    } else {
+                        stp(PLS(io.state_lo, j), i4, xlo[j]);
+                    }
+                }
             }
             stp(io.step_count, i4, t_out);
             if (io.ep_return) stp(io.ep_return, i4, epr);
@@ -1401,7 +1438,7 @@ template <int SYS>
 static bool launch_step_sys(LaunchGeom g, const KParams& p, const scg_step_io& io, const KTables* tb,
                             const ConTable* ct, const float* ref, uint32_t n, int num_cus, hipStream_t s) {
     const uint32_t ft = features_needed(p, io);
-    if (io.state_lo && io.state_lo_kind == 1) {
+    if (io.state_lo && (io.state_lo_kind == 1 || io.state_lo_kind == 2)) {
         if constexpr (SYS == SCG_QUAD_3D) return launch_step_ft<SYS, 2>(ft, g, p, io, tb, ct, ref, n, s);
         else return false;
     }

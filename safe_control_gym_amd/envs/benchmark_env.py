@@ -161,17 +161,20 @@ class BenchmarkEnv:
         self._fresh_outputs = False          # decided in _alloc_buffers
         self._handed_out = False             # fresh-output mode: a tensor of the engine's buffer table went out through step() / reset()
         self._pingpong = False
-        # precise mode: state kept as hi + lo float32 planes and integrated in float64.  True / 'full':
-        # every state; 'attitude' (3-D quadrotor): residual planes and float64 arithmetic for the rotational chain only
-        # (attitude + body rates), float32 positions and velocities -- 48 B per env-step less, same <= 1e-5 drift bound
+        # precise mode: state kept as hi + lo planes and accumulated in float64.  True / 'full': every state,
+        # float32 residual planes, float64 arithmetic throughout; 'attitude' (3-D quadrotor): residual planes and double
+        # accumulation for the rotational chain only (attitude + body rates), float32 positions and velocities, the residuals as
+        # int16 planes in units of 2^-16 ulp(hi) (40 significant bits) -- 72 B per env-step less than 'full', same <= 1e-5 drift
+        # bound; 'attitude_f32': the same with float32 residual planes (48 B less than 'full'; scg_step_io.state_lo_kind = 1)
         if compensated_state in (True, 'full'):
             self.COMPENSATED_STATE = 'full'
-        elif compensated_state == 'attitude':
+        elif compensated_state in ('attitude', 'attitude_f32'):
             self.COMPENSATED_STATE = 'attitude'
         elif not compensated_state:
             self.COMPENSATED_STATE = False
         else:
-            raise ValueError("[ERROR] compensated_state must be False, True / 'full' or 'attitude'.")
+            raise ValueError("[ERROR] compensated_state must be False, True / 'full', 'attitude' or 'attitude_f32'.")
+        self.RESIDUAL_DTYPE = torch.float32 if compensated_state == 'attitude_f32' or self.COMPENSATED_STATE == 'full' else torch.int16
         self.TRACK_EPISODE_STATS = bool(track_episode_stats)
         self.ENV_INDEX_BASE = int(env_index_base)
         # launch policy of this env's handle (scg_config fields; the SCG_* environment variables are only the defaults
@@ -443,7 +446,7 @@ class BenchmarkEnv:
         if self.COMPENSATED_STATE == 'attitude':
             if self.SYSTEM != _capi.SCG_QUAD_3D:
                 raise ValueError("[ERROR] compensated_state='attitude' is defined for the 3-D quadrotor (use True elsewhere).")
-            b['state_lo'] = torch.zeros((6, ld), dtype=f32, device=dev)        # residuals of states 6..11
+            b['state_lo'] = torch.zeros((6, ld), dtype=self.RESIDUAL_DTYPE, device=dev)        # residuals of states 6..11 (int16: units of 2^-16 ulp)
         elif self.COMPENSATED_STATE:
             b['state_lo'] = torch.zeros((nx, ld), dtype=f32, device=dev)
         if self.RANDOMIZED_INERTIAL_PROP:
@@ -508,6 +511,29 @@ class BenchmarkEnv:
     @property
     def state_soa(self):
         return self._bufs['state'][:, :self.num_envs]
+
+    @property
+    def residual_planes(self):
+        """The residual planes of a precise mode ([nx | 6, ld]; float32, or int16 in the attitude mode), None otherwise."""
+        self._ensure_engine()
+        return self._bufs.get('state_lo')
+
+    @property
+    def state_precise(self):
+        """[N, nx] float64: the state with its residual planes added (precise modes; the float32 state otherwise).  int16
+        residuals count 2^(e - 40) where the float32 plane value is f 2^e, f in [1/2, 1) (scg_step_io.state_lo_kind = 2)."""
+        x = self.state.double().clone()
+        lo = self._bufs.get('state_lo') if self._bufs is not None else None
+        if lo is None:
+            return x
+        lo = lo[:, :self.num_envs].T
+        first = self.state_dim - lo.shape[1]
+        if lo.dtype == torch.int16:
+            e = torch.frexp(self.state[:, first:])[1]
+            x[:, first:] += torch.ldexp(lo.double(), (e - 40))
+        else:
+            x[:, first:] += lo.double()
+        return x
 
     @property
     def action_buffer(self):
@@ -827,7 +853,7 @@ class BenchmarkEnv:
             if m is None:
                 self._bufs['state_lo'].zero_()
             else:
-                self._bufs['state_lo'][:, m.bool()] = 0.0
+                self._bufs['state_lo'][:, m.bool()] = 0
         self._engine.reset(rb, m, self._reset_state_buf, self._serial, self.num_envs, self._ld)
         self._bound = False
         self._serial += 1

@@ -88,7 +88,8 @@ class Engine:
         rec = bufs.get('terminal_record')
         io.terminal_stride = rec.shape[1] if rec is not None else 0
         lo = bufs.get('state_lo')
-        io.state_lo_kind = 1 if (lo is not None and lo.shape[0] != self.nx) else 0      # [6, ld]: attitude-only residuals
+        # [6, ld]: attitude-only residuals, as float32 (kind 1) or int16 (kind 2) planes
+        io.state_lo_kind = 0 if (lo is None or lo.shape[0] == self.nx) else (2 if lo.dtype == torch.int16 else 1)
         for name in self._IO_FIELDS:
             t = bufs.get(name)
             setattr(io, name, None if t is None else t.data_ptr())

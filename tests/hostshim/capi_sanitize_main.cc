@@ -215,6 +215,17 @@ static void check_step_and_rollout() {
     shim_reset();
     g_shim.fail_event_record_after = 1;
     EXPECT(scg_rollout(h, &b.io, n, 7, 16, 2, nullptr) == SCG_ERR_HIP && g_shim.aux_streams_open == 0 && g_shim.stream_syncs == 1);
+    // residual-plane kinds: 0 all states (float), 1 / 2 attitude-only (float / int16): 3-D quadrotor only, kind <= 2, int16 planes 2-byte aligned
+    {
+        Buffers r(n);
+        r.io.state_lo = r.f.data();
+        r.io.state_lo_kind = 3;
+        EXPECT(scg_step(h, &r.io, 8, nullptr) == SCG_ERR_INVALID);
+        r.io.state_lo_kind = 2;
+        EXPECT(scg_step(h, &r.io, 8, nullptr) == SCG_OK);                       // this handle is the 3-D quadrotor
+        r.io.state_lo = reinterpret_cast<float*>(reinterpret_cast<char*>(r.f.data()) + 1);
+        EXPECT(scg_step(h, &r.io, 8, nullptr) == SCG_ERR_INVALID);
+    }
     shim_reset();
     EXPECT(scg_rollout_fused(h, &b.io, 1000, 4, 16, 2, nullptr) == SCG_OK && g_shim.launches == 1);
     EXPECT(scg_destroy(h) == SCG_OK);

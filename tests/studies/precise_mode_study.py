@@ -96,7 +96,7 @@ def run(lo_planes, trans32, steps=1000, seeds=(5, 6, 7)):
 F32 = np.float32
 
 
-def f_parts(x, u, trig32=False, kin32=False, acc32=False, torque32=False, bias=0.0):
+def f_parts(x, u, trig32=False, kin32=False, acc32=False, torque32=False, bias=0.0, acc_df=False):
     """The derivative with chosen parts in float32 (inputs rounded, float32 operations); everything else float64.  The translational
     derivative is rounded to float32 at the end in every variant (the attitude mode stores positions / velocities in float32).
     bias: a constant relative error (1 + bias) on sin, (1 - bias) on cos."""
@@ -114,7 +114,15 @@ def f_parts(x, u, trig32=False, kin32=False, acc32=False, torque32=False, bias=0
     (sph, cph), (sth, cth), (sps, cps) = trig(ph), trig(th), trig(ps)
     if bias:
         sph, sth, sps, cph, cth, cps = sph * (1 + bias), sth * (1 + bias), sps * (1 + bias), cph * (1 - bias), cth * (1 - bias), cps * (1 - bias)
-    if acc32:
+    if acc_df:
+        # float32 products; T/m and g enter the VERTICAL channel as double-float pairs (hi + lo), each FMA rounding a small result once
+        fma32 = lambda a, b, cc: (a.astype(np.float64) * b.astype(np.float64) + cc).astype(F32)
+        Thi = c(T); Tlo = c(T - Thi.astype(np.float64)); ghi = F32(P.g); glo = F32(P.g - np.float64(ghi))
+        shc, chc = c(sth) * c(cph), c(cth) * c(cph)
+        ax = fma32(c(cps), shc, (c(sps) * c(sph)).astype(np.float64)) * Thi
+        ay = fma32(c(sps), shc, -(c(cps) * c(sph)).astype(np.float64)) * Thi
+        az = fma32(chc, Thi, -np.float64(ghi)) + fma32(chc, Tlo, -np.float64(glo))
+    elif acc32:
         ax, ay, az = (c(cps) * c(sth) * c(cph) + c(sps) * c(sph)) * c(T), (c(sps) * c(sth) * c(cph) - c(cps) * c(sph)) * c(T), c(cth) * c(cph) * c(T) - F32(P.g)
     else:
         ax, ay, az = (cps * sth * cph + sps * sph) * T, (sps * sth * cph - cps * sph) * T, cth * cph * T - P.g
@@ -175,7 +183,8 @@ ARITHMETIC_ROWS = [
     ('acceleration products R(:,2) T/m - g in float32', dict(acc32=True)),
     ('torques from float32 thrusts', dict(torque32=True)),
     ('constant bias 6e-8 on sin / cos (double arithmetic)', dict(bias=6e-8)),
-    ('SHIPPED: float32 sin / cos + kinematics, double torques / rates / acceleration products', dict(trig32=True, kin32=True)),
+    ('float32 sin / cos + kinematics, double torques / rates / acceleration products', dict(trig32=True, kin32=True)),
+    ('SHIPPED: ... and the acceleration in float32 with T/m and g as double-float pairs in the vertical channel', dict(trig32=True, kin32=True, acc_df=True)),
     ('first attempt: float32 sin / cos + kinematics + acceleration products', dict(trig32=True, kin32=True, acc32=True)),
 ]
 

@@ -379,7 +379,7 @@ def test_precise_mode_open_loop_1000_step_drift(gpu, scenario):
         rng = np.random.default_rng(6)
         x0 = None
     errs = {}
-    for comp in (False, True, 'attitude'):
+    for comp in (False, True, 'attitude', 'attitude_f32'):
         env, ref, sampler = make_pair(3, n, randomized_init=False, init_states=x0,
                                       engine_kwargs=dict(compensated_state=comp), **kw)
         sync_reset(env, ref, sampler)
@@ -398,11 +398,7 @@ def test_precise_mode_open_loop_1000_step_drift(gpu, scenario):
             f = _pd_controller(xs, hover) if scenario == 'hover' else _pd_tracking(xs, xg[min(k, xg.shape[0] - 1)], hover)
             out_e, out_r = sync_step(env, ref, sampler, f)
             assert not bool(out_e[2].any()) and not out_r[2].any()
-            xe = env.state.double()
-            if comp == 'attitude':                      # residual planes of states 6..11 only
-                xe[:, 6:] += env._bufs['state_lo'][:, :n].T.double()
-            elif comp:
-                xe = xe + env._bufs['state_lo'][:, :n].T.double()
+            xe = env.state_precise                      # hi + residual planes (all 12 float32 / states 6..11 as int16 or float32)
             worst = max(worst, rel_err(xe.cpu().numpy(), np.stack([r.state for r in ref.envs])))
             if k + 1 in (100, 300, 1000):
                 at[k + 1] = worst
@@ -413,12 +409,14 @@ def test_precise_mode_open_loop_1000_step_drift(gpu, scenario):
         else:
             assert np.abs(xs[:, [0, 2, 4]] - xg[999][[0, 2, 4]]).max() < 0.6, 'controller does not track'      # (the reference's velocity rows carry its position offset: a standing lag)
         env.close()
-    print('open-loop replay drift (%s)  float32: %s   precise (fp64 integration): %s   attitude-only residuals: %s'
-          % ((scenario,) + tuple({k: '%.1e' % v for k, v in errs[c].items()} for c in (False, True, 'attitude'))))
+    print('open-loop replay drift (%s)  float32: %s   precise (fp64 integration): %s   attitude-only residuals, int16: %s   float32: %s'
+          % ((scenario,) + tuple({k: '%.1e' % v for k, v in errs[c].items()} for c in (False, True, 'attitude', 'attitude_f32'))))
     assert errs[True][1000] <= 1e-5
     assert errs[True][1000] < errs[False][1000]
     # double accumulation of attitude / rates on residual planes, float32 positions / velocities: same bound at 48 B per env-step less
     assert errs['attitude'][1000] <= 1e-5 and errs['attitude'][1000] < errs[False][1000]
+    # the int16 residual planes (40 significant bits) lose nothing against the float32 ones (48)
+    assert errs['attitude_f32'][1000] <= 1e-5 and errs['attitude'][1000] <= 1.5 * errs['attitude_f32'][1000] + 1e-7
 
 
 def _pd_tracking(xs, goal, hover):
@@ -608,7 +606,7 @@ def test_reference_verbose_api_config_runs(gpu):
     env.close()
 
 
-@pytest.mark.parametrize('mode', [True, 'attitude'])
+@pytest.mark.parametrize('mode', [True, 'attitude', 'attitude_f32'])
 @pytest.mark.parametrize('info_level', ['minimal', 'full'])
 def test_precise_modes_teacher_forced_parity_resets_and_queues(gpu, mode, info_level):
     """Both precise modes (all residual planes / attitude-only residual planes with float32 positions and velocities) in the
@@ -625,7 +623,8 @@ def test_precise_modes_teacher_forced_parity_resets_and_queues(gpu, mode, info_l
     env, ref, sampler = make_pair(3, n, randomized_init=True, engine_kwargs=dict(compensated_state=mode, info_level=info_level), **kw)
     sync_reset(env, ref, sampler)
     lo = env._bufs['state_lo']
-    assert lo.shape[0] == (6 if mode == 'attitude' else 12)
+    assert lo.shape[0] == (6 if str(mode).startswith('attitude') else 12)
+    assert lo.dtype == (torch.int16 if mode == 'attitude' else torch.float32)
     rng = np.random.default_rng(23)
     worst = 0.0
     for k in range(40):                                   # 18-step episodes: every env auto-resets twice
@@ -633,12 +632,17 @@ def test_precise_modes_teacher_forced_parity_resets_and_queues(gpu, mode, info_l
         lo.zero_()                                        # teacher forcing sets the hi planes: the residual restarts at 0
         worst = max(worst, compare_step(*sync_step(env, ref, sampler, _actions(env, rng, n)), ref))
     assert worst <= RTOL
-    assert float(lo.abs().max()) > 0 and float(lo.abs().max()) < 1e-6          # residuals of float32 roundings, in use
+    if lo.dtype == torch.int16:                                                 # counts of 2^-16 ulp(hi): in use, within +-2^15
+        assert int(lo.abs().max()) > 1000
+        d = (env.state_precise - env.state.double()).abs().max()
+        assert 0 < float(d) < 1e-6
+    else:
+        assert float(lo.abs().max()) > 0 and float(lo.abs().max()) < 1e-6      # residuals of float32 roundings, in use
     # a masked reset clears the residuals of the masked lanes only
     mask = torch.zeros(n, dtype=torch.bool, device='cuda'); mask[::3] = True
     keep = lo[:, 1].clone()
     env.reset(mask=mask)
-    assert float(lo[:, :n][:, mask].abs().max()) == 0.0 and torch.equal(lo[:, 1], keep)
+    assert float(lo[:, :n][:, mask].double().abs().max()) == 0.0 and torch.equal(lo[:, 1], keep)
     env.close()
     # two launch queues: bit-identical to the step loop in this mode too
     big = 300001
@@ -656,10 +660,10 @@ def test_precise_modes_teacher_forced_parity_resets_and_queues(gpu, mode, info_l
     for key in ('state', 'state_lo', 'step_count', 'reward', 'done', 'ep_return'):
         assert torch.equal(a._bufs[key], b._bufs[key]), key
     a.close(), b.close()
-    if mode == 'attitude':
+    if str(mode).startswith('attitude'):
         with pytest.raises(ValueError, match='3-D'):
-            scg.make('quadrotor', quad_type=2, num_envs=8, device='cuda', compensated_state='attitude').reset()
-        noisy = scg.make('quadrotor', quad_type=3, num_envs=8, device='cuda', task='traj_tracking', compensated_state='attitude',
+            scg.make('quadrotor', quad_type=2, num_envs=8, device='cuda', compensated_state=mode).reset()
+        noisy = scg.make('quadrotor', quad_type=3, num_envs=8, device='cuda', task='traj_tracking', compensated_state=mode,
                          disturbances={'dynamics': [{'disturbance_func': 'white_noise', 'std': 0.01}]})
         noisy.reset()
         with pytest.raises(ScgError, match='lean and info'):

@@ -121,5 +121,15 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_cmd.json 2> $
 python -c "import __graft_entry__ as g; g.smoke()"
 )
 ;;
-*) echo "usage: tools/r03_sessions.sh ab|tiers|misc|final|lds_ab|close [args]"; exit 2 ;;
+residuals)
+(
+# attitude precise mode: int16 residual planes (compensated_state='attitude') vs float32 ones ('attitude_f32'), interleaved on one box
+root="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"; cd "$root"; out=gpurun_out/r03/residuals; mkdir -p $out
+python -m pytest tests/test_parity_gpu.py tests/test_config_fuzz_gpu.py -q -m gpu -s -k "precise or drift or fuzz or random_configuration" 2>&1 | grep -E "drift|passed|failed|FAILED|Error" | tee $out/tests.txt
+for r in 1 2 3; do for m in attitude attitude_f32; do
+  python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-sub-records --no-episode-stats --env-kw compensated_state=$m 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read()); print('round $r %-13s %.2f us/step  %d B moved  %.3f of peak' % ('$m', j['ms_per_step']*1e3, j['config']['moved_bytes_per_env_step'], j['roofline']['frac']))"
+done; done | tee $out/attitude_int16_vs_f32.txt
+)
+;;
+*) echo "usage: tools/r03_sessions.sh ab|tiers|misc|final|lds_ab|close|residuals [args]"; exit 2 ;;
 esac
