@@ -144,7 +144,8 @@ typedef struct scg_config {
 } scg_config;
 
 /* np.random.RandomState methods the reset path can draw from on the device (benchmark_env.py:297-307); u, u2 are
- * Philox uniforms in [0, 1).  Anything else (choice, multivariate draws ...) is rejected by the Python layer. */
+ * Philox uniforms in [0, 1).  Rejection samplers (gamma, beta, vonmises ...), multivariate draws and choice() with probabilities or more
+ * than three values are rejected by the Python layer. */
 typedef enum scg_distribution {
     SCG_RAND_UNIFORM = 0,        /* uniform(low, high): low + (high - low) u              (fields *_rand_low / high) */
     SCG_RAND_NORMAL = 1,         /* normal(loc = p0, scale = p1): Box-Muller on (u, u2); standard_normal: p = (0, 1) */
@@ -152,8 +153,17 @@ typedef enum scg_distribution {
     SCG_RAND_LAPLACE = 3,        /* laplace(loc = p0, scale = p1): inverse CDF */
     SCG_RAND_LOGISTIC = 4,       /* logistic(loc = p0, scale = p1): p0 + p1 ln(u / (1 - u)) */
     SCG_RAND_TRIANGULAR = 5,     /* triangular(left = p0, mode = p1, right = p2): inverse CDF */
-    SCG_RAND_RANDINT = 6         /* randint(low = p0, high = p1): floor(p0 + (p1 - p0) u) */
+    SCG_RAND_RANDINT = 6,        /* randint(low = p0, high = p1): floor(p0 + (p1 - p0) u) */
+    SCG_RAND_CHOICE = 7,         /* choice(a) over 1..3 equiprobable values p0, p1, p2: p[floor(count u)], count in *_rand_low */
+    SCG_RAND_RAYLEIGH = 8,       /* rayleigh(scale = p0): p0 sqrt(-2 ln(1 - u)) */
+    SCG_RAND_GUMBEL = 9,         /* gumbel(loc = p0, scale = p1): p0 - p1 ln(-ln u) */
+    SCG_RAND_WEIBULL = 10,       /* weibull(a = p0): (-ln(1 - u))^(1 / p0) */
+    SCG_RAND_PARETO = 11,        /* pareto(a = p0) (Lomax, as numpy): (1 - u)^(-1 / p0) - 1 */
+    SCG_RAND_POWER = 12,         /* power(a = p0): u^(1 / p0) */
+    SCG_RAND_LOGNORMAL = 13,     /* lognormal(mean = p0, sigma = p1): exp(normal(p0, p1)) on (u, u2) */
+    SCG_RAND_CAUCHY = 14         /* standard_cauchy(): tan(pi (u - 1/2)) */
 } scg_distribution;
+#define SCG_RAND_KIND_MAX 14
 
 /* One scalar constraint g(v) <= 0 over v = [state ; RAW action] (constraints.py:160-172).
  * LinearConstraint / BoundedConstraint / DefaultConstraint (constraints.py:226-368) compile to

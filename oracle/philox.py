@@ -51,7 +51,7 @@ def uniform01(words):
 
 # scg_distribution (include/scg_rollout.h): the np.random.RandomState methods the reference may name in its yaml
 # (envs/benchmark_env.py:297-307), as transforms of the Philox uniforms -- shared with csrc/scg_kernels.hip::draw_distribution
-UNIFORM, NORMAL, EXPONENTIAL, LAPLACE, LOGISTIC, TRIANGULAR, RANDINT = range(7)
+UNIFORM, NORMAL, EXPONENTIAL, LAPLACE, LOGISTIC, TRIANGULAR, RANDINT, CHOICE, RAYLEIGH, GUMBEL, WEIBULL, PARETO, POWER, LOGNORMAL, CAUCHY = range(15)
 
 
 def draw(kind, u, u2, p, low=0.0, high=1.0):
@@ -71,6 +71,22 @@ def draw(kind, u, u2, p, low=0.0, high=1.0):
         return p[0] + np.sqrt(u * base * (p[1] - p[0])) if u <= ratio else p[2] - np.sqrt((1.0 - u) * base * (p[2] - p[1]))
     if kind == RANDINT:
         return np.floor(p[0] + (p[1] - p[0]) * u)
+    if kind == CHOICE:                                       # `low` carries the number of equiprobable values (1..3)
+        return p[min(int(u * low), int(low) - 1)]
+    if kind == RAYLEIGH:
+        return p[0] * np.sqrt(-2.0 * np.log(1.0 - u))
+    if kind == GUMBEL:
+        return p[0] - p[1] * np.log(-np.log(uo))
+    if kind == WEIBULL:
+        return (-np.log(1.0 - u)) ** (1.0 / p[0])
+    if kind == PARETO:
+        return np.exp(-np.log(1.0 - u) / p[0]) - 1.0
+    if kind == POWER:
+        return uo ** (1.0 / p[0])
+    if kind == LOGNORMAL:
+        return np.exp(p[0] + p[1] * np.sqrt(-2.0 * np.log(uo)) * np.cos(2.0 * np.pi * u2))
+    if kind == CAUCHY:
+        return np.tan(np.pi * (uo - 0.5))
     return low + (high - low) * u
 
 

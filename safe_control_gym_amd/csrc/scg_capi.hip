@@ -335,10 +335,10 @@ int scg_create(const scg_config* cfg, scg_handle** out) {
     if (cfg->rollout_split_min < 0 || cfg->grid_cap_per_cu < 0)
         return fail(SCG_ERR_INVALID, "scg_create: rollout_split_min and grid_cap_per_cu must be >= 0");
     for (int j = 0; j < SCG_MAX_NX; ++j)
-        if (cfg->init_rand_kind[j] < SCG_RAND_UNIFORM || cfg->init_rand_kind[j] > SCG_RAND_RANDINT)
+        if (cfg->init_rand_kind[j] < SCG_RAND_UNIFORM || cfg->init_rand_kind[j] > SCG_RAND_KIND_MAX)
             return fail(SCG_ERR_INVALID, "scg_create: init_rand_kind[%d] = %d is not a scg_distribution", j, cfg->init_rand_kind[j]);
     for (int q = 0; q < 4; ++q)
-        if (cfg->inertial_rand_kind[q] < SCG_RAND_UNIFORM || cfg->inertial_rand_kind[q] > SCG_RAND_RANDINT)
+        if (cfg->inertial_rand_kind[q] < SCG_RAND_UNIFORM || cfg->inertial_rand_kind[q] > SCG_RAND_KIND_MAX)
             return fail(SCG_ERR_INVALID, "scg_create: inertial_rand_kind[%d] = %d is not a scg_distribution", q, cfg->inertial_rand_kind[q]);
 
     if (cfg->randomized_inertial) {
@@ -356,8 +356,13 @@ int scg_create(const scg_config* cfg, scg_handle** out) {
                 if (cfg->inertial_rand_high[q] < cfg->inertial_rand_low[q])
                     return fail(SCG_ERR_INVALID, "scg_create: randomised inertial property %d has high < low", q);
             } else if (kind == SCG_RAND_TRIANGULAR || kind == SCG_RAND_RANDINT) lowest = cfg->inertial_rand_p[q][0];
-            else if (kind == SCG_RAND_EXPONENTIAL) lowest = 0.0;
-            else bounded = false;
+            else if (kind == SCG_RAND_EXPONENTIAL || kind == SCG_RAND_RAYLEIGH || kind == SCG_RAND_WEIBULL || kind == SCG_RAND_PARETO ||
+                     kind == SCG_RAND_POWER || kind == SCG_RAND_LOGNORMAL) lowest = 0.0;
+            else if (kind == SCG_RAND_CHOICE) {
+                const int cnt = (int)cfg->inertial_rand_low[q];
+                lowest = cfg->inertial_rand_p[q][0];
+                for (int r = 1; r < cnt && r < 3; ++r) lowest = cfg->inertial_rand_p[q][r] < lowest ? cfg->inertial_rand_p[q][r] : lowest;
+            } else bounded = false;
             if (bounded && !(nominal[q] + lowest > 0.0))
                 return fail(SCG_ERR_INVALID, "scg_create: randomised inertial property %d can become non-positive", q);
         }

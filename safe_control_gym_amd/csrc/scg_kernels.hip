@@ -176,6 +176,22 @@ __device__ __forceinline__ float draw_distribution(int kind, float u, float u2, 
             return u <= ratio ? p[0] + sqrt_f(u * base * (p[1] - p[0])) : p[2] - sqrt_f((1.0f - u) * base * (p[2] - p[1]));
         }
         case SCG_RAND_RANDINT: return floorf(fmaf(p[1] - p[0], u, p[0]));
+        case SCG_RAND_CHOICE: {                                          // `lo` carries the number of values (1..3)
+            const int k = min((int)(u * lo), (int)lo - 1);
+            return k == 0 ? p[0] : (k == 1 ? p[1] : p[2]);
+        }
+        case SCG_RAND_RAYLEIGH: return p[0] * sqrt_f(-2.0f * logf(1.0f - u));
+        case SCG_RAND_GUMBEL: return p[0] - p[1] * logf(-logf(uo));
+        case SCG_RAND_WEIBULL: return powf(-logf(1.0f - u), 1.0f / p[0]);
+        case SCG_RAND_PARETO: return expf(-logf(1.0f - u) / p[0]) - 1.0f;
+        case SCG_RAND_POWER: return powf(uo, 1.0f / p[0]);
+        case SCG_RAND_LOGNORMAL: {
+            const float r = sqrt_f(-2.0f * logf(uo));
+            float sn, cs;
+            sincos_f(6.283185307179586f * u2, sn, cs);
+            return expf(fmaf(p[1] * r, cs, p[0]));
+        }
+        case SCG_RAND_CAUCHY: return tanf(3.141592653589793f * (uo - 0.5f));
         default: return fmaf(span, u, lo);                               // SCG_RAND_UNIFORM
     }
 }

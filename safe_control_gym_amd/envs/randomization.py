@@ -4,8 +4,9 @@ The reference draws every randomised quantity with ``getattr(self.np_random, inf
 (/root/reference/safe_control_gym/envs/benchmark_env.py:297-307): any ``numpy.random.RandomState`` method name is legal in the
 yaml.  On the device the draw is a transform of one or two Philox uniforms per quantity (``scg_distribution`` in
 include/scg_rollout.h); this module maps the RandomState signatures of the supported methods onto it.  Methods that are
-not a transform of a fixed number of uniforms (``choice``, ``permutation``, ``multivariate_normal``, rejection samplers
-such as ``gamma`` / ``beta`` ...) raise ``NotImplementedError`` naming the method.
+not a transform of a fixed number of uniforms (``permutation``, ``multivariate_normal``, rejection samplers such as ``gamma`` /
+``beta`` / ``vonmises`` ...) raise ``NotImplementedError`` naming the method; so does ``choice`` with probabilities or more than
+three values (the device record of a quantity holds three parameters).
 """
 from safe_control_gym_amd import _capi
 
@@ -19,6 +20,18 @@ _SIGNATURES = {
     'logistic': (_capi.SCG_RAND_LOGISTIC, (('loc', 0.0), ('scale', 1.0))),
     'triangular': (_capi.SCG_RAND_TRIANGULAR, (('left', None), ('mode', None), ('right', None))),
     'randint': (_capi.SCG_RAND_RANDINT, (('low', None), ('high', None))),
+    'rayleigh': (_capi.SCG_RAND_RAYLEIGH, (('scale', 1.0),)),
+    'gumbel': (_capi.SCG_RAND_GUMBEL, (('loc', 0.0), ('scale', 1.0))),
+    'weibull': (_capi.SCG_RAND_WEIBULL, (('a', None),)),
+    'pareto': (_capi.SCG_RAND_PARETO, (('a', None),)),
+    'power': (_capi.SCG_RAND_POWER, (('a', None),)),
+    'lognormal': (_capi.SCG_RAND_LOGNORMAL, (('mean', 0.0), ('sigma', 1.0))),
+    'standard_cauchy': (_capi.SCG_RAND_CAUCHY, ()),
+    # aliases of kinds above
+    'standard_exponential': (_capi.SCG_RAND_EXPONENTIAL, ()),
+    'random_sample': (_capi.SCG_RAND_UNIFORM, ()), 'random': (_capi.SCG_RAND_UNIFORM, ()), 'ranf': (_capi.SCG_RAND_UNIFORM, ()),
+    'sample': (_capi.SCG_RAND_UNIFORM, ()), 'rand': (_capi.SCG_RAND_UNIFORM, ()),
+    'choice': (_capi.SCG_RAND_CHOICE, (('a', None), ('size', None), ('replace', True), ('p', None))),
 }
 SUPPORTED = tuple(sorted(_SIGNATURES))
 
@@ -33,6 +46,8 @@ def parse_distribution(info, what=''):
         raise NotImplementedError('[ERROR] distrib %r%s is not available on the device (supported: %s).'
                                   % (name, ' for ' + what if what else '', ', '.join(SUPPORTED)))
     kind, params = _SIGNATURES[name]
+    if name == 'choice':
+        return _parse_choice(args, info, what)
     info.pop('size', None)
     if len(args) > len(params):
         raise TypeError('[ERROR] %s() takes at most %d positional arguments (%d given)%s.'
@@ -56,8 +71,14 @@ def parse_distribution(info, what=''):
     v = [float(vals[p]) for p, _ in params]
     if name == 'standard_normal':
         v = [0.0, 1.0]
+    if name == 'standard_exponential':
+        v = [1.0]
     if kind == _capi.SCG_RAND_UNIFORM:
-        return kind, v[0], v[1], (0.0, 0.0, 0.0)
+        return (kind, v[0], v[1], (0.0, 0.0, 0.0)) if v else (kind, 0.0, 1.0, (0.0, 0.0, 0.0))
+    if kind in (_capi.SCG_RAND_RAYLEIGH,) and v[0] < 0 or kind in (_capi.SCG_RAND_GUMBEL, _capi.SCG_RAND_LOGNORMAL) and v[1] < 0:
+        raise ValueError('[ERROR] scale < 0 in %s()%s.' % (name, ' for ' + what if what else ''))
+    if kind in (_capi.SCG_RAND_WEIBULL, _capi.SCG_RAND_PARETO, _capi.SCG_RAND_POWER) and not v[0] > 0:
+        raise ValueError('[ERROR] a <= 0 in %s()%s.' % (name, ' for ' + what if what else ''))
     if kind in (_capi.SCG_RAND_NORMAL, _capi.SCG_RAND_LAPLACE, _capi.SCG_RAND_LOGISTIC) and v[1] < 0:
         raise ValueError('[ERROR] scale < 0 in %s()%s.' % (name, ' for ' + what if what else ''))
     if kind == _capi.SCG_RAND_EXPONENTIAL and v[0] < 0:
@@ -69,6 +90,37 @@ def parse_distribution(info, what=''):
     return kind, 0.0, 0.0, tuple(v + [0.0] * (3 - len(v)))
 
 
+def _parse_choice(args, info, what):
+    """RandomState.choice(a, size=None, replace=True, p=None) for a scalar draw: `a` an int (= randint(0, a)) or a sequence of at
+    most three values, equiprobable."""
+    names = ('a', 'size', 'replace', 'p')
+    if len(args) > len(names):
+        raise TypeError('[ERROR] choice() takes at most 4 positional arguments.')
+    vals = dict(zip(names, args))
+    for k in list(info):
+        if k in names:
+            if k in vals:
+                raise TypeError('[ERROR] choice() got multiple values for argument %r.' % k)
+            vals[k] = info.pop(k)
+    if info:
+        raise TypeError('[ERROR] choice() got unexpected keyword arguments %s.' % sorted(info))
+    if 'a' not in vals:
+        raise TypeError('[ERROR] choice() is missing a required argument%s.' % (' for ' + what if what else ''))
+    if vals.get('size') is not None:
+        raise NotImplementedError('[ERROR] choice(size=...) draws an array; a randomised quantity is a scalar.')
+    if vals.get('p') is not None:
+        raise NotImplementedError('[ERROR] choice() with probabilities is not available on the device (equiprobable values only).')
+    a = vals['a']
+    if isinstance(a, (int, float)) and not isinstance(a, bool):
+        if int(a) != a or a < 1:
+            raise ValueError('[ERROR] choice(a): a must be a positive integer or a sequence.')
+        return _capi.SCG_RAND_RANDINT, 0.0, 0.0, (0.0, float(a), 0.0)
+    a = [float(v) for v in a]
+    if not 1 <= len(a) <= 3:
+        raise NotImplementedError('[ERROR] choice() over %d values is not available on the device (at most 3).' % len(a))
+    return _capi.SCG_RAND_CHOICE, float(len(a)), 0.0, tuple(a + [0.0] * (3 - len(a)))
+
+
 def lower_bound(kind, low, p):
     """The smallest value the draw can take (-inf when unbounded): used for the reference's positivity check of
     randomised inertial properties (quadrotor.py:464-465)."""
@@ -78,4 +130,8 @@ def lower_bound(kind, low, p):
         return 0.0
     if kind in (_capi.SCG_RAND_TRIANGULAR, _capi.SCG_RAND_RANDINT):
         return p[0]
+    if kind in (_capi.SCG_RAND_RAYLEIGH, _capi.SCG_RAND_WEIBULL, _capi.SCG_RAND_PARETO, _capi.SCG_RAND_POWER, _capi.SCG_RAND_LOGNORMAL):
+        return 0.0
+    if kind == _capi.SCG_RAND_CHOICE:
+        return min(p[:int(low)])
     return float('-inf')

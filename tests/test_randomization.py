@@ -22,7 +22,18 @@ SPECS = {
     'triangular': ({'distrib': 'triangular', 'left': -0.2, 'mode': 0.1, 'right': 0.3}, (philox.TRIANGULAR, (-0.2, 0.1, 0.3))),
     'randint': ({'distrib': 'randint', 'low': -2, 'high': 3}, (philox.RANDINT, (-2.0, 3.0, 0.0))),
     'randint_one_arg': ({'distrib': 'randint', 'args': [4]}, (philox.RANDINT, (0.0, 4.0, 0.0))),
+    'rayleigh': ({'distrib': 'rayleigh', 'scale': 0.2}, (philox.RAYLEIGH, (0.2, 0.0, 0.0))),
+    'gumbel': ({'distrib': 'gumbel', 'loc': 0.1, 'scale': 0.05}, (philox.GUMBEL, (0.1, 0.05, 0.0))),
+    'weibull': ({'distrib': 'weibull', 'a': 1.5}, (philox.WEIBULL, (1.5, 0.0, 0.0))),
+    'pareto': ({'distrib': 'pareto', 'args': [6.0]}, (philox.PARETO, (6.0, 0.0, 0.0))),
+    'power': ({'distrib': 'power', 'a': 3.0}, (philox.POWER, (3.0, 0.0, 0.0))),
+    'lognormal': ({'distrib': 'lognormal', 'mean': -1.0, 'sigma': 0.3}, (philox.LOGNORMAL, (-1.0, 0.3, 0.0))),
+    'standard_exponential': ({'distrib': 'standard_exponential'}, (philox.EXPONENTIAL, (1.0, 0.0, 0.0))),
+    'choice_3': ({'distrib': 'choice', 'args': [[-0.1, 0.0, 0.25]]}, (philox.CHOICE, (-0.1, 0.0, 0.25))),
+    'choice_2_kw': ({'distrib': 'choice', 'a': [0.5, 1.5]}, (philox.CHOICE, (0.5, 1.5, 0.0))),
+    'choice_int': ({'distrib': 'choice', 'args': [3]}, (philox.RANDINT, (0.0, 3.0, 0.0))),
 }
+DISCRETE = {'randint', 'randint_one_arg', 'choice_3', 'choice_2_kw', 'choice_int'}
 
 
 @pytest.mark.parametrize('name', sorted(SPECS))
@@ -37,8 +48,14 @@ def test_parser_binds_arguments_like_randomstate(name):
 
 
 def test_parser_rejects_what_the_device_cannot_draw():
-    with pytest.raises(NotImplementedError, match='choice'):
-        rz.parse_distribution({'distrib': 'choice', 'args': [[1, 2, 3]]})
+    with pytest.raises(NotImplementedError, match='at most 3'):
+        rz.parse_distribution({'distrib': 'choice', 'args': [[1, 2, 3, 4]]})
+    with pytest.raises(NotImplementedError, match='probabilities'):
+        rz.parse_distribution({'distrib': 'choice', 'a': [1, 2], 'p': [0.3, 0.7]})
+    with pytest.raises(ValueError, match='a <= 0'):
+        rz.parse_distribution({'distrib': 'weibull', 'a': 0.0})
+    assert rz.parse_distribution({'distrib': 'random_sample'})[:3] == (philox.UNIFORM, 0.0, 1.0)
+    assert rz.parse_distribution({'distrib': 'standard_cauchy'})[0] == philox.CAUCHY
     with pytest.raises(NotImplementedError, match='gamma'):
         rz.parse_distribution({'distrib': 'gamma', 'shape': 2.0})
     with pytest.raises(TypeError, match='unexpected'):
@@ -59,7 +76,8 @@ def test_oracle_transform_has_the_distribution_numpy_draws(name):
     m = 1 << 18
     u = (np.arange(m) + 0.5) / m
     u2 = ((np.arange(m) * 0.6180339887498949) % 1.0)                    # an independent low-discrepancy sequence
-    mine = np.array([philox.draw(kind, a, b, p) for a, b in zip(u[::8], u2[::8])])
+    low = rz.parse_distribution(info, name)[1]                          # (choice: the number of values travels in `low`)
+    mine = np.array([philox.draw(kind, a, b, p, low) for a, b in zip(u[::8], u2[::8])])
     d = dict(info)
     fn = getattr(np.random.RandomState(12345), d.pop('distrib'))
     theirs = np.asarray(fn(*d.pop('args', []), size=400000, **d), dtype=np.float64)
@@ -67,10 +85,10 @@ def test_oracle_transform_has_the_distribution_numpy_draws(name):
     assert abs(mine.mean() - theirs.mean()) < 0.02 * scale
     assert abs(mine.std() - theirs.std()) < 0.03 * scale
     for q in (0.05, 0.25, 0.5, 0.75, 0.95):
-        if kind == philox.RANDINT:
+        if name in DISCRETE:
             continue
         assert abs(np.quantile(mine, q) - np.quantile(theirs, q)) < 0.03 * scale, q
-    if kind == philox.RANDINT:
+    if name in DISCRETE:
         assert set(np.unique(mine)) == set(np.unique(theirs))
     if kind in (philox.TRIANGULAR, philox.EXPONENTIAL):
         assert mine.min() >= theirs.min() - 1e-3 * scale and mine.max() <= max(theirs.max(), p[2] if kind == philox.TRIANGULAR else np.inf)
@@ -84,17 +102,30 @@ RAND_3D = {'init_x': {'distrib': 'normal', 'loc': 0.0, 'scale': 0.2}, 'init_x_do
            'init_psi': {'distrib': 'randint', 'low': -1, 'high': 2}, 'init_p': {'distrib': 'uniform', 'args': [-0.02, 0.02]}}
 
 
+# the kinds added in round 3 (the heavy tails of standard_cauchy are left to the statistics test below: tan near +-pi/2 amplifies a
+# float32 rounding of its argument beyond any per-env tolerance)
+RAND_3D_MORE = {'init_x': {'distrib': 'rayleigh', 'scale': 0.2}, 'init_x_dot': {'distrib': 'gumbel', 'loc': 0.0, 'scale': 0.02},
+                'init_y': {'distrib': 'weibull', 'a': 1.5}, 'init_y_dot': {'distrib': 'power', 'a': 3.0},
+                'init_z': {'distrib': 'lognormal', 'mean': -1.0, 'sigma': 0.3}, 'init_z_dot': {'distrib': 'pareto', 'args': [6.0]},
+                'init_phi': {'distrib': 'choice', 'args': [[-0.1, 0.0, 0.25]]}, 'init_theta': {'distrib': 'choice', 'a': [0.05, -0.05]},
+                'init_psi': {'distrib': 'choice', 'args': [3]}, 'init_p': {'distrib': 'standard_exponential'},
+                'init_q': {'distrib': 'random_sample'}}
+
+
 @pytest.mark.gpu
-def test_device_draws_equal_the_oracle_for_every_distribution(gpu):
+@pytest.mark.parametrize('which', ['round2_kinds', 'round3_kinds'])
+def test_device_draws_equal_the_oracle_for_every_distribution(gpu, which):
     """Same Philox counters, same transforms: the kernel's reset states (scg_reset and the fused auto-reset) equal the
-    oracle's per env, for all seven kinds mixed in one env; then teacher-forced step parity through several auto-resets."""
+    oracle's per env, for all kinds mixed in one env; then teacher-forced step parity through several auto-resets."""
     n = 200
     kw = dict(task='traj_tracking', cost='quadratic', ctrl_freq=60, pyb_freq=240, episode_len_sec=0.2,
-              init_state_randomization_info=RAND_3D)
+              init_state_randomization_info=RAND_3D if which == 'round2_kinds' else RAND_3D_MORE, done_on_out_of_bound=which == 'round2_kinds')
     env, ref, sampler = make_pair(3, n, randomized_init=True, **kw)
     obs_e, obs_r = sync_reset(env, ref, sampler)
-    assert rel_err(obs_e.cpu().numpy(), obs_r) <= 2e-6
+    assert rel_err(obs_e.cpu().numpy(), obs_r) <= (2e-6 if which == 'round2_kinds' else 5e-6)     # (powf / expf are ~2 ulp)
     assert np.abs(obs_r[:, 8] - np.round(obs_r[:, 8])).max() == 0.0          # randint dims hold integers
+    if which == 'round3_kinds':
+        assert set(np.unique(np.round(obs_r[:, 6], 6))) <= {-0.1, 0.0, 0.25} and set(np.unique(np.round(obs_r[:, 7], 6))) == {-0.05, 0.05}
     rng = np.random.default_rng(5)
     lo, hi = env.action_space.low, env.action_space.high
     worst = 0.0
@@ -124,6 +155,23 @@ def test_device_draw_statistics_and_inertial_distributions(gpu):
     assert abs(x[:, 6].mean() - 0.05) < 1e-3 and x[:, 6].min() >= 0.0                             # exponential(0.05)
     assert set(np.unique(x[:, 8])) == {-1.0, 0.0, 1.0}                                           # randint(-1, 2)
     assert abs(np.corrcoef(x[:, 0], x[:, 7])[0, 1]) < 0.01                                       # independent streams
+    env.close()
+    more = dict(RAND_3D_MORE, init_r={'distrib': 'standard_cauchy'})
+    env = scg.make('quadrotor', quad_type=3, num_envs=n, device='cuda', seed=10, task='traj_tracking', randomized_init=True,
+                   init_state_randomization_info=more)
+    x = env.reset().double().cpu().numpy()
+    assert abs(x[:, 0].mean() - 0.2 * np.sqrt(np.pi / 2)) < 2e-3 and x[:, 0].min() >= 0.0         # rayleigh(0.2)
+    assert abs(x[:, 1].mean() - 0.02 * 0.5772156649) < 3e-4                                       # gumbel(0, 0.02): mean = scale * Euler's gamma
+    assert abs(x[:, 2].mean() - 0.9027452929) < 6e-3                                              # weibull(1.5): Gamma(1 + 1/1.5)
+    assert abs(x[:, 3].mean() - 0.75) < 3e-3 and x[:, 3].max() <= 1.0                             # power(3): a / (a + 1)
+    assert abs(x[:, 4].mean() - np.exp(-1.0 + 0.045)) < 2e-3 and x[:, 4].min() > 0.0                # lognormal(-1, 0.3): exp(mean + sigma^2 / 2)
+    assert abs(x[:, 5].mean() - 1.0 / 5.0) < 5e-3 and x[:, 5].min() >= 0.0                        # pareto(6) (Lomax): 1 / (a - 1)
+    for vals, col in (((-0.1, 0.0, 0.25), 6), ((0.05, -0.05), 7), ((0.0, 1.0, 2.0), 8)):           # choice: equiprobable
+        for v in vals:
+            assert abs(np.mean(np.abs(x[:, col] - v) < 1e-6) - 1.0 / len(vals)) < 0.01
+    assert abs(x[:, 9].mean() - 1.0) < 0.02 and abs(x[:, 10].mean() - 0.5) < 5e-3                 # standard_exponential, random_sample
+    q1, med, q3 = np.quantile(x[:, 11], [0.25, 0.5, 0.75])
+    assert abs(med) < 0.02 and abs(q1 + 1.0) < 0.03 and abs(q3 - 1.0) < 0.03                     # standard_cauchy: quartiles at -1, 0, 1
     env.close()
     rand = {'M': {'distrib': 'normal', 'loc': 0.0, 'scale': 0.002}, 'Ixx': {'distrib': 'triangular', 'left': -2e-6, 'mode': 0.0, 'right': 4e-6},
             'Iyy': {'distrib': 'uniform', 'low': -1e-6, 'high': 1e-6}, 'Izz': {'distrib': 'normal', 'loc': 0.0, 'scale': 2.17e-5}}
