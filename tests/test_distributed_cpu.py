@@ -176,3 +176,20 @@ def test_bench_rejects_a_world_size_mismatch():
     run = subprocess.run([sys.executable, BENCH, '--gpus', '4', '--steps', '2', '--warmup', '1'],
                          env=_clean_env(WORLD_SIZE='1', RANK='0'), capture_output=True, text=True, timeout=300)
     assert run.returncode != 0 and 'WORLD_SIZE is 1' in run.stderr     # ... the real body refuses
+
+
+def test_bench_under_torch_distributed_run():
+    """The driver's N > 1 command: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- the ranks exist already (WORLD_SIZE is set), every one runs the body, rank 0 prints the
+    line.  Dry run over gloo: the rendezvous, the collectives of the timed region and the rank layout."""
+    port = 29000 + (os.getpid() % 2000)
+    run = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                          '--master-port', str(port), BENCH, '--gpus', '2', '--steps', '20', '--warmup', '5', '--dry-run'],
+                         env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, run.stdout
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['ranks_seen'] == 2 and j['gather_ok'] is True
+    assert [(d['rank'], d['device_index'], d['env_index_base']) for d in sorted(j['rank_layout'], key=lambda d: d['rank'])] == \
+        [(0, 0, 0), (1, 1, 1 << 20)]
