@@ -1076,7 +1076,10 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                         ov[j] = o;
                     }
                     // without a goal horizon the record is [obs | return | length]: whole 16-byte stores (4 instead of 14 for the
-                    // 3-D quadrotor; the few finishing lanes of a wave pay one store instruction each way, but so does the wave)
+                    // 3-D quadrotor), nontemporal -- a 64-byte record is half a cache line, and allocated in L2 it is filled from HBM
+                    // first (measured at 2^20 envs by leaving the record out: it cost 1.75 us of the default tier's step as plain
+                    // stores, 0.45 us now).  Staging the finishing lanes' records in LDS so that the whole wave writes them with one
+                    // store instruction per four records was built too: no better -- the cost was in the cache, not in the instructions.
                     const bool packed_record = !(OBS && p.obs_goal_horizon > 0) && (reinterpret_cast<uintptr_t>(io.terminal_record) & 15u) == 0;
                     if (packed_record) {
                         typedef float v4 __attribute__((ext_vector_type(4)));
@@ -1086,27 +1089,27 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                         for (int j = 0; j < 4 * W4; ++j) buf[j] = j < NX ? ov[j] : (j == NX ? epr : (j == NX + 1 ? __int_as_float(epl) : 0.f));
 #pragma unroll
                         for (int q = 0; q < W4; ++q)
-                            reinterpret_cast<v4*>(rec)[q] = v4{buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]};
+                            __builtin_nontemporal_store(v4{buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]}, reinterpret_cast<v4*>(rec) + q);
                     } else {
 #pragma unroll
-                        for (int j = 0; j < NX; ++j) rec[j] = ov[j];
+                        for (int j = 0; j < NX; ++j) __builtin_nontemporal_store(ov[j], rec + j);
                         if (OBS && p.obs_goal_horizon > 0) {
                             if (tracking) {
                                 for (int k = 0; k < p.obs_goal_horizon; ++k) {
                                     float g[NX];
                                     load_goal<NX>(p, ref, s_tab, t + 1 + k, g);
 #pragma unroll
-                                    for (int j = 0; j < NX; ++j) rec[NX * (1 + k) + j] = g[j];
+                                    for (int j = 0; j < NX; ++j) __builtin_nontemporal_store(g[j], rec + NX * (1 + k) + j);
                                 }
                                 od = NX * (1 + p.obs_goal_horizon);
                             } else {
 #pragma unroll
-                                for (int j = 0; j < NX; ++j) rec[NX + j] = tb->x_goal[j];
+                                for (int j = 0; j < NX; ++j) __builtin_nontemporal_store(tb->x_goal[j], rec + NX + j);
                                 od = 2 * NX;
                             }
                         }
-                        rec[od] = epr;
-                        rec[od + 1] = __int_as_float(epl);
+                        __builtin_nontemporal_store(epr, rec + od);
+                        __builtin_nontemporal_store(__int_as_float(epl), rec + od + 1);
                     }
                 }
             }
