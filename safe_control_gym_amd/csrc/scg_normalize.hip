@@ -66,14 +66,24 @@ __global__ __launch_bounds__(256) void scg_moments_kernel(const float* __restric
     const double c = state[j];
     double acc[2] = {0.0, 0.0};
     if constexpr (VEC) {
-        const uint32_t n4 = n >> 2;
-        for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < n4; q += gridDim.x * 256u) {
-            const nf4 v4 = __builtin_nontemporal_load(reinterpret_cast<const nf4*>(plane) + q);
+        // four independent 16-byte loads in flight per thread before the first use (round 3): with one, the dozen iterations of a
+        // thread were a dozen exposed memory latencies -- this pass ran at 2.3 TB/s while the apply pass behind it streams at 10
+        const uint32_t n4 = n >> 2, stride = gridDim.x * 256u;
+        for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < n4; q += 4u * stride) {
+            nf4 v4[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double v = (double)v4[k] - c;
-                acc[0] += v;
-                acc[1] = fma(v, v, acc[1]);
+            for (int u = 0; u < 4; ++u)
+                if (q + u * stride < n4) v4[u] = reinterpret_cast<const nf4*>(plane)[q + u * stride];     // plain load: the apply pass re-reads x from the cache
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (q + u * stride < n4) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const double v = (double)v4[u][k] - c;
+                        acc[0] += v;
+                        acc[1] = fma(v, v, acc[1]);
+                    }
+                }
             }
         }
         if (blockIdx.x == 0 && threadIdx.x < (n & 3u)) {                // ragged tail: at most 3 elements
