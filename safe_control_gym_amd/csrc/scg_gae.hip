@@ -107,6 +107,8 @@ __global__ __launch_bounds__(256) void scg_gae_kernel(const float* rew, const fl
 }
 
 // adv <- (adv - mean) / (std + eps) with the population statistics accumulated by scg_gae_kernel (ppo.py:288).
+// One grid row per time step (plane t = adv + t ld): no per-element index arithmetic; 16-byte accesses when the planes allow.
+template <bool VEC>
 __global__ __launch_bounds__(256) void scg_normalize_kernel(float* __restrict__ adv, const double* __restrict__ stats,
                                                             int T, uint32_t n, int64_t ld, float eps) {
     const double count = (double)T * (double)n;
@@ -114,9 +116,23 @@ __global__ __launch_bounds__(256) void scg_normalize_kernel(float* __restrict__ 
     double var = stats[1] / count - mean * mean;
     var = var > 0.0 ? var : 0.0;
     const float mu = (float)mean, inv = (float)(1.0 / (sqrt(var) + (double)eps));
-    const int64_t total = (int64_t)T * ld;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        if ((uint32_t)(e % ld) < n) adv[e] = (adv[e] - mu) * inv;
+    float* plane = adv + (int64_t)blockIdx.y * ld;
+    if constexpr (VEC) {
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        const uint32_t n4 = n >> 2, stride = gridDim.x * 256u;
+        for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < n4; q += 2u * stride) {
+            v4 a = reinterpret_cast<v4*>(plane)[q], b = a;
+            const bool two = q + stride < n4;
+            if (two) b = reinterpret_cast<v4*>(plane)[q + stride];
+            __builtin_nontemporal_store((a - mu) * inv, reinterpret_cast<v4*>(plane) + q);
+            if (two) __builtin_nontemporal_store((b - mu) * inv, reinterpret_cast<v4*>(plane) + q + stride);
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3u)) {
+            const uint32_t i = (n & ~3u) + threadIdx.x;
+            plane[i] = (plane[i] - mu) * inv;
+        }
+    } else {
+        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) plane[i] = (plane[i] - mu) * inv;
     }
 }
 
@@ -132,10 +148,19 @@ hipError_t launch_gae(const float* rew, const float* val, const float* mask, con
 }
 
 hipError_t launch_normalize(float* adv, const double* stats, int T, int64_t n, int64_t ld, float eps, hipStream_t s) {
-    int64_t blocks = ((int64_t)T * ld + 255) / 256;
-    if (blocks < 1) blocks = 1;
-    if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(scg_normalize_kernel, dim3((unsigned)blocks), dim3(256), 0, s, adv, stats, T, (uint32_t)n, ld, eps);
+    if (T <= 0 || n <= 0) return hipSuccess;
+    const bool vec = ((reinterpret_cast<uintptr_t>(adv) | (uintptr_t)(ld * 4)) & 15u) == 0;
+    int64_t per_row = ((vec ? (n + 3) / 4 : n) + 255) / 256;                 // workgroups that cover one plane
+    const int64_t cap = T >= 64 ? 64 : 4096 / T;                              // ~4096 workgroups in all
+    if (per_row > cap) per_row = cap;
+    if (per_row < 1) per_row = 1;
+    for (int t0 = 0; t0 < T; t0 += 65535) {                                   // (grid.y holds at most 65535 rows)
+        const int rows = T - t0 < 65535 ? T - t0 : 65535;
+        const dim3 grid((unsigned)per_row, (unsigned)rows), block(256);
+        float* base = adv + (int64_t)t0 * ld;
+        if (vec) hipLaunchKernelGGL(scg_normalize_kernel<true>, grid, block, 0, s, base, stats, T, (uint32_t)n, ld, eps);
+        else hipLaunchKernelGGL(scg_normalize_kernel<false>, grid, block, 0, s, base, stats, T, (uint32_t)n, ld, eps);
+    }
     return hipGetLastError();
 }
 
