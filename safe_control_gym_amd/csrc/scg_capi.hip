@@ -38,7 +38,6 @@ struct scg_handle {
     struct GraphEntry {
         RolloutKey key;
         hipGraphExec_t exec;
-        hipStream_t last_stream;   // where it was last replayed: synchronised before the executable graph is destroyed
         uint64_t last_use;
     };
     static constexpr int kGraphSlots = 4;
@@ -265,7 +264,9 @@ static void derive_tables(const scg_handle* h, KTables& t) {
 static void drop_rollout_graphs(scg_handle* h) {
     for (int q = 0; q < scg_handle::kGraphSlots; ++q) {
         if (h->graphs[q].exec) {
-            (void)hipStreamSynchronize(h->graphs[q].last_stream);       // a replay may still be running
+            // a replay may still be running; the stream it ran on is the caller's and may be gone by now, so wait for the device
+            // (this happens when a table is replaced or the handle is destroyed: not on a hot path)
+            (void)hipDeviceSynchronize();
             (void)hipGraphExecDestroy(h->graphs[q].exec);
         }
         h->graphs[q].exec = nullptr;
@@ -748,16 +749,14 @@ static int rollout_by_graph(scg_handle* h, const scg_step_io* io, int64_t n, int
             if (h->graphs[q].last_use < slot->last_use) slot = &h->graphs[q];
         }
         if (slot->exec) {                                               // least recently used
-            (void)hipStreamSynchronize(slot->last_stream);
+            (void)hipDeviceSynchronize();
             (void)hipGraphExecDestroy(slot->exec);
         }
         slot->key = key;
         slot->exec = exec;
-        slot->last_stream = s0;
         hit = slot;
     }
     hit->last_use = ++h->graph_clock;
-    hit->last_stream = s0;
     // Replayed on the CALLER's stream, in order with its other work.  (Replaying on the handle's queue, forked from / joined into
     // the caller's stream by events, costs 1.1 us MORE per node than plain launches when that stream is the legacy default
     // stream -- tools/ubench/graph_launch.hip: 4.09 vs 3.20 plain vs 2.99 replayed in place.)

@@ -40,6 +40,7 @@ hipError_t hipMemset(void* dst, int value, size_t bytes);
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipDeviceSynchronize(void);
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
 hipError_t hipEventDestroy(hipEvent_t e);

@@ -61,6 +61,7 @@ hipError_t hipMemsetD32Async(hipDeviceptr_t dst, int value, size_t count, hipStr
 }
 hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t s) { ++g_shim.stream_syncs; if (s && s->pending) { s->pending = 0; --g_shim.aux_streams_open; } return hipSuccess; }
+hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new ihipEvent_t{g_next_id++, nullptr}; return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
