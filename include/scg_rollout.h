@@ -359,6 +359,20 @@ int scg_normalize_advantages(float* adv, const double* stats, int32_t T, int64_t
  * (`input` is the model input; inertial nullable).  xdot and xnext are [nx][ld] planes, each nullable, not both. */
 int scg_model_eval(scg_handle* h, const float* state, const float* input, const float* inertial, float* xdot,
                    float* xnext, int64_t ld, int64_t n, void* stream);
+/* SymbolicModel.fd_func AS THE REFERENCE DEFINES IT (symbolic_systems.py:70-73: cs.integrator('fd', 'cvodes', {x, p, ode},
+ * {'tf': dt})): the flow of x' = f(x, p) over [0, dt] under a constant model input, in float64, to the tolerance the caller
+ * states (CasADi's CVODES defaults are rtol 1e-6, atol 1e-8), for n (x0, p) pairs in one launch -- and, on request, its
+ * forward sensitivities, the integrator's jac_xf_x0 / jac_xf_p.  state [nx][ld], input [nu][ld], inertial (nullable,
+ * [4][ld]) and xf [nx][ld] are float64 SoA planes; dxf_dx0 [n][nx][nx] and dxf_dp [n][nx][nu] are row-major float64
+ * batches; at least one of the three outputs.  Error control is step doubling on RK4 (m and 2m steps; accepted when
+ * |y_2m - y_m| / 15 <= atol + rtol |y| in every component, m doubled at most max_doublings <= 16 times; the value is the
+ * order-5 extrapolation); intervals (nullable, [n]) receives the 2m of the accepted solution, NEGATED where the tolerance
+ * was not met (or the state is not finite).  The sensitivities are central differences of the same discretisation
+ * (internal numerical differentiation: ~1e-9 relative).  dt need not be the handle's control period.  n <= 2^30
+ * (2^26 with sensitivities). */
+int scg_model_flow(scg_handle* h, const double* state, const double* input, const double* inertial, double dt, double rtol,
+                   double atol, int32_t max_doublings, double* xf, double* dxf_dx0, double* dxf_dp, int32_t* intervals,
+                   int64_t ld, int64_t n, void* stream);
 int scg_linearize(scg_handle* h, const float* state, const float* input, const float* inertial, float* dfdx,
                   float* dfdu, double disc_dt, int64_t ld, int64_t n, void* stream);
 /* SymbolicModel.fc_linear_func (symbolic_systems.py:93-101): the model linearised about (state, input), evaluated at

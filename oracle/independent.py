@@ -116,3 +116,35 @@ def exact_step(system, x, u, p, dt):
     sol = solve_ivp(lambda t, y: np.asarray(f(y, u, pv), dtype=float).ravel(), (0.0, dt),
                     np.asarray(x, dtype=float), method='DOP853', rtol=1e-13, atol=1e-15)
     return sol.y[:, -1]
+
+
+_JAC = {}
+
+
+def _jacobians(system):
+    if system not in _JAC:
+        X, U, P, Xdot = symbolic(system)
+        _JAC[system] = (sp.lambdify([X, U, P], Xdot.jacobian(X), 'numpy'), sp.lambdify([X, U, P], Xdot.jacobian(U), 'numpy'))
+    return _JAC[system]
+
+
+def exact_step_sensitivities(system, x, u, p, dt):
+    """(x(dt), d x(dt) / d x0, d x(dt) / d u) with ZOH input: DOP853 at rtol 1e-13 on the variational equations
+    Sx' = A(x) Sx, Sx(0) = I;  Su' = A(x) Su + B(x), Su(0) = 0 -- what CVODES' forward sensitivities of the reference's
+    ``fd_func`` (symbolic_systems.py:70-73) converge to."""
+    f = f_independent(system)
+    fa, fb = _jacobians(system)
+    pv = params_vector(system, p)
+    x = np.asarray(x, dtype=float)
+    nx, nu = x.size, np.asarray(u).size
+
+    def rhs(t, z):
+        y = z[:nx]
+        A = np.asarray(fa(y, u, pv), dtype=float).reshape(nx, nx)
+        B = np.asarray(fb(y, u, pv), dtype=float).reshape(nx, nu)
+        Sx, Su = z[nx:nx + nx * nx].reshape(nx, nx), z[nx + nx * nx:].reshape(nx, nu)
+        return np.concatenate([np.asarray(f(y, u, pv), dtype=float).ravel(), (A @ Sx).ravel(), (A @ Su + B).ravel()])
+
+    z0 = np.concatenate([x, np.eye(nx).ravel(), np.zeros(nx * nu)])
+    z = solve_ivp(rhs, (0.0, dt), z0, method='DOP853', rtol=1e-13, atol=1e-15).y[:, -1]
+    return z[:nx], z[nx:nx + nx * nx].reshape(nx, nx), z[nx + nx * nx:].reshape(nx, nu)

@@ -105,7 +105,7 @@ class ScgDisturbance(C.Structure):
 
 EXPORTS = (
     'scg_create', 'scg_destroy', 'scg_set_reference', 'scg_set_constraints', 'scg_set_disturbances', 'scg_reset', 'scg_step', 'scg_rollout', 'scg_rollout_fused',
-    'scg_eval_constraints', 'scg_gae', 'scg_normalize_advantages', 'scg_model_eval', 'scg_linearize', 'scg_fc_linear', 'scg_discretize_exact', 'scg_quadratic_loss', 'scg_mean_std_normalize', 'scg_reward_normalize', 'scg_num_constraints', 'scg_obs_dim', 'scg_kernel_info', 'scg_rollout_graph_info', 'scg_last_error',
+    'scg_eval_constraints', 'scg_gae', 'scg_normalize_advantages', 'scg_model_eval', 'scg_model_flow', 'scg_linearize', 'scg_fc_linear', 'scg_discretize_exact', 'scg_quadratic_loss', 'scg_mean_std_normalize', 'scg_reward_normalize', 'scg_num_constraints', 'scg_obs_dim', 'scg_kernel_info', 'scg_rollout_graph_info', 'scg_last_error',
     'scg_version', 'scg_sizeof_config', 'scg_sizeof_step_io', 'scg_sizeof_constraint_row', 'scg_sizeof_disturbance',
 )
 
@@ -157,6 +157,8 @@ def load():
     lib.scg_gae.argtypes = [_fp] * 9 + [_i32, C.c_int64, C.c_int64, C.c_float, C.c_float, _i32, C.c_void_p]
     lib.scg_normalize_advantages.argtypes = [_fp, _fp, _i32, C.c_int64, C.c_int64, C.c_float, C.c_void_p]
     lib.scg_model_eval.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int64, C.c_void_p]
+    lib.scg_model_flow.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_double, C.c_double, C.c_double, _i32, _fp, _fp, _fp, _fp,
+                                   C.c_int64, C.c_int64, C.c_void_p]
     lib.scg_linearize.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, _fp, _dbl, C.c_int64, C.c_int64, C.c_void_p]
     lib.scg_fc_linear.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int64, C.c_void_p]
     lib.scg_discretize_exact.argtypes = [_fp, _fp, _i32, _i32, _dbl, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_void_p]

@@ -1,8 +1,7 @@
 #!/bin/bash
 # Build libscg_rollout.so (HIP kernels + C ABI) for gfx950, in-tree.
 # -fno-slp-vectorize: the SLP vectoriser packs the RK4 stages into v_pk_fma_f32 register pairs,
-# which costs 40+ VGPRs (147 vs 103) and a wave of occupancy per SIMD for no FLOP-rate gain (the packed sin / cos of
-# scg_math.h is written with explicit two-lane vectors instead).
+# which costs 40+ VGPRs (147 vs 103) and a wave of occupancy per SIMD for no FLOP-rate gain.
 # The translation units are compiled in parallel (scg_kernels.hip dominates: ~90 s), then linked.  A unit is recompiled
 # when its source, any header of this directory, the C-ABI header or the flags changed (SCG_BUILD_FORCE=1: always).
 set -euo pipefail
@@ -12,7 +11,7 @@ obj="$out/obj"
 mkdir -p "$out" "$obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 flags=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize "$@")
-units=(scg_kernels scg_gae scg_linearize scg_normalize scg_expm scg_capi)
+units=(scg_kernels scg_gae scg_linearize scg_normalize scg_expm scg_flow scg_capi)
 stamp="$obj/flags.txt"
 if [ ! -f "$stamp" ] || [ "$(cat "$stamp")" != "${flags[*]}" ]; then rm -f "$obj"/*.o; echo "${flags[*]}" > "$stamp"; fi
 pids=()

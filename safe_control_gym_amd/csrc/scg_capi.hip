@@ -895,6 +895,24 @@ int scg_model_eval(scg_handle* h, const float* state, const float* input, const 
     return SCG_OK;
 }
 
+int scg_model_flow(scg_handle* h, const double* state, const double* input, const double* inertial, double dt, double rtol,
+                   double atol, int32_t max_doublings, double* xf, double* dxf_dx0, double* dxf_dp, int32_t* intervals,
+                   int64_t ld, int64_t n, void* stream) {
+    if (!h) return fail(SCG_ERR_INVALID, "scg_model_flow: null handle");
+    if (!state || !input || (!xf && !dxf_dx0 && !dxf_dp)) return fail(SCG_ERR_INVALID, "scg_model_flow: null argument");
+    if (n < 0 || ld < n) return fail(SCG_ERR_INVALID, "scg_model_flow: need 0 <= n <= ld");
+    const bool sens = dxf_dx0 || dxf_dp;
+    if (n > ((int64_t)1 << (sens ? 26 : 30))) return fail(SCG_ERR_INVALID, "scg_model_flow: n > 2^%d", sens ? 26 : 30);
+    if (!(dt > 0.0) || !std::isfinite(dt)) return fail(SCG_ERR_INVALID, "scg_model_flow: dt must be positive and finite");
+    if (!(rtol >= 0.0) || !(atol >= 0.0) || !(rtol + atol > 0.0) || !std::isfinite(rtol + atol))
+        return fail(SCG_ERR_INVALID, "scg_model_flow: need rtol >= 0, atol >= 0, not both zero");
+    if (max_doublings < 0 || max_doublings > 16) return fail(SCG_ERR_INVALID, "scg_model_flow: max_doublings must be in 0..16");
+    if (n == 0) return SCG_OK;
+    HIP_TRY(launch_model_flow(h->system, h->phd, state, input, inertial, dt, rtol, atol, max_doublings, xf, dxf_dx0, dxf_dp,
+                              intervals, ld, n, (hipStream_t)stream));
+    return SCG_OK;
+}
+
 int scg_linearize(scg_handle* h, const float* state, const float* input, const float* inertial, float* dfdx,
                   float* dfdu, double disc_dt, int64_t ld, int64_t n, void* stream) {
     if (!h) return fail(SCG_ERR_INVALID, "scg_linearize: null handle");

@@ -171,6 +171,9 @@ hipError_t launch_gae(const float* rew, const float* val, const float* mask, con
 hipError_t launch_normalize(float* adv, const double* stats, int T, int64_t n, int64_t ld, float eps, hipStream_t s);
 hipError_t launch_model_eval(int system, const KParams& p, const KTables* tb, const float* state, const float* input,
                              const float* inertial, float* xdot, float* xnext, int64_t ld, int64_t n, hipStream_t s);
+hipError_t launch_model_flow(int system, const PhysT<double>& ph, const double* state, const double* input,
+                             const double* inertial, double dt, double rtol, double atol, int max_doublings, double* xf,
+                             double* dxf_dx0, double* dxf_dp, int32_t* intervals, int64_t ld, int64_t n, hipStream_t s);
 hipError_t launch_linearize(int system, const PhysT<float>& ph, const float* state, const float* input,
                             const float* inertial, float* dfdx, float* dfdu, float disc_dt, int64_t ld, int64_t n,
                             hipStream_t s);

@@ -659,6 +659,42 @@ class BenchmarkEnv:
         xs, us, inertial, ld = self._model_planes(state, input)
         return self._engine.model_eval(xs, us, inertial, self.num_envs, ld, False, True)[1][:, :self.num_envs].T
 
+    def _rows64(self, t, dim, default):
+        """[num_envs, dim] rows / a (dim,) vector / None -> contiguous float64 planes [dim, num_envs]."""
+        n = self.num_envs
+        if t is None:
+            t = default
+        a = t if isinstance(t, torch.Tensor) else torch.as_tensor(np.asarray(t, dtype=np.float64))
+        a = a.to(device=self.device, dtype=torch.float64)
+        if a.ndim == 1:
+            a = a.reshape(1, dim).expand(n, dim)
+        if a.shape != (n, dim):
+            raise ValueError('[ERROR] expected (num_envs, %d) rows or a (%d,) vector, got %s' % (dim, dim, tuple(a.shape)))
+        return a.T.contiguous()
+
+    def model_flow(self, state=None, input=None, dt=None, rtol=1e-6, atol=1e-8, sensitivities=False, max_doublings=12,
+                   return_intervals=False):
+        """Batched ``symbolic.fd_func`` AS THE REFERENCE DEFINES IT (symbolic_systems.py:70-73: CasADi's CVODES integrator
+        over ``[0, dt]``; its default tolerances are the defaults here): the state each env's prior model reaches after ``dt``
+        (default ``CTRL_TIMESTEP``) under a constant model input, integrated in float64 to ``atol + rtol |x|`` (RK4 with
+        step-doubling error control and order-5 extrapolation) -> ``xf`` [N, nx] float64.  ``sensitivities=True`` adds the
+        integrator's forward sensitivities ``(xf, dxf_dx0 [N, nx, nx], dxf_dp [N, nx, nu])`` (~1e-9 relative).  ``state``
+        defaults to the envs' current states, ``input`` to ``U_EQ``; rows may be float32 or float64.  ``model_step`` is the
+        fixed-step RK4 discretisation of the same model (the reference's ``rk_discrete``)."""
+        self._ensure_engine()
+        n = self.num_envs
+        xs = self._rows64(state, self.state_dim, self._bufs['state'][:self.state_dim, :n].T if state is None else None)
+        us = self._rows64(input, self.action_dim, np.asarray(self.U_EQ, dtype=np.float64))
+        inertial = self._bufs.get('inertial')
+        if inertial is not None:
+            inertial = inertial[:, :n].to(torch.float64).contiguous()
+        xf, sx, su, intervals = self._engine.model_flow(xs, us, inertial, n, n, self.CTRL_TIMESTEP if dt is None else dt, rtol, atol,
+                                                        want_sens=sensitivities, max_doublings=max_doublings)
+        out = (xf.T, sx, su) if sensitivities else xf.T
+        if return_intervals:
+            return (out + (intervals,)) if sensitivities else (out, intervals)
+        return out
+
     def linearize(self, state=None, input=None, discrete=False):
         """Batched ``symbolic.df_func`` (symbolic_systems.py:77-92) on the device: Jacobians of the continuous
         dynamics about each env's (state, input) -> ``(dfdx [N, nx, nx], dfdu [N, nx, nu])`` float32 tensors.

@@ -163,6 +163,24 @@ class Engine:
                                                 self._stream()), 'scg_model_eval')
         return xdot, xnext
 
+    def model_flow(self, state_soa, input_soa, inertial_soa, n, ld, dt, rtol, atol, want_sens=False, max_doublings=12):
+        """fd_func as the reference defines it (symbolic_systems.py:70-73), on float64 SoA planes: the flow over [0, dt] to the
+        stated tolerance -> (xf [nx, ld], dxf_dx0 [n, nx, nx] | None, dxf_dp [n, nx, nu] | None, intervals [n] int32)."""
+        f64 = torch.float64
+        for t in (state_soa, input_soa, inertial_soa):
+            if t is not None and t.dtype != f64:
+                raise TypeError('[ERROR] model_flow works on float64 planes.')
+        xf = torch.empty((self.nx, ld), dtype=f64, device=self.device)
+        sx = torch.empty((n, self.nx, self.nx), dtype=f64, device=self.device) if want_sens else None
+        su = torch.empty((n, self.nx, self.nu), dtype=f64, device=self.device) if want_sens else None
+        intervals = torch.empty(n, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _capi.check(self.lib.scg_model_flow(self.handle, _capi.ptr(state_soa), _capi.ptr(input_soa), _capi.ptr(inertial_soa),
+                                                float(dt), float(rtol), float(atol), int(max_doublings), _capi.ptr(xf),
+                                                _capi.ptr(sx), _capi.ptr(su), _capi.ptr(intervals), ld, n, self._stream()),
+                        'scg_model_flow')
+        return xf, sx, su, intervals
+
     def linearize(self, state_soa, input_soa, inertial_soa, n, ld, disc_dt=0.0):
         """Batched df_func (symbolic_systems.py:77-92): ([n, nx, nx], [n, nx, nu]) for SoA planes [.][ld]."""
         A = torch.empty((n, self.nx, self.nx), dtype=torch.float32, device=self.device)

@@ -8,9 +8,11 @@ objects do and returns a dict with the same output names; inputs may carry leadi
 dimensions (``x`` of shape (..., nx)).
 
 Differences, all deliberate:
-  * ``fd_func`` integrates with the reference's own RK4 (controllers/mpc/mpc_utils.py:79-101),
-    not CVODES (SUNDIALS is not available) -- the same discretisation the device
-    engine steps with.
+  * ``fd_func`` is the flow over ``[0, dt]`` to CasADi's default CVODES tolerances (rtol 1e-6, atol 1e-8) like the
+    reference's, but integrated by RK4 with step-doubling error control and order-5 extrapolation in float64
+    (SUNDIALS is not available): NumPy here, ``scg_model_flow`` for device tensors.  ``fd_jac_func``
+    gives the integrator's forward sensitivities (``jac_xf_x0`` / ``jac_xf_p``).  ``rk4_func`` is ONE fixed RK4 step
+    (the reference's ``rk_discrete``, controllers/mpc/mpc_utils.py:79-101) -- the discretisation the engine steps with.
   * Jacobians come from a sympy derivation of the same equations, lambdified on first use.
 
 The equations are those of quadrotor.py:594-676 (1-D / 2-D / 3-D) and the textbook cart-pole
@@ -78,7 +80,7 @@ class AnalyticModel:
         self.dt = dt
         self.nx, self.nu = _DIMS[system]
         self.ny = self.nx
-        self.integration_algo = 'rk4'
+        self.integration_algo = 'rk4 + step doubling'   # the reference's attribute (:30, 'cvodes'): how fd_func integrates
         self._jac = None
         self.device_backend = None        # the env (weak proxy): torch device tensors go to its HIP kernels
 
@@ -102,17 +104,87 @@ class AnalyticModel:
             return {'f': self._backend().model_dynamics(x, u)}
         return {'f': self._f(x, u)}
 
-    def fd_func(self, x0, p):
-        """One RK4 step of length dt with zero-order-hold input p (device tensors: the env's own integrator)."""
+    def rk4_func(self, x0, p):
+        """One RK4 step of length dt with zero-order-hold input p (controllers/mpc/mpc_utils.py:79-101; device tensors: the
+        env's own integrator)."""
         if _is_device_tensor(x0):
             return {'xf': self._backend().model_step(x0, p)}
+        return {'xf': self._rk4_chain(np.asarray(x0, dtype=np.float64), p, self.dt, 1)}
+
+    def _rk4_chain(self, x, p, dt, m):
+        h = dt / m
+        for _ in range(m):
+            k1 = self._f(x, p)
+            k2 = self._f(x + h / 2 * k1, p)
+            k3 = self._f(x + h / 2 * k2, p)
+            k4 = self._f(x + h * k3, p)
+            x = x + h / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+        return x
+
+    def _extrapolated(self, x0, p, m):
+        y1, y2 = self._rk4_chain(x0, p, self.dt, m), self._rk4_chain(x0, p, self.dt, 2 * m)
+        return y2 + (y2 - y1) / 15.0
+
+    def _flow(self, x0, p, rtol, atol, max_doublings=12):
+        """Step doubling on RK4, accepted per (x0, p) pair (the scheme of csrc/scg_flow.hip): (extrapolated values, the m of
+        each accepted pair)."""
         x0 = np.asarray(x0, dtype=np.float64)
-        dt = self.dt
-        k1 = self._f(x0, p)
-        k2 = self._f(x0 + dt / 2 * k1, p)
-        k3 = self._f(x0 + dt / 2 * k2, p)
-        k4 = self._f(x0 + dt * k3, p)
-        return {'xf': x0 + dt / 6 * (k1 + 2 * k2 + 2 * k3 + k4)}
+        lead = x0.shape[:-1]
+        p = np.broadcast_to(np.asarray(p, dtype=np.float64), lead + (self.nu,)).reshape(-1, self.nu)
+        x0 = x0.reshape(-1, self.nx)
+        out = np.empty_like(x0)
+        ms = np.zeros(x0.shape[0], dtype=np.int64)
+        m = 1
+        y1 = self._rk4_chain(x0, p, self.dt, m)
+        for lvl in range(max_doublings + 1):
+            y2 = self._rk4_chain(x0, p, self.dt, 2 * m)
+            ok = np.all(np.abs(y2 - y1) <= 15.0 * (atol + rtol * np.abs(y2)), axis=-1)
+            take = (ms == 0) & (ok | (lvl == max_doublings))
+            out[take] = (y2 + (y2 - y1) / 15.0)[take]
+            ms[take] = m
+            if np.all(ms > 0):
+                break
+            y1, m = y2, 2 * m
+        return out.reshape(lead + (self.nx,)), ms.reshape(lead)
+
+    def _extrapolated_per_pair(self, x0, p, ms):
+        out = np.empty_like(x0)
+        for m in np.unique(ms):
+            sel = ms == m
+            out[sel] = self._extrapolated(x0[sel], p[sel], int(m))
+        return out
+
+    def fd_func(self, x0, p, rtol=1e-6, atol=1e-8):
+        """The flow of x' = f(x, p) over [0, dt] with constant p, to atol + rtol |x| (symbolic_systems.py:70-73; defaults =
+        CasADi's CVODES defaults).  Device tensors: ``scg_model_flow`` (float64 inside; returned in x0's dtype)."""
+        if _is_device_tensor(x0):
+            return {'xf': self._backend().model_flow(x0, p, dt=self.dt, rtol=rtol, atol=atol).to(x0.dtype)}
+        return {'xf': self._flow(x0, p, rtol, atol)[0]}
+
+    def fd_jac_func(self, x0, p, rtol=1e-6, atol=1e-8):
+        """Forward sensitivities of ``fd_func`` (the CasADi integrator's ``jac_xf_x0`` / ``jac_xf_p``): central differences of
+        the same discretisation (internal numerical differentiation, ~1e-9 relative)."""
+        if _is_device_tensor(x0):
+            xf, sx, su = self._backend().model_flow(x0, p, dt=self.dt, rtol=rtol, atol=atol, sensitivities=True)
+            return {'xf': xf.to(x0.dtype), 'jac_xf_x0': sx.to(x0.dtype), 'jac_xf_p': su.to(x0.dtype)}
+        x0 = np.asarray(x0, dtype=np.float64)
+        lead = x0.shape[:-1]
+        p = np.broadcast_to(np.asarray(p, dtype=np.float64), lead + (self.nu,)).reshape(-1, self.nu)
+        x0 = x0.reshape(-1, self.nx)
+        xf, m = self._flow(x0, p, rtol, atol)
+        cols = []
+        for j in range(self.nx + self.nu):
+            v = x0 if j < self.nx else p
+            k = j if j < self.nx else j - self.nx
+            h = 6.0554544523933395e-6 * np.maximum(np.abs(v[..., k]), 1.0)
+            h = (v[..., k] + h) - v[..., k]
+            e = np.zeros(v.shape[-1]); e[k] = 1.0
+            dv = h[..., None] * e
+            plus = self._extrapolated_per_pair(x0 + dv, p, m) if j < self.nx else self._extrapolated_per_pair(x0, p + dv, m)
+            minus = self._extrapolated_per_pair(x0 - dv, p, m) if j < self.nx else self._extrapolated_per_pair(x0, p - dv, m)
+            cols.append((plus - minus) / (2.0 * h[..., None]))
+        J = np.stack(cols, -1).reshape(lead + (self.nx, self.nx + self.nu))
+        return {'xf': xf.reshape(lead + (self.nx,)), 'jac_xf_x0': J[..., :self.nx], 'jac_xf_p': J[..., self.nx:]}
 
     def g_func(self, x, u):
         return {'g': np.asarray(x, dtype=np.float64)}

@@ -330,6 +330,14 @@ static void check_next_row_entry_points() {
     EXPECT(scg_eval_constraints(h, f.data(), nullptr, f.data(), nullptr, 4, 8, nullptr) == SCG_ERR_INVALID);
     EXPECT(scg_model_eval(h, f.data(), f.data(), nullptr, nullptr, nullptr, 8, 8, nullptr) == SCG_ERR_INVALID);
     EXPECT(scg_model_eval(h, f.data(), f.data(), nullptr, f.data(), nullptr, 8, 8, nullptr) == SCG_OK);
+    EXPECT(scg_model_flow(h, d.data(), d.data(), nullptr, 0.02, 1e-6, 1e-8, 8, nullptr, nullptr, nullptr, nullptr, 8, 8, nullptr) == SCG_ERR_INVALID);   // no output
+    EXPECT(scg_model_flow(h, d.data(), d.data(), nullptr, 0.0, 1e-6, 1e-8, 8, d.data(), nullptr, nullptr, nullptr, 8, 8, nullptr) == SCG_ERR_INVALID);       // dt
+    EXPECT(scg_model_flow(h, d.data(), d.data(), nullptr, 0.02, 0.0, 0.0, 8, d.data(), nullptr, nullptr, nullptr, 8, 8, nullptr) == SCG_ERR_INVALID);        // tolerances
+    EXPECT(scg_model_flow(h, d.data(), d.data(), nullptr, 0.02, 1e-6, 1e-8, 17, d.data(), nullptr, nullptr, nullptr, 8, 8, nullptr) == SCG_ERR_INVALID);     // doublings
+    EXPECT(scg_model_flow(h, d.data(), d.data(), nullptr, 0.02, 1e-6, 1e-8, 8, d.data(), nullptr, nullptr, nullptr, 4, 8, nullptr) == SCG_ERR_INVALID);      // ld < n
+    EXPECT(scg_model_flow(h, d.data(), d.data(), nullptr, 0.02, 1e-6, 1e-8, 8, nullptr, d.data(), nullptr, nullptr, ((int64_t)1 << 26) + 1, ((int64_t)1 << 26) + 1, nullptr) == SCG_ERR_INVALID);   // n with sensitivities
+    EXPECT(scg_model_flow(h, d.data(), d.data(), nullptr, 0.02, 1e-6, 1e-8, 8, d.data(), d.data(), d.data(), (int32_t*)f.data(), 8, 8, nullptr) == SCG_OK);
+    EXPECT(scg_model_flow(h, d.data(), d.data(), nullptr, 0.02, 1e-6, 0.0, 0, d.data(), nullptr, nullptr, nullptr, 8, 0, nullptr) == SCG_OK);                 // n == 0
     EXPECT(scg_linearize(h, f.data(), f.data(), nullptr, f.data(), f.data(), -1.0, 8, 8, nullptr) == SCG_ERR_INVALID);
     EXPECT(scg_linearize(h, f.data(), f.data(), nullptr, f.data(), f.data(), 0.02, 8, 8, nullptr) == SCG_OK);
     EXPECT(scg_fc_linear(h, nullptr, nullptr, f.data(), f.data(), nullptr, f.data(), 8, 8, nullptr) == SCG_ERR_INVALID);

@@ -96,6 +96,7 @@ hipError_t launch_reset(int, const KParams&, const KTables*, float*, float*, int
 hipError_t launch_gae(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, double*, int, int64_t, int64_t, float, float, int, hipStream_t) { ++g_shim.launches; return hipSuccess; }
 hipError_t launch_normalize(float*, const double*, int, int64_t, int64_t, float, hipStream_t) { ++g_shim.launches; return hipSuccess; }
 hipError_t launch_model_eval(int, const KParams&, const KTables*, const float*, const float*, const float*, float*, float*, int64_t, int64_t, hipStream_t) { ++g_shim.launches; return hipSuccess; }
+hipError_t launch_model_flow(int, const PhysT<double>&, const double*, const double*, const double*, double, double, double, int, double*, double*, double*, int32_t*, int64_t, int64_t, hipStream_t) { ++g_shim.launches; return hipSuccess; }
 hipError_t launch_linearize(int, const PhysT<float>&, const float*, const float*, const float*, float*, float*, float, int64_t, int64_t, hipStream_t) { ++g_shim.launches; return hipSuccess; }
 hipError_t launch_fc_linear(int, const PhysT<float>&, const float*, const float*, const float*, const float*, const float*, float*, int64_t, int64_t, hipStream_t) { ++g_shim.launches; return hipSuccess; }
 hipError_t launch_discretize_exact(const float*, const float*, int, int, float, float*, float*, const float*, const float*, float*, int64_t, int, hipStream_t) { ++g_shim.launches; return hipSuccess; }

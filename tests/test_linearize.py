@@ -275,8 +275,8 @@ def test_linearize_c_abi_rejects_bad_arguments(gpu):
 @pytest.mark.gpu
 @pytest.mark.parametrize('system', SYSTEMS)
 def test_model_eval_matches_oracle(gpu, system):
-    """env.symbolic.fc_func / fd_func on device tensors: x_dot = f(x, u) and one zero-order-hold step of the env's
-    integrator for explicit (x, u) pairs, without touching the envs (symbolic_systems.py:68-73)."""
+    """env.symbolic.fc_func / rk4_func on device tensors: x_dot = f(x, u) (symbolic_systems.py:68) and one zero-order-hold step of
+    the env's integrator (rk_discrete, mpc_utils.py:79-101) for explicit (x, u) pairs, without touching the envs."""
     import torch
     n = 333
     env = _make(system, n, ctrl_freq=50, pyb_freq=50)
@@ -287,7 +287,7 @@ def test_model_eval_matches_oracle(gpu, system):
     xt = torch.as_tensor(xs, dtype=torch.float32, device='cuda')
     ut = torch.as_tensor(us, dtype=torch.float32, device='cuda')
     f_dev = env.symbolic.fc_func(xt, ut)['f'].cpu().numpy().astype(np.float64)
-    x_dev = env.symbolic.fd_func(xt, ut)['xf'].cpu().numpy().astype(np.float64)
+    x_dev = env.symbolic.rk4_func(xt, ut)['xf'].cpu().numpy().astype(np.float64)        # (fd_func, the error-controlled flow: tests/test_model_flow.py)
     assert torch.equal(env.state, before)                                  # the envs were not advanced
     p = params_of(system)
     x32, u32 = xs.astype(np.float32).astype(np.float64), us.astype(np.float32).astype(np.float64)

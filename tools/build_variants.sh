@@ -13,7 +13,7 @@ rm -f "$out"/*.o        # arms already in lib/variants stay (e.g. a copy of an e
 build() { # name, extra flags...
   local name="$1"; shift
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c "$src/scg_kernels.hip" -o "$out/$name.o" &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$out/$name.so" "$out/$name.o" "$obj/scg_gae.o" "$obj/scg_linearize.o" "$obj/scg_normalize.o" "$obj/scg_expm.o" "$obj/scg_capi.o" &&
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$out/$name.so" "$out/$name.o" "$obj/scg_gae.o" "$obj/scg_linearize.o" "$obj/scg_normalize.o" "$obj/scg_expm.o" "$obj/scg_flow.o" "$obj/scg_capi.o" &&
     rm -f "$out/$name.o" ) &
 }
 if [ "$#" -gt 0 ]; then
