@@ -282,7 +282,7 @@ class Timer:
         return {'ms': med, 'ms_min': dev[0], 'ms_max': dev[-1], 'wall_ms': wall, 'regions': len(dev)}
 
 
-def sub_record(args, timer, workload, n, steps, track=False, extra=None, note=None):
+def sub_record(args, timer, workload, n, steps, track=False, extra=None, note=None, fused_too=False):
     """One secondary measurement on this GPU (its own env, a few hundred ms)."""
     import torch
     env, name, survey, moved = build_env(args, workload, 0, n, track, extra)
@@ -298,6 +298,9 @@ def sub_record(args, timer, workload, n, steps, track=False, extra=None, note=No
            'achieved_GBs': moved * n / (us * 1e-6) / 1e9, 'frac': moved * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
     if note:
         rec['note'] = note
+    if fused_too:
+        fm = timer.measure(lambda k: env.rollout(acts, steps=k, fused=True), steps, min(args.warmup, 20) + 5, 3)
+        rec['open_loop_fused_us_per_step'] = fm['ms'] * 1e3 / steps
     env.close()
     del env, acts
     torch.cuda.empty_cache()
@@ -580,10 +583,16 @@ def run_rank(args):
         # the north-star's N in {1k ... 1M}: the bare C4 step at each batch size, same clock (a few ms apiece)
         sweep = []
         for e in range(10, 21, 2):
-            r = sub_record(args, timer, 'c4', 1 << e, max(sub_steps, 1000 if e < 18 else 300))
-            sweep.append({'envs': r['envs'], 'steps': r['steps'], 'us_per_step': r['us_per_step'], 'value': r['value'], 'frac': r['frac']})
+            r = sub_record(args, timer, 'c4', 1 << e, max(sub_steps, 1000 if e < 18 else 300), fused_too=True)
+            fus = r['open_loop_fused_us_per_step']
+            sweep.append({'envs': r['envs'], 'steps': r['steps'], 'us_per_step': r['us_per_step'], 'value': r['value'], 'frac': r['frac'],
+                          'open_loop_fused_us_per_step': fus, 'open_loop_fused_value': r['envs'] / (fus * 1e-6)})
         out['n_sweep'] = {'workload': 'bare C4 step (125 B moved per env-step), scg_rollout; below the two-queue threshold the launches are '
-                                      'replayed from a hipGraph (scg_config.rollout_graph)', 'unit': 'env-steps/s', 'points': sweep}
+                                      'replayed from a hipGraph (scg_config.rollout_graph)', 'unit': 'env-steps/s', 'points': sweep,
+                          'open_loop_fused': 'the same action sequence through scg_rollout_fused: ONE launch for all steps, the envs stay in '
+                                             'registers (same states, rewards, auto-resets and episode statistics; per-step observations are '
+                                             'not written: 16 B per env-step, so no roofline fraction) -- what a sampling planner that scores '
+                                             'open-loop action sequences calls; a policy in the loop needs the per-step form'}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)

@@ -23,8 +23,50 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 #endif
 constexpr int kGaeDepth = SCG_GAE_DEPTH;
 
+#ifndef SCG_GAE_W
+#define SCG_GAE_W 2            // envs per lane when the planes allow (n, ld multiples of W, W * 4-byte aligned bases).  Measured at
+#endif                         // T = 128 x 2^20, interleaved on one box (profiles/r03/gae_envs_per_lane_ab.txt): W = 1 / 2 / 4 at depth 4 =
+                               // 0.524-0.540 / 0.502-0.509 / 0.542-0.543 ms (W = 4: 148 VGPRs, 3 waves per SIMD; at depth 2 / 1: 0.527-0.531)
+#ifndef SCG_GAE_NT
+#define SCG_GAE_NT 1           // nontemporal hint on the streaming loads
+#endif
+
+template <int W> struct GaeVec;
+template <> struct GaeVec<1> { typedef float type; };
+template <> struct GaeVec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct GaeVec<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+template <int W>
+__device__ __forceinline__ void gae_load(const float* p, float (&out)[W]) {
+    typedef typename GaeVec<W>::type VT;
+#if SCG_GAE_NT
+    const VT v = __builtin_nontemporal_load(reinterpret_cast<const VT*>(p));
+#else
+    const VT v = *reinterpret_cast<const VT*>(p);
+#endif
+    if constexpr (W == 1) out[0] = v;
+    else {
+#pragma unroll
+        for (int c = 0; c < W; ++c) out[c] = v[c];
+    }
+}
+template <int W>
+__device__ __forceinline__ void gae_store(const float (&in)[W], float* p) {
+    typedef typename GaeVec<W>::type VT;
+    VT v;
+    if constexpr (W == 1) v = in[0];
+    else {
+#pragma unroll
+        for (int c = 0; c < W; ++c) v[c] = in[c];
+    }
+    __builtin_nontemporal_store(v, reinterpret_cast<VT*>(p));
+}
+
 // rew and rew_out carry NO __restrict__: the reference updates the rewards in place (ppo_utils.py:443) and callers pass the
 // same buffer for both; each element is loaded before the same lane stores it.
+// W envs per lane (adjacent columns of every plane): W = 2 makes every access an 8-byte one -- half the memory instructions
+// for the same bytes, twice the bytes in flight per lane of the sequential scan.
+template <int W>
 __global__ __launch_bounds__(256) void scg_gae_kernel(const float* rew, const float* __restrict__ val,
                                                       const float* __restrict__ mask, const float* __restrict__ term_val,
                                                       const float* __restrict__ last_val, float* __restrict__ ret_out,
@@ -32,64 +74,80 @@ __global__ __launch_bounds__(256) void scg_gae_kernel(const float* rew, const fl
                                                       double* __restrict__ stats, int T, uint32_t n, int64_t ld,
                                                       float gamma, float lam, int use_gae) {
     double s1 = 0.0, s2 = 0.0;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        float ret = last_val[i];                     // ppo_utils.py:440: ret, adv = last_val, 0
-        float v_next = ret;                          // vals[T] = last_val (:441)
-        float adv = 0.f;
+    const uint32_t groups = n / W;                   // the launcher picks W = 1 unless n is a multiple of W
+    for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < groups; q += gridDim.x * 256) {
+        const uint32_t i = q * W;
+        float ret[W], v_next[W], adv[W];
+        gae_load<W>(last_val + i, ret);              // ppo_utils.py:440: ret, adv = last_val, 0
+#pragma unroll
+        for (int c = 0; c < W; ++c) { v_next[c] = ret[c]; adv[c] = 0.f; }   // vals[T] = last_val (:441)
         // The scan over t is sequential per lane, so bandwidth comes from bytes in flight: the loads of kGaeDepth steps
-        // are issued together (4 steps x 3-4 planes x 256 B per wave) before the dependent arithmetic of those steps.
-        // Measured at T = 128 x 2^20: depth 1 / 2 / 4 / 8 = 0.568 / 0.563 / 0.515-0.564 / 0.532 ms -- within the box-to-box
-        // noise of each other (~5 TB/s either way); 4 is kept.
+        // are issued together (4 steps x 3-4 planes) before the dependent arithmetic of those steps.
         constexpr int D = kGaeDepth;
         int t = T - 1;
         for (; t >= D - 1; t -= D) {
-            float r[D], v[D], m[D], tv[D];
+            float r[D][W], v[D][W], m[D][W], tv[D][W];
 #pragma unroll
             for (int k = 0; k < D; ++k) {
                 const int64_t o = (int64_t)(t - k) * ld + i;
-                r[k] = __builtin_nontemporal_load(rew + o);
-                v[k] = __builtin_nontemporal_load(val + o);
-                m[k] = __builtin_nontemporal_load(mask + o);
-                tv[k] = term_val ? __builtin_nontemporal_load(term_val + o) : 0.f;
+                gae_load<W>(rew + o, r[k]);
+                gae_load<W>(val + o, v[k]);
+                gae_load<W>(mask + o, m[k]);
+                if (term_val) gae_load<W>(term_val + o, tv[k]);
+                else {
+#pragma unroll
+                    for (int c = 0; c < W; ++c) tv[k][c] = 0.f;
+                }
             }
 #pragma unroll
             for (int k = 0; k < D; ++k) {
-                const float rr = fmaf(gamma, tv[k], r[k]);                    // :443 rews += gamma * terminal_vals
-                const float gm = gamma * m[k];
-                ret = fmaf(gm, ret, rr);                                      // :446
-                if (use_gae) {
-                    const float td = fmaf(gm, v_next, rr) - v[k];             // :450
-                    adv = fmaf(adv * lam, gm, td);                            // :451
-                } else {
-                    adv = ret - v[k];                                         // :448
+                float rr[W];
+#pragma unroll
+                for (int c = 0; c < W; ++c) {
+                    rr[c] = fmaf(gamma, tv[k][c], r[k][c]);                   // :443 rews += gamma * terminal_vals
+                    const float gm = gamma * m[k][c];
+                    ret[c] = fmaf(gm, ret[c], rr[c]);                         // :446
+                    if (use_gae) {
+                        const float td = fmaf(gm, v_next[c], rr[c]) - v[k][c];   // :450
+                        adv[c] = fmaf(adv[c] * lam, gm, td);                  // :451
+                    } else {
+                        adv[c] = ret[c] - v[k][c];                            // :448
+                    }
+                    s1 += (double)adv[c];
+                    s2 += (double)adv[c] * (double)adv[c];
+                    v_next[c] = v[k][c];
                 }
                 const int64_t o = (int64_t)(t - k) * ld + i;
-                __builtin_nontemporal_store(ret, ret_out + o);
-                __builtin_nontemporal_store(adv, adv_out + o);
-                if (rew_out) __builtin_nontemporal_store(rr, rew_out + o);
-                s1 += (double)adv;
-                s2 += (double)adv * (double)adv;
-                v_next = v[k];
+                gae_store<W>(ret, ret_out + o);
+                gae_store<W>(adv, adv_out + o);
+                if (rew_out) gae_store<W>(rr, rew_out + o);
             }
         }
         for (; t >= 0; --t) {                                                 // the T mod D oldest steps
             const int64_t o = (int64_t)t * ld + i;
-            const float r = rew[o], v = val[o], m = mask[o], tv = term_val ? term_val[o] : 0.f;
-            const float rr = fmaf(gamma, tv, r);
-            const float gm = gamma * m;
-            ret = fmaf(gm, ret, rr);
-            if (use_gae) {
-                const float td = fmaf(gm, v_next, rr) - v;
-                adv = fmaf(adv * lam, gm, td);
-            } else {
-                adv = ret - v;
+            float r[W], v[W], m[W], tv[W], rr[W];
+            gae_load<W>(rew + o, r);
+            gae_load<W>(val + o, v);
+            gae_load<W>(mask + o, m);
+            if (term_val) gae_load<W>(term_val + o, tv);
+#pragma unroll
+            for (int c = 0; c < W; ++c) {
+                rr[c] = fmaf(gamma, term_val ? tv[c] : 0.f, r[c]);
+                const float gm = gamma * m[c];
+                ret[c] = fmaf(gm, ret[c], rr[c]);
+                if (use_gae) {
+                    const float td = fmaf(gm, v_next[c], rr[c]) - v[c];
+                    adv[c] = fmaf(adv[c] * lam, gm, td);
+                } else {
+                    adv[c] = ret[c] - v[c];
+                }
+                s1 += (double)adv[c];
+                s2 += (double)adv[c] * (double)adv[c];
+                v_next[c] = v[c];
             }
-            ret_out[o] = ret;
-            adv_out[o] = adv;
-            if (rew_out) rew_out[o] = rr;
-            s1 += (double)adv;
-            s2 += (double)adv * (double)adv;
-            v_next = v;
+            gae_store<W>(ret, ret_out + o);
+            gae_store<W>(adv, adv_out + o);
+            if (rew_out) gae_store<W>(rr, rew_out + o);
         }
     }
     if (stats) {
@@ -139,11 +197,20 @@ __global__ __launch_bounds__(256) void scg_normalize_kernel(float* __restrict__ 
 hipError_t launch_gae(const float* rew, const float* val, const float* mask, const float* term_val,
                       const float* last_val, float* ret, float* adv, float* rew_out, double* stats, int T, int64_t n,
                       int64_t ld, float gamma, float lam, int use_gae, hipStream_t s) {
-    int64_t blocks = (n + 255) / 256;
+    // W envs per lane when every plane row starts on a W * 4-byte boundary and n is a multiple of W; one otherwise
+    constexpr int W = SCG_GAE_W;
+    uintptr_t bits = (uintptr_t)(ld * 4) | (uintptr_t)(n * 4);
+    for (const void* ptr : {(const void*)rew, (const void*)val, (const void*)mask, (const void*)term_val, (const void*)last_val,
+                            (const void*)ret, (const void*)adv, (const void*)rew_out})
+        bits |= reinterpret_cast<uintptr_t>(ptr);
+    const bool wide = W > 1 && (bits & (uintptr_t)(W * 4 - 1)) == 0;
+    int64_t blocks = ((wide ? n / W : n) + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(scg_gae_kernel, dim3((unsigned)blocks), dim3(256), 0, s, rew, val, mask, term_val, last_val, ret,
-                       adv, rew_out, stats, T, (uint32_t)n, ld, gamma, lam, use_gae);
+    if (wide) hipLaunchKernelGGL(scg_gae_kernel<W>, dim3((unsigned)blocks), dim3(256), 0, s, rew, val, mask, term_val, last_val, ret,
+                                 adv, rew_out, stats, T, (uint32_t)n, ld, gamma, lam, use_gae);
+    else hipLaunchKernelGGL(scg_gae_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, rew, val, mask, term_val, last_val, ret,
+                            adv, rew_out, stats, T, (uint32_t)n, ld, gamma, lam, use_gae);
     return hipGetLastError();
 }
 
