@@ -80,6 +80,12 @@ class Quadrotor(BenchmarkEnv):
                  done_on_out_of_bound=True, info_mse_metric_state_weight=None, **kwargs):
         self.QUAD_TYPE = QuadType(quad_type)
         self.SYSTEM = int(self.QUAD_TYPE)
+        # gates / obstacles (quadrotor.py:370-437,1046-1132) need a contact / ray-casting physics engine: the analytic engine flies
+        # through them.  The keys are accepted (the reference's configs carry them) and the caller is told.
+        if kwargs.get('gates') or kwargs.get('obstacles') or kwargs.get('randomized_gates_and_obstacles'):
+            import warnings
+            warnings.warn('[WARNING] gates / obstacles (and done_on_collision / done_on_completion) need a contact physics engine: '
+                          'ignored by the analytic engine (DESIGN.md section 1).', stacklevel=3)
         self.DISTURBANCE_MODES = {'observation': {'dim': -1}, 'action': {'dim': -1}, 'dynamics': {'dim': -1}}
         self.norm_act_scale = norm_act_scale
         self.obs_goal_horizon = obs_goal_horizon

@@ -80,16 +80,14 @@ def draw_config(rng):
     return system, kw, engine, n
 
 
-@pytest.mark.parametrize('seed', range(int(os.environ.get('SCG_FUZZ_SEEDS', '96'))))
-def test_random_configuration_against_the_oracle(gpu, seed):
-    rng = np.random.default_rng(9000 + seed)
-    system, kw, engine, n = draw_config(rng)
-    env, ref, sampler = make_pair(system, n, seed=100 + seed, randomized_init=True, engine_kwargs=engine, **kw)
+def run_against_the_oracle(system, kw, engine, n, seed, rng, steps=14, randomized_init=True, inertial_rand=INERTIAL_RAND):
+    """One configuration, teacher-forced against the float64 oracle for `steps` steps; returns the worst relative error."""
+    env, ref, sampler = make_pair(system, n, seed=100 + seed, randomized_init=randomized_init, engine_kwargs=engine, **kw)
     label = 'system %s n %d %s %s' % (system, n, kw, engine)
     if engine.get('randomized_inertial_prop'):
         from oracle import philox
-        ilo = [INERTIAL_RAND[k]['low'] for k in ('M', 'Ixx', 'Iyy', 'Izz')]
-        ihi = [INERTIAL_RAND[k]['high'] for k in ('M', 'Ixx', 'Iyy', 'Izz')]
+        ilo = [inertial_rand[k]['low'] for k in ('M', 'Ixx', 'Iyy', 'Izz')]
+        ihi = [inertial_rand[k]['high'] for k in ('M', 'Ixx', 'Iyy', 'Izz')]
         for r in ref.envs:
             r.inertial_sampler = lambda i, e: philox.inertial_offsets(100 + seed, i, sampler.serial, ilo, ihi)
     obs_e, obs_r = sync_reset(env, ref, sampler)
@@ -97,7 +95,7 @@ def test_random_configuration_against_the_oracle(gpu, seed):
     spread = 0.3 if 'constraints' in kw else 0.8
     guard = 1.5 if kw.get('done_on_out_of_bound', True) else 1.3
     worst = 0.0
-    for k in range(14):
+    for k in range(steps):
         force_state(env, ref)
         if 'state_lo' in env._bufs:
             env._bufs['state_lo'].zero_()           # teacher forcing sets the hi planes: the residual restarts at 0
@@ -113,8 +111,69 @@ def test_random_configuration_against_the_oracle(gpu, seed):
             for r in ref.envs:                                  # without the 85-degree guard: keep lanes off the Euler singularity
                 if not (np.all(np.isfinite(r.state)) and (system != 3 or abs(r.state[7]) < 1.3)):
                     r.state = r.init_nominal.copy() + 0.01
-    print('fuzz %2d  worst %.2e  %s' % (seed, worst, label))
     env.close()
+    return worst, label
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('SCG_FUZZ_SEEDS', '96'))))
+def test_random_configuration_against_the_oracle(gpu, seed):
+    rng = np.random.default_rng(9000 + seed)
+    system, kw, engine, n = draw_config(rng)
+    worst, label = run_against_the_oracle(system, kw, engine, n, seed, rng)
+    print('fuzz %2d  worst %.2e  %s' % (seed, worst, label))
+
+
+# The reference's one concrete Quadrotor-3D configuration family: competition/level0.yaml .. level3.yaml (quadrotor_config; the harness
+# runs them at ctrl_freq 60 / pyb_freq 240 without the firmware, competition/getting_started.py:57-59,85).  The values below are those
+# files' values for the keys the analytic engine implements; `gates` / `obstacles` (+ their randomisation) are ignored with a warning and
+# `cost: competition` is refused -- both need a contact / ray-casting engine -- so each level runs here under the two
+# costs the path has.  level1 and level2 differ only in the gate randomisation; level3 adds reseed_on_reset: False.
+LEVEL_COMMON = dict(
+    ctrl_freq=60, pyb_freq=240, episode_len_sec=33, done_on_violation=True, task='stabilization',
+    task_info={'stabilization_goal': [-0.5, 2.9, 0.75], 'stabilization_goal_tolerance': 0.15},
+    init_state=dict(init_x=-0.9, init_x_dot=0, init_y=-2.9, init_y_dot=0, init_z=0.03, init_z_dot=0, init_phi=0, init_theta=0,
+                    init_psi=0, init_p=0, init_q=0, init_r=0),
+    gates=[[0.5, -2.5, 0, 0, 0, -1.57, 0], [2, -1.5, 0, 0, 0, 0, 1], [0, 0.2, 0, 0, 0, 1.57, 1], [-0.5, 1.5, 0, 0, 0, 0, 0]],
+    obstacles=[[1.5, -2.5, 0, 0, 0, 0], [0.5, -1, 0, 0, 0, 0], [1.5, 0, 0, 0, 0, 0], [-1, 0, 0, 0, 0, 0]],
+    constraints=[{'constraint_form': 'default_constraint', 'constrained_variable': 'input'},
+                 {'constraint_form': 'bounded_constraint', 'constrained_variable': 'state', 'active_dims': [0, 2, 4],
+                  'upper_bounds': [3, 3, 2], 'lower_bounds': [-3, -3, -0.1]}],
+    normalized_rl_action_space=False, done_on_out_of_bound=False, physics='pyb')
+LEVEL_INIT_RAND = {k: {'distrib': 'uniform', 'low': lo, 'high': hi} for k, (lo, hi) in dict(
+    init_x=(-0.1, 0.1), init_y=(-0.1, 0.1), init_z=(0.0, 0.02), init_phi=(-0.1, 0.1), init_theta=(-0.1, 0.1), init_psi=(-0.1, 0.1)).items()}
+LEVEL_INERTIAL_RAND = {'M': {'distrib': 'uniform', 'low': -0.01, 'high': 0.01}, 'Ixx': {'distrib': 'uniform', 'low': -1e-6, 'high': 1e-6},
+                       'Iyy': {'distrib': 'uniform', 'low': -1e-6, 'high': 1e-6}, 'Izz': {'distrib': 'uniform', 'low': -1e-6, 'high': 1e-6}}
+LEVEL_DISTURBANCES = {'action': [{'disturbance_func': 'white_noise', 'std': 0.001}],
+                      'dynamics': [{'disturbance_func': 'uniform', 'low': [-0.1, -0.1, -0.1], 'high': [0.1, 0.1, 0.1]}]}
+
+
+@pytest.mark.parametrize('cost', ['quadratic', 'rl_reward'])
+@pytest.mark.parametrize('level', [0, 1, 3])
+def test_competition_level_configurations_against_the_oracle(gpu, level, cost):
+    import warnings
+    kw = dict(LEVEL_COMMON, cost=cost)
+    engine = dict(info_level='full')
+    randomized = level >= 1
+    if randomized:
+        kw.update(init_state_randomization_info=LEVEL_INIT_RAND, disturbances=LEVEL_DISTURBANCES)
+        engine.update(randomized_inertial_prop=True, inertial_prop_randomization_info=LEVEL_INERTIAL_RAND)
+    engine['reseed_on_reset'] = level != 3
+    ignored = {k: kw.pop(k) for k in ('gates', 'obstacles')}          # engine-only keys: the oracle has no such arguments
+    engine.update(ignored, randomized_gates_and_obstacles=level >= 2, done_on_collision=True, done_on_completion=True)
+    rng = np.random.default_rng(70 + level)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        worst, label = run_against_the_oracle(3, kw, engine, 70, 40 + level, rng, steps=20, randomized_init=randomized,
+                                              inertial_rand=LEVEL_INERTIAL_RAND)
+    assert any('gates' in str(w.message) for w in caught)            # the caller is told what is not simulated
+    assert worst <= RTOL
+    print('level%d %s  worst %.2e' % (level, cost, worst))
+
+
+def test_competition_cost_is_refused(gpu):
+    import safe_control_gym_amd as scg
+    with pytest.raises(NotImplementedError, match='competition'):
+        scg.make('quadrotor', quad_type=3, num_envs=4, device='cuda', cost='competition', task_info=LEVEL_COMMON['task_info'])
 
 
 @pytest.mark.parametrize('seed', range(int(os.environ.get('SCG_FUZZ_SEEDS', '96')) // 2))
