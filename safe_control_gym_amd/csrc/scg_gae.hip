@@ -217,9 +217,16 @@ hipError_t launch_gae(const float* rew, const float* val, const float* mask, con
 hipError_t launch_normalize(float* adv, const double* stats, int T, int64_t n, int64_t ld, float eps, hipStream_t s) {
     if (T <= 0 || n <= 0) return hipSuccess;
     const bool vec = ((reinterpret_cast<uintptr_t>(adv) | (uintptr_t)(ld * 4)) & 15u) == 0;
-    int64_t per_row = ((vec ? (n + 3) / 4 : n) + 255) / 256;                 // workgroups that cover one plane
-    const int64_t cap = T >= 64 ? 64 : 4096 / T;                              // ~4096 workgroups in all
-    if (per_row > cap) per_row = cap;
+    // One 16-byte unit per thread and NO loop: short-lived waves over a large grid that is dispatched in address order.  A streaming
+    // pass is faster the closer the order in which its accesses ARRIVE follows the addresses (tools/ubench/write_pattern.hip: one
+    // store per wave 6.9 TB/s, 3-48 stores per wave 5.4, a 98-iteration grid-stride loop 4.3).  Measured here at 128 x 2^20, interleaved
+    // on one box (profiles/r03/advnorm_grid_ab.txt): 64 / 128 / 256 / 512 workgroups per row = 240 / 211 / 185 / 178 us; 4 / 2 / 1 units
+    // per thread without a cap = 185 / 178 / 176 us.
+#ifndef SCG_ADVNORM_UNITS
+#define SCG_ADVNORM_UNITS 1
+#endif
+    int64_t per_row = ((vec ? (n + 3) / 4 : n) + 256 * SCG_ADVNORM_UNITS - 1) / (256 * SCG_ADVNORM_UNITS);   // workgroups that cover one plane
+    if (per_row > 65535) per_row = 65535;
     if (per_row < 1) per_row = 1;
     for (int t0 = 0; t0 < T; t0 += 65535) {                                   // (grid.y holds at most 65535 rows)
         const int rows = T - t0 < 65535 ? T - t0 : 65535;
