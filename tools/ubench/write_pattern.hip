@@ -68,6 +68,28 @@ __global__ __launch_bounds__(256) void placed(v4* out, size_t units) {
     out[b * 256 + threadIdx.x] = v;
 }
 
+// the records layout written COOPERATIVELY: a workgroup owns 256 envs (144 KiB of dfdx + 48 KiB of dfdu); in each of 16 passes its four
+// waves together write the next 9 KiB + 3 KiB (wave j the KiB j, j + 4, j + 8 of the pass), a workgroup barrier between passes (where
+// the kernel would restage LDS).  SYNC = false drops the barriers.
+template <bool SYNC>
+__global__ __launch_bounds__(256) void coop_passes(v4* a, v4* b, uint32_t blocks) {
+    if (blockIdx.x >= blocks) return;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const v4 v = {1.f, 2.f, 3.f, (float)lane};
+    v4* pa = a + (size_t)blockIdx.x * (256 * 144 / 4);
+    v4* pb = b + (size_t)blockIdx.x * (256 * 48 / 4);
+#pragma unroll 1
+    for (int p = 0; p < 16; ++p) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int kib = (int)wave + 4 * k;
+            if (kib < 9) pa[(p * 9 + kib) * 64 + lane] = v;
+        }
+        if (wave < 3) pb[(p * 3 + wave) * 64 + lane] = v;
+        if (SYNC) __syncthreads();
+    }
+}
+
 template <bool NT>
 __global__ __launch_bounds__(256) void records(v4* a, v4* b, uint32_t waves) {
     const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -124,9 +146,9 @@ int main() {
     v4* a = reinterpret_cast<v4*>(buf); v4* b = reinterpret_cast<v4*>(buf + bytes_a);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const size_t units = (bytes_a + bytes_b) / 16;
-    const char* names[] = {"linear", "linear_nt", "records", "records_nt", "staged_nt", "tiles4", "tiles4_nt", "tiles1", "tiles16", "runs4", "linear_g2048", "linear_g65536", "hipMemsetD32", "chunks48", "chunks24", "chunks12", "chunks6", "chunks3", "chunks1", "placed_b", "placed_b+1", "placed_perm3", "placed_eighths", "placed_b^1", "placed_8KiB"};
+    const char* names[] = {"linear", "linear_nt", "records", "records_nt", "staged_nt", "tiles4", "tiles4_nt", "tiles1", "tiles16", "runs4", "linear_g2048", "linear_g65536", "hipMemsetD32", "chunks48", "chunks24", "chunks12", "chunks6", "chunks3", "chunks1", "placed_b", "placed_b+1", "placed_perm3", "placed_eighths", "placed_b^1", "placed_8KiB", "coop_passes", "coop_nosync"};
     for (int rep = 0; rep < 3; ++rep) {
-        for (int v = 0; v < 25; ++v) {
+        for (int v = 0; v < 27; ++v) {
             const int R = 20;
             for (int r = -2; r < R; ++r) {
                 if (r == 0) CK(hipEventRecord(e0, nullptr));
@@ -154,6 +176,8 @@ int main() {
                 if (v == 22) hipLaunchKernelGGL((placed<3>), dim3((unsigned)(units / 256)), dim3(256), 0, nullptr, a, units);
                 if (v == 23) hipLaunchKernelGGL((placed<4>), dim3((unsigned)(units / 256)), dim3(256), 0, nullptr, a, units);
                 if (v == 24) hipLaunchKernelGGL((placed<5>), dim3((unsigned)(units / 256)), dim3(256), 0, nullptr, a, units);
+                if (v == 25) hipLaunchKernelGGL((coop_passes<true>), dim3(n / 256), dim3(256), 0, nullptr, a, b, n / 256);
+                if (v == 26) hipLaunchKernelGGL((coop_passes<false>), dim3(n / 256), dim3(256), 0, nullptr, a, b, n / 256);
                 if (v == 4) hipLaunchKernelGGL(staged_nt, dim3(waves / 4), dim3(256), 4 * 16 * 144 * 4, nullptr, a, b, waves, 0.5f);
             }
             CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
