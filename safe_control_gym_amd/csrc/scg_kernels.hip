@@ -55,7 +55,10 @@ constexpr int kBlock = SCG_BLOCK;
 #else
 #define SCG_SGPR_CAP
 #endif
-#define SCG_BOUNDS __launch_bounds__(kBlock, (COMP == 2 ? SCG_ATT_WAVES : (COMP == 1 ? SCG_COMP_WAVES : (SCG_MIN_WAVES > 0 ? SCG_MIN_WAVES : 1)))) SCG_SGPR_CAP
+#ifndef SCG_DIST_WAVES
+#define SCG_DIST_WAVES 5       // ... in the float disturbance-tier instantiations (FT_DIST): 89-93 VGPRs without a spill (left alone: 112, 4 waves; 6: spills)
+#endif
+#define SCG_BOUNDS __launch_bounds__(kBlock, (COMP == 2 ? SCG_ATT_WAVES : (COMP == 1 ? SCG_COMP_WAVES : (SCG_MIN_WAVES > 0 ? SCG_MIN_WAVES : ((FT & 16u) ? SCG_DIST_WAVES : 1))))) SCG_SGPR_CAP
 
 // Philox4x32-10 (Salmon et al., SC'11).  Counter layout shared with oracle/philox.py.
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
@@ -742,6 +745,19 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
     asm volatile("" ::: "memory");
     const uint32_t serial_base = p.serial_base ? *p.serial_base : 0u;
 
+    // The disturbance table is read entry by entry behind data-dependent branches (count -> kind -> parameters).  Read in place that was
+    // ~60 global loads at wave-uniform addresses, each round trip to L2 ahead of the arithmetic that depends on it, in every wave.
+    // Staged once per workgroup with vector loads that travel with the lane loads above, and read from LDS (uniform addresses:
+    // broadcasts): 2^20 envs, interleaved on one box (profiles/r03/dist_table_in_lds.txt), white observation noise C4 52.2 -> 42.1-42.7 us,
+    // C3 35.5 -> 29.5, action noise + dynamics force (the competition levels) 40.6 -> 30.4.
+    __shared__ DistTable s_dist;
+    if (DIST && p.dist) {                            // block-uniform
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(p.dist);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&s_dist);
+        for (int e = threadIdx.x; e < (int)(sizeof(DistTable) / 4); e += kBlock) dst[e] = src[e];
+        __syncthreads();
+    }
+
     if (tracking && (p.flags & F_REF_IN_LDS)) {
         // stage X_GOAL (quadrotor.py:280-325) once per workgroup; rows*NX floats, 16-B vector copies
         const int total4 = (p.ref_rows * NX + 3) >> 2;                      // buffer is padded to 16 B
@@ -786,17 +802,17 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         for (int j = 0; j < NX; ++j) obs_noise[j] = 0.f;
         if (DIST && p.dist) {
             const uint32_t episode = io.episode_id ? ldp(io.episode_id, i4) : 0u;
-            apply_disturbances<NU>(p, p.dist, SCG_DIST_ACTION, 0, i, serial, episode, t, act_noise);
+            apply_disturbances<NU>(p, &s_dist, SCG_DIST_ACTION, 0, i, serial, episode, t, act_noise);
             constexpr int ND = SYS == SCG_QUAD_3D ? 3 : (SYS == SCG_QUAD_2D ? 2 : 1);
             float dn[ND];
 #pragma unroll
             for (int j = 0; j < ND; ++j) dn[j] = 0.f;
-            apply_disturbances<ND>(p, p.dist, SCG_DIST_DYNAMICS, 0, i, serial, episode, t, dn);
+            apply_disturbances<ND>(p, &s_dist, SCG_DIST_DYNAMICS, 0, i, serial, episode, t, dn);
             if constexpr (SYS == SCG_QUAD_3D) { fx += dn[0]; fy += dn[1]; fz += dn[2]; }
             else if constexpr (SYS == SCG_QUAD_2D) { fx += dn[0]; fz += dn[1]; }        // x-z plane (:543-545)
             else if constexpr (SYS == SCG_QUAD_1D) { fz += dn[0]; }                     // z only (:540-542)
             else { fx += dn[0]; }                                                       // cart force
-            apply_disturbances<NX>(p, p.dist, SCG_DIST_OBSERVATION, 0, i, serial, episode, t, obs_noise);
+            apply_disturbances<NX>(p, &s_dist, SCG_DIST_OBSERVATION, 0, i, serial, episode, t, obs_noise);
         }
 
         // ---- before_step / _preprocess_control (benchmark_env.py:394-404, quadrotor.py:815-842) and the state
@@ -1140,7 +1156,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                     // the observation handed back is the one reset() computes: counter 0, its own draws (:497)
 #pragma unroll
                     for (int j = 0; j < NX; ++j) obs_noise[j] = 0.f;
-                    apply_disturbances<NX>(p, p.dist, SCG_DIST_OBSERVATION, 1, i, serial, serial, 0, obs_noise);
+                    apply_disturbances<NX>(p, &s_dist, SCG_DIST_OBSERVATION, 1, i, serial, serial, 0, obs_noise);
                 }
                 if (EXTRA && io.inertial && (p.flags & F_RAND_INERTIAL)) {
                     float prop[4];
