@@ -248,7 +248,7 @@ __device__ __forceinline__ void reset_state_of(const KParams& p, const KTables* 
 // 64/ceil(NX/4) resetting lanes.  `scratch` is kCoopFloats floats of LDS private to this wave.
 constexpr int kCoopFloats = 64 + 64 * 4;
 
-template <int NX>
+template <int NX, bool GEN = true>
 __device__ __forceinline__ void reset_state_coop(const KParams& p, const KTables* __restrict__ tb,
                                                  const float* __restrict__ reset_state, int64_t ld, uint32_t i,
                                                  uint32_t serial, bool need, float* scratch, float (&x)[NX]) {
@@ -256,9 +256,12 @@ __device__ __forceinline__ void reset_state_coop(const KParams& p, const KTables
     constexpr int W = 4 * NB;                 // uniforms per env (>= NX)
     constexpr int JOBS = 64 / NB;             // envs served per pass
     const unsigned long long exec = __ballot(1);
-    if (!(p.flags & F_RAND_INIT) || (p.flags & F_RAND_GENERAL) || exec != ~0ull) {
-        // no randomisation, non-uniform distributions, or a ragged last wave: plain per-lane path
-        if (need) reset_state_of<NX>(p, tb, reset_state, ld, i, serial, x);
+    if (!(p.flags & F_RAND_INIT) || (GEN && (p.flags & F_RAND_GENERAL)) || exec != ~0ull) {
+        // no randomisation, non-uniform distributions, or a ragged last wave: plain per-lane path.  GEN = false (the lean tiers, the
+        // only ones the fused rollout takes: F_RAND_GENERAL selects the catch-all tier) keeps the 15-kind distribution code out of the
+        // instantiation -- inlined per state dim it tripled the fused kernel's code (10.4k static VALU instructions, past the
+        // instruction cache) and cost it 2.5 us per step
+        if (need) reset_state_of<NX, GEN>(p, tb, reset_state, ld, i, serial, x);
         return;
     }
     if (need) {
@@ -744,6 +747,24 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
     // would sit on the critical path of every wave ahead of the first vector load (measured: +1.1 us on a 4.6 us step kernel).
     asm volatile("" ::: "memory");
     const uint32_t serial_base = p.serial_base ? *p.serial_base : 0u;
+#ifndef SCG_XGOAL_EARLY
+#define SCG_XGOAL_EARLY 1
+#endif
+    // Stabilisation: the goal state comes out of the constant table by scalar loads.  Left where it is used -- behind the integration --
+    // every wave meets a cold scalar-cache miss there at its own moment, and the waves of a workgroup then reach the pooled reset's
+    // barriers out of step (3-D stabilisation on two launch queues: 25.8-26.6 us per step against 22.6 for tracking, which gathers its
+    // goal row with a vector load; with the per-wave reset form, no barriers: 22.8-23.2).  Fetched here instead, in the shadow of the
+    // lane loads, and pinned in SGPRs: 23.3-23.9 (profiles/r03/stabilisation_goal_early.txt).  Touching EVERY line of the table here
+    // instead (seven scalar loads and a wait) cost the tracking kernel 4 us: rejected.
+    float xg[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) xg[j] = 0.f;
+    if (SCG_XGOAL_EARLY && !tracking) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) xg[j] = tb->x_goal[j];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) asm volatile("" : "+s"(xg[j]));
+    }
 
     // The disturbance table is read entry by entry behind data-dependent branches (count -> kind -> parameters).  Read in place that was
     // ~60 global loads at wave-uniform addresses, each round trip to L2 ahead of the arithmetic that depends on it, in every wave.
@@ -966,7 +987,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
             for (int j = 0; j < NX; ++j) e[j] = x[j] - e[j];
         } else {
 #pragma unroll
-            for (int j = 0; j < NX; ++j) e[j] = x[j] - tb->x_goal[j];
+            for (int j = 0; j < NX; ++j) e[j] = x[j] - (SCG_XGOAL_EARLY ? xg[j] : tb->x_goal[j]);
         }
 
         // ---- _get_info: mse (quadrotor.py:1015-1025)
@@ -1137,10 +1158,10 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
             float xr[NX];
             if (wg_full) reset_state_wg<NX>(p, tb, io.reset_state, ld, i, serial, need_reset, wg_scratch, kstep & 1, xr);
 #if SCG_WG_RESET
-            else if (!SCG_WG_RESET_FUSED && MODE == MODE_FUSED) reset_state_coop<NX>(p, tb, io.reset_state, ld, i, serial, need_reset, coop_scratch, xr);
+            else if (!SCG_WG_RESET_FUSED && MODE == MODE_FUSED) reset_state_coop<NX, EXTRA>(p, tb, io.reset_state, ld, i, serial, need_reset, coop_scratch, xr);
             else if (need_reset) reset_state_of<NX, EXTRA>(p, tb, io.reset_state, ld, i, serial, xr);   // ragged last workgroup / no randomisation / non-uniform draws
 #else
-            else reset_state_coop<NX>(p, tb, io.reset_state, ld, i, serial, need_reset, coop_scratch, xr);
+            else reset_state_coop<NX, EXTRA>(p, tb, io.reset_state, ld, i, serial, need_reset, coop_scratch, xr);
 #endif
             if (need_reset) {
 #pragma unroll
