@@ -28,7 +28,9 @@ values measure scaling and nothing else:
     asynchronously on a snapshot, overlapping the chunk's step kernels.  ``SCG_BENCH_FORCE_COLLECTIVES=1`` with ``--gpus 1`` runs
     this whole path (every collective, on RCCL) in a one-rank world: the rehearsal a one-GPU box allows.
   * At N = 1 the line also carries sub-records, each a few hundred ms: ``c4_without_episode_stats`` (the bare 125-byte
-    step), ``precise_mode`` (the <= 1e-5-drift-over-1000-steps mode), ``c3`` and ``c2`` (BASELINE configs 3 and 2).
+    step), ``precise_mode`` / ``precise_mode_attitude`` (the <= 1e-5-drift-over-1000-steps modes), ``c3`` and ``c2`` (BASELINE configs 3
+    and 2), ``n_sweep`` (the north-star's N in {1k .. 1M}: the bare step at 2^10 .. 2^20 envs through scg_rollout, and beside it the same
+    action sequences through the one-launch open-loop form scg_rollout_fused).
 Actions are i.i.d. U(a_low, a_high) float32, pre-generated on the device ([300, nu, N]) and reused cyclically; initial /
 reset states are nominal + the reference's uniform offsets (Philox on device).  Inputs are resident in HBM when the
 timed region starts.
