@@ -18,7 +18,11 @@
  *   - every launch is asynchronous on the hipStream_t passed in; no implicit synchronisation.
  *   - return value: 0 on success, negative scg_status on error; nothing throws across the ABI;
  *     scg_last_error() returns a thread-local message for the last failing call.
- *   - a handle is not thread-safe; distinct handles are.  One handle per device.
+ *   - a handle is not thread-safe; distinct handles are.  One handle per device: a handle belongs to the device that was
+ *     current in scg_create(), and every call that takes a handle must be made with THAT device current -- anything else
+ *     returns SCG_ERR_INVALID naming both device indices (the handle's tables live on its device; a launch from another
+ *     one would read them across the fabric, or fault).  The handle-free entry points (scg_gae, scg_normalize_advantages,
+ *     scg_discretize_exact, the normalisers) run on whatever device is current, like any HIP call.
  */
 #ifndef SCG_ROLLOUT_H
 #define SCG_ROLLOUT_H
@@ -29,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SCG_ABI_VERSION 5
+#define SCG_ABI_VERSION 6
 #define SCG_MAX_NX 12        /* quadrotor.py:625  (3-D: nx = 12) */
 #define SCG_MAX_NU 4         /* quadrotor.py:625  (3-D: nu = 4)  */
 #define SCG_MAX_NV 16        /* constrained variable: [state ; raw action], constraints.py:58-63 */
@@ -326,6 +330,71 @@ int scg_rollout(scg_handle* h, const scg_step_io* io, int64_t n, int32_t steps, 
 int scg_rollout_fused(scg_handle* h, const scg_step_io* io, int64_t n, int32_t steps, int64_t action_stride,
                       int32_t action_period, void* stream);
 
+/* ---- the step as the reference's VecEnv protocol splits it: step_async / step_wait ------------------------------------
+ * (env_wrappers/vectorized_env/vec_env.py:47-72; SubprocVecEnv.step_async sends the actions to its workers and returns,
+ * step_wait collects: subproc_vec_env.py:50-63.)  Here the "worker" is a launch queue (HIP stream) OWNED BY THE HANDLE:
+ *   scg_step_async(h, io, n, stream): everything queued on `stream` so far (the policy that produced io->action) happens
+ *     before the step; the step kernel itself is issued on the handle's own queue and the call returns.  Work queued on
+ *     `stream` AFTERWARDS does not wait for it.
+ *   scg_step_wait(h, stream): whatever is queued on `stream` from now on happens after the handle's pending step (a device-side
+ *     event wait; the host never blocks).  Without a pending step it is a no-op.
+ * Why: a step kernel spends ~5 of its ~28 us (2^20 envs) ramping up and draining.  A caller that cuts its batch into two
+ * (or more) independent shards -- one handle each, scg_config.env_index_base = the shard's first global env index, so the
+ * Philox streams and therefore the results are those of the unsplit batch, bit for bit -- and interleaves
+ *     policy(A); step_async(A); policy(B); step_async(B); step_wait(A); policy(A); ...
+ * keeps two step kernels in flight: one shard's ramp-up / drain (and its policy) overlaps the other shard's body, which is
+ * what scg_rollout() does for a pre-recorded action sequence -- with a consumer in the loop.  `stream` may be the handle's
+ * own queue (scg_step_queue): then both calls add no event at all and step_async is scg_step on that queue.  At most one
+ * step may be pending per handle; scg_step_async on a handle with a pending step orders the new step behind it (same
+ * queue).  Every other entry point that launches on a caller's stream (scg_step, scg_reset, scg_rollout ...) first makes
+ * that stream wait for a pending asynchronous step, so mixing the two forms is safe, only serial. */
+int scg_step_async(scg_handle* h, const scg_step_io* io, int64_t n, void* stream);
+int scg_step_wait(scg_handle* h, void* stream);
+/* The handle's own launch queue (a hipStream_t, created on first use; owned by the handle, destroyed with it).  A caller may
+ * run its policy on it (torch.cuda.ExternalStream) so that a shard's policy and step need no cross-stream event. */
+int scg_step_queue(scg_handle* h, void** stream);
+
+/* ---- a trajectory sink for the multi-step forms --------------------------------------------------------------------------
+ * scg_rollout / scg_rollout_fused reuse every output buffer per step: after the call they hold the LAST step's values.  The
+ * harness they stand for uses every step (tests/scripts/verbose_api.py:71-108 prints each one) and the consumer of a rollout
+ * is a [T, N, ...] buffer (controllers/ppo/ppo_utils.py:308-336).  With a sink, step k writes its observation / reward /
+ * done (and, when given, constraint values / violation / truncated / mse) at base + k * stride instead -- straight into
+ * time-major rollout-buffer planes [T][...][ld].  No extra byte moves:
+ *   - per-step launches (scg_rollout_trajectory, fused = 0): when the observation IS the state (io->obs NULL, or the shared
+ *     goal-horizon buffer io->obs == io->state) the state ping-pongs THROUGH the sink -- step k reads slab k - 1 (step 0:
+ *     io->state) and writes slab k (scg_step_io.state_out), so the trajectory is the chain of states itself, 8 nx + 4 nu + 13
+ *     bytes per env-step as ever; the last slab is copied back to io->state once per call (device-to-device, after the last
+ *     step; SCG_SINK_KEEP_STATE_IN_SINK skips it and leaves io->state stale).  An observation buffer of its own (observation
+ *     noise) is simply re-pointed per step.
+ *   - one launch (fused = 1; lean configurations as scg_rollout_fused, others fall back to per-step launches): each lane
+ *     keeps its env in registers and streams the per-step outputs out: 4 nu bytes read + 4 nx + 5 (+ 4 nc + 1) written per
+ *     env-step -- the launch-free form WITH the Gym outputs.
+ * Plane strides inside a slab are io->ld (obs: obs_dim planes; constraint_values: nc planes).  Strides are in ELEMENTS of
+ * the array's type.  Members left NULL keep their scg_step_io behaviour (last step's values).  terminal_record is not sunk.
+ * Results per env are bit-identical to a scg_step loop. */
+#define SCG_SINK_KEEP_STATE_IN_SINK 1u
+typedef struct scg_trajectory_sink {
+    uint32_t struct_size;            /* = sizeof(scg_trajectory_sink) */
+    uint32_t flags;                  /* SCG_SINK_* */
+    float* obs;                      /* [steps][obs_dim][ld]: what step() returns as obs (the reset observation for envs that
+                                        finished and were auto-reset, dummy_vec_env.py:41-47) */
+    int64_t obs_step_stride;         /* >= obs_dim * ld */
+    float* reward;                   /* nullable [steps][>= n] */
+    int64_t reward_step_stride;
+    uint8_t* done;                   /* nullable [steps][>= n] */
+    int64_t done_step_stride;
+    float* constraint_values;        /* nullable [steps][nc][ld] */
+    int64_t constraint_values_step_stride;
+    uint8_t* constraint_violation;   /* nullable [steps][>= n] */
+    int64_t constraint_violation_step_stride;
+    uint8_t* truncated;              /* nullable [steps][>= n]; per-step launches only (info tier) */
+    int64_t truncated_step_stride;
+    float* mse;                      /* nullable [steps][>= n]; per-step launches only (info tier) */
+    int64_t mse_step_stride;
+} scg_trajectory_sink;
+int scg_rollout_trajectory(scg_handle* h, const scg_step_io* io, const scg_trajectory_sink* sink, int64_t n, int32_t steps,
+                           int64_t action_stride, int32_t action_period, int32_t fused, void* stream);
+
 /* ConstraintList.get_values (constraints.py:503-520) on explicit buffers: state [nx][ld],
  * action [nu][ld] (nullable -> only_state semantics: input rows are written as NaN), out [nc][ld]. */
 int scg_eval_constraints(scg_handle* h, const float* state, const float* action, float* c_val,
@@ -432,6 +501,7 @@ int scg_sizeof_config(void);
 int scg_sizeof_step_io(void);
 int scg_sizeof_constraint_row(void);
 int scg_sizeof_disturbance(void);
+int scg_sizeof_trajectory_sink(void);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@ module raises.  Struct layouts mirror the header field for field; ``load()`` cro
 import ctypes as C
 import os
 
-SCG_ABI_VERSION = 5
+SCG_ABI_VERSION = 6
 SCG_MAX_NX = 12
 SCG_MAX_NU = 4
 SCG_MAX_NV = 16
@@ -95,6 +95,23 @@ class ScgStepIO(C.Structure):
     ]
 
 
+class ScgTrajectorySink(C.Structure):
+    """scg_trajectory_sink: step k of a multi-step rollout writes its outputs at base + k * step stride (elements)."""
+    _fields_ = [
+        ('struct_size', C.c_uint32), ('flags', C.c_uint32),
+        ('obs', _fp), ('obs_step_stride', C.c_int64),
+        ('reward', _fp), ('reward_step_stride', C.c_int64),
+        ('done', _fp), ('done_step_stride', C.c_int64),
+        ('constraint_values', _fp), ('constraint_values_step_stride', C.c_int64),
+        ('constraint_violation', _fp), ('constraint_violation_step_stride', C.c_int64),
+        ('truncated', _fp), ('truncated_step_stride', C.c_int64),
+        ('mse', _fp), ('mse_step_stride', C.c_int64),
+    ]
+
+
+SCG_SINK_KEEP_STATE_IN_SINK = 1
+
+
 class ScgDisturbance(C.Structure):
     _fields_ = [
         ('mode', _i32), ('kind', _i32), ('step_offset', _i32), ('max_step', _i32), ('duration', _i32), ('has_mask', _i32),
@@ -105,6 +122,7 @@ class ScgDisturbance(C.Structure):
 
 EXPORTS = (
     'scg_create', 'scg_destroy', 'scg_set_reference', 'scg_set_constraints', 'scg_set_disturbances', 'scg_reset', 'scg_step', 'scg_rollout', 'scg_rollout_fused',
+    'scg_step_async', 'scg_step_wait', 'scg_step_queue', 'scg_rollout_trajectory', 'scg_sizeof_trajectory_sink',
     'scg_eval_constraints', 'scg_gae', 'scg_normalize_advantages', 'scg_model_eval', 'scg_model_flow', 'scg_linearize', 'scg_fc_linear', 'scg_discretize_exact', 'scg_quadratic_loss', 'scg_mean_std_normalize', 'scg_reward_normalize', 'scg_num_constraints', 'scg_obs_dim', 'scg_kernel_info', 'scg_rollout_graph_info', 'scg_last_error',
     'scg_version', 'scg_sizeof_config', 'scg_sizeof_step_io', 'scg_sizeof_constraint_row', 'scg_sizeof_disturbance',
 )
@@ -153,6 +171,11 @@ def load():
     lib.scg_step.argtypes = [C.c_void_p, C.POINTER(ScgStepIO), C.c_int64, C.c_void_p]
     lib.scg_rollout.argtypes = [C.c_void_p, C.POINTER(ScgStepIO), C.c_int64, _i32, C.c_int64, _i32, C.c_void_p]
     lib.scg_rollout_fused.argtypes = [C.c_void_p, C.POINTER(ScgStepIO), C.c_int64, _i32, C.c_int64, _i32, C.c_void_p]
+    lib.scg_step_async.argtypes = [C.c_void_p, C.POINTER(ScgStepIO), C.c_int64, C.c_void_p]
+    lib.scg_step_wait.argtypes = [C.c_void_p, C.c_void_p]
+    lib.scg_step_queue.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.scg_rollout_trajectory.argtypes = [C.c_void_p, C.POINTER(ScgStepIO), C.POINTER(ScgTrajectorySink), C.c_int64, _i32, C.c_int64,
+                                           _i32, _i32, C.c_void_p]
     lib.scg_eval_constraints.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, C.c_int64, C.c_int64, C.c_void_p]
     lib.scg_gae.argtypes = [_fp] * 9 + [_i32, C.c_int64, C.c_int64, C.c_float, C.c_float, _i32, C.c_void_p]
     lib.scg_normalize_advantages.argtypes = [_fp, _fp, _i32, C.c_int64, C.c_int64, C.c_float, C.c_void_p]
@@ -178,7 +201,8 @@ def load():
     if lib.scg_version() != SCG_ABI_VERSION:
         raise ScgError('libscg_rollout.so ABI %d != binding ABI %d' % (lib.scg_version(), SCG_ABI_VERSION))
     for struct, fn in ((ScgConfig, lib.scg_sizeof_config), (ScgStepIO, lib.scg_sizeof_step_io),
-                       (ScgConstraintRow, lib.scg_sizeof_constraint_row), (ScgDisturbance, lib.scg_sizeof_disturbance)):
+                       (ScgConstraintRow, lib.scg_sizeof_constraint_row), (ScgDisturbance, lib.scg_sizeof_disturbance),
+                       (ScgTrajectorySink, lib.scg_sizeof_trajectory_sink)):
         if C.sizeof(struct) != fn():
             raise ScgError('%s layout mismatch: ctypes %d bytes, library %d bytes'
                            % (struct.__name__, C.sizeof(struct), fn()))

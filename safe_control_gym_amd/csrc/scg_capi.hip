@@ -29,7 +29,7 @@ struct scg_handle {
     hipStream_t aux_stream;    // second launch queue of scg_rollout (created on first use); also where rollout graphs are captured / replayed
     hipEvent_t ev_fork, ev_join;
     // hipGraph replay of small-batch rollouts (scg_config.rollout_graph): the launches of a rollout signature seen twice in a
-    // row are captured once and replayed from then on.  The step serial is not baked into the nodes: they read *d_serial.
+    // row are captured once and replayed from then on.  The step serial is not baked into the nodes: they read the entry's device word.
     struct RolloutKey {
         scg_step_io io;        // reset_serial zeroed; every pointer as passed (any change is a different key)
         int64_t n, action_stride;
@@ -39,6 +39,9 @@ struct scg_handle {
         RolloutKey key;
         hipGraphExec_t exec;
         uint64_t last_use;
+        uint32_t* d_serial;    // device word this entry's nodes read the rollout's serial base from (one per entry: two signatures
+                               // replayed on two streams do not share it)
+        hipEvent_t replayed;   // recorded behind every replay; waited for before the exec is destroyed
     };
     static constexpr int kGraphSlots = 4;
     GraphEntry graphs[kGraphSlots];
@@ -46,7 +49,9 @@ struct scg_handle {
     bool last_key_valid;
     bool graph_broken;         // a capture failed once: this handle stays on plain launches
     uint64_t graph_clock;
-    uint32_t* d_serial;        // device word: reset serial base of the rollout being replayed
+    // scg_step_async / scg_step_wait: a step issued on the handle's own queue (aux_stream) that no caller stream has joined yet
+    bool async_pending;
+    hipEvent_t ev_async_in, ev_async_out;
     PhysT<double> phd;
     float* d_ref;          // device, [rows][nx]
     int ref_rows;
@@ -69,6 +74,16 @@ static int fail(int code, const char* fmt, ...) {
         if (_e != hipSuccess)                                                                 \
             return fail(SCG_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),   \
                         __FILE__, __LINE__);                                                  \
+    } while (0)
+
+// One handle per device (include/scg_rollout.h, conventions): the handle's tables and queues live on the device that was current
+// in scg_create(); a call made with another device current would launch against them from the wrong device.
+#define GUARD_DEVICE(h, who)                                                                                   \
+    do {                                                                                                       \
+        int _dev = -1;                                                                                         \
+        if (hipGetDevice(&_dev) != hipSuccess || _dev != (h)->device)                                          \
+            return fail(SCG_ERR_INVALID, "%s: the handle belongs to device %d but device %d is current "      \
+                        "(one handle per device; make the call with the handle's device current)", who, (h)->device, _dev); \
     } while (0)
 
 static bool dims_of(int system, int& nx, int& nu) {
@@ -261,34 +276,47 @@ static void derive_tables(const scg_handle* h, KTables& t) {
 
 // Every instantiated rollout graph bakes the handle's table pointers and constants into its nodes: whatever changes those
 // (scg_set_reference / _constraints / _disturbances) drops the graphs; they are captured again on demand.
-static void drop_rollout_graphs(scg_handle* h) {
-    for (int q = 0; q < scg_handle::kGraphSlots; ++q) {
-        if (h->graphs[q].exec) {
-            // a replay may still be running; the stream it ran on is the caller's and may be gone by now, so wait for the device
-            // (this happens when a table is replaced or the handle is destroyed: not on a hot path)
-            (void)hipDeviceSynchronize();
-            (void)hipGraphExecDestroy(h->graphs[q].exec);
-        }
-        h->graphs[q].exec = nullptr;
+// An exec may still be replaying when it has to go: every replay is followed by an event (GraphEntry::replayed) and the exec is
+// destroyed only after that event has completed.  If the wait itself fails (e.g. another thread holds a global-mode capture) the
+// exec is LEAKED rather than destroyed under a running replay.
+static void retire_graph_entry(scg_handle::GraphEntry& g) {
+    if (g.exec) {
+        const bool idle = !g.replayed || hipEventSynchronize(g.replayed) == hipSuccess;
+        if (idle) (void)hipGraphExecDestroy(g.exec);
+        else (void)hipGetLastError();
     }
+    g.exec = nullptr;
+}
+
+static void drop_rollout_graphs(scg_handle* h) {
+    for (int q = 0; q < scg_handle::kGraphSlots; ++q) retire_graph_entry(h->graphs[q]);
     h->last_key_valid = false;
 }
 
-// The second launch queue (and its fork / join events), created on first use.
+// The handle's own launch queue (second queue of scg_rollout, capture / home queue of scg_step_async) and its events, created on
+// first use.
 static int ensure_aux_queue(scg_handle* h, const char* who) {
     if (h->aux_stream) return SCG_OK;
     hipStream_t s = nullptr;
-    hipEvent_t ef = nullptr, ej = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ef, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ej, hipEventDisableTiming);
+    for (int q = 0; q < 4 && e == hipSuccess; ++q) e = hipEventCreateWithFlags(&ev[q], hipEventDisableTiming);
     if (e != hipSuccess) {
-        if (ej) (void)hipEventDestroy(ej);
-        if (ef) (void)hipEventDestroy(ef);
+        for (int q = 3; q >= 0; --q) if (ev[q]) (void)hipEventDestroy(ev[q]);
         if (s) (void)hipStreamDestroy(s);
-        return fail(SCG_ERR_HIP, "%s: second launch queue: %s", who, hipGetErrorString(e));
+        return fail(SCG_ERR_HIP, "%s: the handle's launch queue: %s", who, hipGetErrorString(e));
     }
-    h->aux_stream = s; h->ev_fork = ef; h->ev_join = ej;
+    h->aux_stream = s; h->ev_fork = ev[0]; h->ev_join = ev[1]; h->ev_async_in = ev[2]; h->ev_async_out = ev[3];
+    return SCG_OK;
+}
+
+// A step issued by scg_step_async runs on the handle's own queue; before anything else of this handle is launched on a caller's
+// stream, that stream is made to wait for it (device-side; a no-op without a pending step or on the handle's queue itself).
+static int join_async(scg_handle* h, hipStream_t stream, const char* who) {
+    if (!h->async_pending || stream == h->aux_stream) return SCG_OK;
+    hipError_t e = hipEventRecord(h->ev_async_out, h->aux_stream);      // everything queued on the handle's queue so far
+    if (e == hipSuccess) e = hipStreamWaitEvent(stream, h->ev_async_out, 0);
+    if (e != hipSuccess) return fail(SCG_ERR_HIP, "%s: joining the pending asynchronous step failed: %s", who, hipGetErrorString(e));
     return SCG_OK;
 }
 
@@ -302,6 +330,7 @@ int scg_sizeof_config(void) { return (int)sizeof(scg_config); }
 int scg_sizeof_step_io(void) { return (int)sizeof(scg_step_io); }
 int scg_sizeof_constraint_row(void) { return (int)sizeof(scg_constraint_row); }
 int scg_sizeof_disturbance(void) { return (int)sizeof(scg_disturbance); }
+int scg_sizeof_trajectory_sink(void) { return (int)sizeof(scg_trajectory_sink); }
 
 int scg_create(const scg_config* cfg, scg_handle** out) {
     if (!cfg || !out) return fail(SCG_ERR_INVALID, "scg_create: null argument");
@@ -341,6 +370,18 @@ int scg_create(const scg_config* cfg, scg_handle** out) {
     for (int q = 0; q < 4; ++q)
         if (cfg->inertial_rand_kind[q] < SCG_RAND_UNIFORM || cfg->inertial_rand_kind[q] > SCG_RAND_KIND_MAX)
             return fail(SCG_ERR_INVALID, "scg_create: inertial_rand_kind[%d] = %d is not a scg_distribution", q, cfg->inertial_rand_kind[q]);
+
+    // SCG_RAND_CHOICE carries its number of values in *_rand_low: 1, 2 or 3 (the kernel selects among p[0..2])
+    for (int j = 0; j < nx; ++j)
+        if (cfg->randomized_init && cfg->init_rand_kind[j] == SCG_RAND_CHOICE &&
+            !(cfg->init_rand_low[j] == 1.0 || cfg->init_rand_low[j] == 2.0 || cfg->init_rand_low[j] == 3.0))
+            return fail(SCG_ERR_INVALID, "scg_create: init_rand_kind[%d] = choice needs a value count of 1, 2 or 3 in init_rand_low (got %g)",
+                        j, cfg->init_rand_low[j]);
+    for (int q = 0; q < 4; ++q)
+        if (cfg->randomized_inertial && cfg->inertial_rand_kind[q] == SCG_RAND_CHOICE &&
+            !(cfg->inertial_rand_low[q] == 1.0 || cfg->inertial_rand_low[q] == 2.0 || cfg->inertial_rand_low[q] == 3.0))
+            return fail(SCG_ERR_INVALID, "scg_create: inertial_rand_kind[%d] = choice needs a value count of 1, 2 or 3 in inertial_rand_low (got %g)",
+                        q, cfg->inertial_rand_low[q]);
 
     if (cfg->randomized_inertial) {
         const double nominal[4] = {cfg->system == SCG_CARTPOLE ? cfg->pole_length : cfg->mass,
@@ -415,14 +456,23 @@ int scg_destroy(scg_handle* h) {
     if (h->d_ref) (void)hipFree(h->d_ref);
     if (h->d_dist) (void)hipFree(h->d_dist);
     drop_rollout_graphs(h);
-    if (h->d_serial) (void)hipFree(h->d_serial);
-    if (h->aux_stream) { (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipStreamDestroy(h->aux_stream); }
+    for (int q = 0; q < scg_handle::kGraphSlots; ++q) {
+        if (h->graphs[q].d_serial) (void)hipFree(h->graphs[q].d_serial);
+        if (h->graphs[q].replayed) (void)hipEventDestroy(h->graphs[q].replayed);
+    }
+    if (h->aux_stream) {
+        (void)hipStreamSynchronize(h->aux_stream);          // a step issued by scg_step_async may still be running on it
+        (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join);
+        (void)hipEventDestroy(h->ev_async_in); (void)hipEventDestroy(h->ev_async_out);
+        (void)hipStreamDestroy(h->aux_stream);
+    }
     delete h;
     return SCG_OK;
 }
 
 int scg_set_disturbances(scg_handle* h, const scg_disturbance* entries, int32_t n) {
     if (!h) return fail(SCG_ERR_INVALID, "scg_set_disturbances: null handle");
+    GUARD_DEVICE(h, "scg_set_disturbances");
     if (n < 0 || (n > 0 && !entries)) return fail(SCG_ERR_INVALID, "scg_set_disturbances: bad entry list");
     DistTable t;
     std::memset(&t, 0, sizeof(t));
@@ -494,6 +544,7 @@ static int check_dist_io(const scg_handle* h, const scg_step_io* io, const char*
 
 int scg_set_reference(scg_handle* h, const double* x_goal, int32_t rows) {
     if (!h || !x_goal) return fail(SCG_ERR_INVALID, "scg_set_reference: null argument");
+    GUARD_DEVICE(h, "scg_set_reference");
     if (rows < 1) return fail(SCG_ERR_INVALID, "scg_set_reference: rows must be >= 1");
     if (h->cfg.task != SCG_TRAJ_TRACKING) return fail(SCG_ERR_INVALID, "scg_set_reference: task is not traj_tracking");
     if (h->cfg.cost == SCG_QUADRATIC && rows < h->cfg.ctrl_steps)
@@ -523,6 +574,7 @@ int scg_set_reference(scg_handle* h, const double* x_goal, int32_t rows) {
 int scg_set_constraints(scg_handle* h, const scg_constraint_row* rows, int32_t n_rows, const double* p_mats,
                         int32_t n_p) {
     if (!h) return fail(SCG_ERR_INVALID, "scg_set_constraints: null handle");
+    GUARD_DEVICE(h, "scg_set_constraints");
     if (n_rows < 0 || n_rows > SCG_MAX_CONSTRAINT_ROWS)
         return fail(SCG_ERR_INVALID, "scg_set_constraints: %d rows (max %d)", n_rows, SCG_MAX_CONSTRAINT_ROWS);
     if (n_rows > 0 && !rows) return fail(SCG_ERR_INVALID, "scg_set_constraints: null rows");
@@ -602,6 +654,7 @@ int scg_reset(scg_handle* h, float* state, float* state_lo, int32_t* step_count,
               int32_t* ep_length, float* obs, const uint8_t* mask, const float* reset_state, float* inertial,
               uint32_t* episode_id, uint32_t reset_serial, int64_t ld, int64_t n, void* stream) {
     if (!h || !state || !step_count) return fail(SCG_ERR_INVALID, "scg_reset: null argument");
+    GUARD_DEVICE(h, "scg_reset");
     if (n < 0 || ld < n) return fail(SCG_ERR_INVALID, "scg_reset: need 0 <= n <= ld (n=%lld ld=%lld)", (long long)n, (long long)ld);
     if (n == 0) return SCG_OK;
     if (n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_reset: n > 2^30 envs per device (32-bit lane offsets)");
@@ -611,44 +664,84 @@ int scg_reset(scg_handle* h, float* state, float* state_lo, int32_t* step_count,
         return fail(SCG_ERR_INVALID, "scg_reset: a per-episode step_offset needs the episode_id plane");
     if (h->dist_obs && obs && obs == state)
         return fail(SCG_ERR_INVALID, "scg_reset: an observation disturbance needs an obs buffer of its own (obs must not alias state)");
+    if (int rc = join_async(h, (hipStream_t)stream, "scg_reset")) return rc;
     HIP_TRY(launch_reset(h->system, h->kp, h->d_tb, state, state_lo, step_count, ep_return, ep_length, obs, mask,
                          reset_state, inertial, episode_id, h->d_ref, reset_serial, ld, n, (hipStream_t)stream));
     return SCG_OK;
 }
 
-int scg_step(scg_handle* h, const scg_step_io* io, int64_t n, void* stream) {
-    if (!h || !io) return fail(SCG_ERR_INVALID, "scg_step: null argument");
+// Argument checks shared by every form of the step (scg_step, scg_step_async, the rollouts validate through it).
+static int step_check(const scg_handle* h, const scg_step_io* io, int64_t n, const char* who) {
+    if (!h || !io) return fail(SCG_ERR_INVALID, "%s: null argument", who);
+    GUARD_DEVICE(h, who);
     if (io->struct_size != sizeof(scg_step_io))
-        return fail(SCG_ERR_INVALID, "scg_step: struct_size %u != %zu", io->struct_size, sizeof(scg_step_io));
-    if (n < 0 || io->ld < n) return fail(SCG_ERR_INVALID, "scg_step: need 0 <= n <= ld (n=%lld ld=%lld)", (long long)n, (long long)io->ld);
+        return fail(SCG_ERR_INVALID, "%s: struct_size %u != %zu", who, io->struct_size, sizeof(scg_step_io));
+    if (n < 0 || io->ld < n) return fail(SCG_ERR_INVALID, "%s: need 0 <= n <= ld (n=%lld ld=%lld)", who, (long long)n, (long long)io->ld);
     if (!io->action || !io->state || !io->step_count || !io->reward || !io->done)
-        return fail(SCG_ERR_INVALID, "scg_step: action, state, step_count, reward and done are mandatory");
+        return fail(SCG_ERR_INVALID, "%s: action, state, step_count, reward and done are mandatory", who);
     if ((h->kp.flags & F_TRACKING) && !h->d_ref)
-        return fail(SCG_ERR_INVALID, "scg_step: traj_tracking needs scg_set_reference() first");
+        return fail(SCG_ERR_INVALID, "%s: traj_tracking needs scg_set_reference() first", who);
     if (h->kp.obs_goal_horizon > 0 && !io->obs)
-        return fail(SCG_ERR_INVALID, "scg_step: obs_goal_horizon > 0 needs an obs buffer (obs does not alias state)");
+        return fail(SCG_ERR_INVALID, "%s: obs_goal_horizon > 0 needs an obs buffer (obs does not alias state)", who);
     if (io->obs_noise && !io->obs)
-        return fail(SCG_ERR_INVALID, "scg_step: obs_noise needs an obs buffer");
+        return fail(SCG_ERR_INVALID, "%s: obs_noise needs an obs buffer", who);
     if (io->terminal_record && (io->terminal_stride < h->obs_dim + 2 || (io->terminal_stride & 3)))
-        return fail(SCG_ERR_INVALID, "scg_step: terminal_stride must be a multiple of 4 and >= obs_dim + 2 = %d (got %lld)",
+        return fail(SCG_ERR_INVALID, "%s: terminal_stride must be a multiple of 4 and >= obs_dim + 2 = %d (got %lld)", who,
                     h->obs_dim + 2, (long long)io->terminal_stride);
     if (io->action_rows > 1 || (io->action_rows && (reinterpret_cast<uintptr_t>(io->action) % (4u * h->nu)) != 0))
-        return fail(SCG_ERR_INVALID, "scg_step: row-major actions must be %d-byte aligned (action_rows in {0, 1})", 4 * h->nu);
-    if (int rc = check_dist_io(h, io, "scg_step")) return rc;
-    if (io->state_lo_kind > 2) return fail(SCG_ERR_INVALID, "scg_step: state_lo_kind must be 0, 1 or 2");
+        return fail(SCG_ERR_INVALID, "%s: row-major actions must be %d-byte aligned (action_rows in {0, 1})", who, 4 * h->nu);
+    if (int rc = check_dist_io(h, io, who)) return rc;
+    if (io->state_lo_kind > 2) return fail(SCG_ERR_INVALID, "%s: state_lo_kind must be 0, 1 or 2", who);
     if (io->state_lo && io->state_lo_kind == 2 && (reinterpret_cast<uintptr_t>(io->state_lo) & 1u))
-        return fail(SCG_ERR_INVALID, "scg_step: int16 residual planes (state_lo_kind = 2) must be 2-byte aligned");
+        return fail(SCG_ERR_INVALID, "%s: int16 residual planes (state_lo_kind = 2) must be 2-byte aligned", who);
     if (io->state_lo && io->state_lo_kind >= 1) {
         if (h->system != SCG_QUAD_3D)
-            return fail(SCG_ERR_UNSUPPORTED, "scg_step: attitude-only residual planes (state_lo_kind = 1, 2) are defined for the 3-D quadrotor");
+            return fail(SCG_ERR_UNSUPPORTED, "%s: attitude-only residual planes (state_lo_kind = 1, 2) are defined for the 3-D quadrotor", who);
         if (h->kp.dist || io->obs || io->inertial || io->action_disturbance || io->dynamics_force || io->stats || io->episode_id ||
             (h->kp.flags & (F_GND | F_DRAG | F_RAND_GENERAL)) || !(h->kp.flags & F_Q_DIAG))
-            return fail(SCG_ERR_UNSUPPORTED, "scg_step: state_lo_kind = 1 / 2 supports the lean and info configurations only "
-                                             "(no disturbances, aero terms, per-env inertia, full Q / R, obs buffer)");
+            return fail(SCG_ERR_UNSUPPORTED, "%s: state_lo_kind = 1 / 2 supports the lean and info configurations only "
+                                             "(no disturbances, aero terms, per-env inertia, full Q / R, obs buffer)", who);
     }
+    if (n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "%s: n > 2^30 envs per device (32-bit lane offsets)", who);
+    return SCG_OK;
+}
+
+int scg_step(scg_handle* h, const scg_step_io* io, int64_t n, void* stream) {
+    if (int rc = step_check(h, io, n, "scg_step")) return rc;
     if (n == 0) return SCG_OK;
-    if (n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_step: n > 2^30 envs per device (32-bit lane offsets)");
+    if (int rc = join_async(h, (hipStream_t)stream, "scg_step")) return rc;
     HIP_TRY(launch_step(h->system, h->kp, *io, h->d_tb, h->d_con, h->d_ref, n, h->num_cus, (hipStream_t)stream));
+    return SCG_OK;
+}
+
+int scg_step_async(scg_handle* h, const scg_step_io* io, int64_t n, void* stream) {
+    if (int rc = step_check(h, io, n, "scg_step_async")) return rc;
+    if (n == 0) return SCG_OK;
+    if (int rc = ensure_aux_queue(h, "scg_step_async")) return rc;
+    hipStream_t s = (hipStream_t)stream, q = h->aux_stream;
+    if (s != q) {
+        // the policy's writes (io->action) and whatever else the caller queued come first
+        HIP_TRY(hipEventRecord(h->ev_async_in, s));
+        HIP_TRY(hipStreamWaitEvent(q, h->ev_async_in, 0));
+    }
+    HIP_TRY(launch_step(h->system, h->kp, *io, h->d_tb, h->d_con, h->d_ref, n, h->num_cus, q));
+    h->async_pending = true;
+    return SCG_OK;
+}
+
+int scg_step_wait(scg_handle* h, void* stream) {
+    if (!h) return fail(SCG_ERR_INVALID, "scg_step_wait: null handle");
+    GUARD_DEVICE(h, "scg_step_wait");
+    if (int rc = join_async(h, (hipStream_t)stream, "scg_step_wait")) return rc;
+    h->async_pending = false;
+    return SCG_OK;
+}
+
+int scg_step_queue(scg_handle* h, void** stream) {
+    if (!h || !stream) return fail(SCG_ERR_INVALID, "scg_step_queue: null argument");
+    GUARD_DEVICE(h, "scg_step_queue");
+    if (int rc = ensure_aux_queue(h, "scg_step_queue")) return rc;
+    *stream = (void*)h->aux_stream;
     return SCG_OK;
 }
 
@@ -665,6 +758,7 @@ static scg_step_io shifted_io(const scg_step_io& io, int64_t first) {
     s.inertial = const_cast<float*>(f32(io.inertial));
     s.state = const_cast<float*>(f32(io.state));
     s.state_lo = const_cast<float*>(f32(io.state_lo));
+    s.state_out = const_cast<float*>(f32(io.state_out));
     if (io.state_lo && io.state_lo_kind == 2)                            // int16 planes: `first` elements are 2 bytes each
         s.state_lo = reinterpret_cast<float*>(reinterpret_cast<int16_t*>(io.state_lo) + first);
     s.step_count = io.step_count ? io.step_count + first : nullptr;
@@ -712,7 +806,14 @@ static int rollout_by_graph(scg_handle* h, const scg_step_io* io, int64_t n, int
         if (!second) return kGraphNotTaken;                             // first sighting: plain launches, remember the signature
         if (int rc = scg_step(h, io, 0, s0)) return rc;                 // validates the buffers, launches nothing (n = 0)
         if (int rc = ensure_aux_queue(h, "scg_rollout")) return rc;
-        if (!h->d_serial && hipMalloc(&h->d_serial, sizeof(uint32_t)) != hipSuccess) {
+        // the slot first (an empty one, else the least recently used): its own serial word is baked into the nodes
+        scg_handle::GraphEntry* slot = &h->graphs[0];
+        for (int q = 0; q < scg_handle::kGraphSlots; ++q) {
+            if (!h->graphs[q].exec) { slot = &h->graphs[q]; break; }
+            if (h->graphs[q].last_use < slot->last_use) slot = &h->graphs[q];
+        }
+        if ((!slot->d_serial && hipMalloc(&slot->d_serial, sizeof(uint32_t)) != hipSuccess) ||
+            (!slot->replayed && hipEventCreateWithFlags(&slot->replayed, hipEventDisableTiming) != hipSuccess)) {
             (void)hipGetLastError();
             h->graph_broken = true;
             return kGraphNotTaken;
@@ -724,7 +825,7 @@ static int rollout_by_graph(scg_handle* h, const scg_step_io* io, int64_t n, int
             return kGraphNotTaken;
         }
         KParams kp = h->kp;
-        kp.serial_base = h->d_serial;                                   // the nodes read the serial of the rollout being replayed
+        kp.serial_base = slot->d_serial;                                // the nodes read the serial of the rollout being replayed
         scg_step_io local = *io;
         hipError_t err = hipSuccess;
         for (int32_t k = 0; k < steps && err == hipSuccess; ++k) {
@@ -743,15 +844,7 @@ static int rollout_by_graph(scg_handle* h, const scg_step_io* io, int64_t n, int
             h->graph_broken = true;                                     // plain launches from now on (this call included)
             return kGraphNotTaken;
         }
-        scg_handle::GraphEntry* slot = &h->graphs[0];
-        for (int q = 0; q < scg_handle::kGraphSlots; ++q) {
-            if (!h->graphs[q].exec) { slot = &h->graphs[q]; break; }
-            if (h->graphs[q].last_use < slot->last_use) slot = &h->graphs[q];
-        }
-        if (slot->exec) {                                               // least recently used
-            (void)hipDeviceSynchronize();
-            (void)hipGraphExecDestroy(slot->exec);
-        }
+        retire_graph_entry(*slot);                                      // least recently used: waits for ITS last replay only
         slot->key = key;
         slot->exec = exec;
         hit = slot;
@@ -759,22 +852,44 @@ static int rollout_by_graph(scg_handle* h, const scg_step_io* io, int64_t n, int
     hit->last_use = ++h->graph_clock;
     // Replayed on the CALLER's stream, in order with its other work.  (Replaying on the handle's queue, forked from / joined into
     // the caller's stream by events, costs 1.1 us MORE per node than plain launches when that stream is the legacy default
-    // stream -- tools/ubench/graph_launch.hip: 4.09 vs 3.20 plain vs 2.99 replayed in place.)
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)h->d_serial, (int)io->reset_serial, 1, s0));
+    // stream -- tools/ubench/graph_launch.hip: 4.09 vs 3.20 plain vs 2.99 replayed in place.)  One signature must not be in flight
+    // on two streams at once: its replays share the entry's serial word (distinct signatures have distinct words).
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)hit->d_serial, (int)io->reset_serial, 1, s0));
     HIP_TRY(hipGraphLaunch(hit->exec, s0));
+    HIP_TRY(hipEventRecord(hit->replayed, s0));
     return SCG_OK;
 }
 
-int scg_rollout(scg_handle* h, const scg_step_io* io, int64_t n, int32_t steps, int64_t action_stride,
-                int32_t action_period, void* stream) {
-    if (!h || !io) return fail(SCG_ERR_INVALID, "scg_rollout: null argument");
-    if (steps < 0 || action_period < 1 || action_stride < 0)
-        return fail(SCG_ERR_INVALID, "scg_rollout: need steps >= 0, action_period >= 1, action_stride >= 0");
-    if (io->action_rows) return fail(SCG_ERR_INVALID, "scg_rollout: actions are [period][nu][ld] planes (action_rows must be 0)");
-    if (io->state_out && io->state_out != io->state) return fail(SCG_ERR_INVALID, "scg_rollout: a multi-step rollout updates the state in place (state_out must be NULL)");
-    if (n < 0 || io->ld < n || n > (int64_t)1 << 30)
-        return fail(SCG_ERR_INVALID, "scg_rollout: need 0 <= n <= ld and n <= 2^30 (n=%lld ld=%lld)", (long long)n, (long long)io->ld);
-    if (steps == 0) return SCG_OK;
+// Step k of a rollout that writes into a trajectory sink: the same buffers with this step's output pointers.  When the
+// observation IS the state (no obs buffer, or the shared goal-horizon buffer obs == state) the state ping-pongs through the
+// sink: step k reads slab k - 1 (step 0: io.state) and writes slab k.
+static bool sink_obs_is_state(const scg_step_io& io) { return !io.obs || io.obs == io.state; }
+
+static scg_step_io sunk_io(const scg_step_io& io, const scg_trajectory_sink* sink, int32_t k) {
+    scg_step_io s = io;
+    if (!sink) return s;
+    if (sink->obs) {
+        float* slab = sink->obs + (int64_t)k * sink->obs_step_stride;
+        if (sink_obs_is_state(io)) {
+            s.state = k == 0 ? io.state : sink->obs + (int64_t)(k - 1) * sink->obs_step_stride;
+            s.state_out = slab;
+            if (io.obs) s.obs = slab;
+        } else {
+            s.obs = slab;
+        }
+    }
+    if (sink->reward) s.reward = sink->reward + (int64_t)k * sink->reward_step_stride;
+    if (sink->done) s.done = sink->done + (int64_t)k * sink->done_step_stride;
+    if (sink->constraint_values) s.constraint_values = sink->constraint_values + (int64_t)k * sink->constraint_values_step_stride;
+    if (sink->constraint_violation) s.constraint_violation = sink->constraint_violation + (int64_t)k * sink->constraint_violation_step_stride;
+    if (sink->truncated) s.truncated = sink->truncated + (int64_t)k * sink->truncated_step_stride;
+    if (sink->mse) s.mse = sink->mse + (int64_t)k * sink->mse_step_stride;
+    return s;
+}
+
+// The per-step launches of scg_rollout / scg_rollout_trajectory (`sink` nullable).
+static int rollout_launches(scg_handle* h, const scg_step_io* io, const scg_trajectory_sink* sink, int64_t n, int32_t steps,
+                            int64_t action_stride, int32_t action_period, void* stream, const char* who) {
     // Two launch queues.  A step kernel spends ~5 us of its ~28 us (2^20 envs) ramping up and draining; the envs are
     // independent, so the batch is cut in two halves whose step chains run on two streams: the tail of one half's
     // kernel overlaps the body of the other's (measured 24.9 vs 29.0 us per step of the whole batch; four queues are
@@ -783,12 +898,10 @@ int scg_rollout(scg_handle* h, const scg_step_io* io, int64_t n, int32_t steps, 
     const int64_t split_min = h->cfg.rollout_split_min > 0 ? h->cfg.rollout_split_min : (int64_t)131072;
     const int64_t half = (n / 2) / 256 * 256;
     if (queues == 2 && steps >= 2 && half >= split_min && half > 0) {
-        if (int rc = scg_step(h, io, 0, stream)) return rc;                 // validates the buffers, launches nothing (n = 0)
-        if (int rc = ensure_aux_queue(h, "scg_rollout")) return rc;
+        if (int rc = ensure_aux_queue(h, who)) return rc;
         hipStream_t s0 = (hipStream_t)stream, s1 = h->aux_stream;
         HIP_TRY(hipEventRecord(h->ev_fork, s0));                            // nothing runs on s1 yet: plain returns are safe
         HIP_TRY(hipStreamWaitEvent(s1, h->ev_fork, 0));
-        scg_step_io a = *io, b = shifted_io(*io, half);
         KParams kb = h->kp;
         kb.env_base += half;                                               // Philox streams follow the global env index
         // From here on s1 may hold work on the caller's buffers: whatever fails, s1 is joined back into s0 before this
@@ -796,10 +909,10 @@ int scg_rollout(scg_handle* h, const scg_step_io* io, int64_t n, int32_t steps, 
         hipError_t err = hipSuccess;
         const char* what = "";
         for (int32_t k = 0; k < steps && err == hipSuccess; ++k) {
-            const float* act = io->action + (int64_t)(k % action_period) * action_stride;
-            a.action = act;
-            b.action = act + half;
-            a.reset_serial = b.reset_serial = io->reset_serial + (uint32_t)k;
+            scg_step_io a = sunk_io(*io, sink, k);
+            a.action = io->action + (int64_t)(k % action_period) * action_stride;
+            a.reset_serial = io->reset_serial + (uint32_t)k;
+            const scg_step_io b = shifted_io(a, half);
             err = launch_step(h->system, h->kp, a, h->d_tb, h->d_con, h->d_ref, half, h->num_cus, s0);
             what = "launch_step (first half)";
             if (err != hipSuccess) break;
@@ -813,49 +926,109 @@ int scg_rollout(scg_handle* h, const scg_step_io* io, int64_t n, int32_t steps, 
             (void)hipStreamSynchronize(s1);
             if (err == hipSuccess) { err = je; what = "join of the second launch queue"; }
         }
-        if (err != hipSuccess) return fail(SCG_ERR_HIP, "scg_rollout: %s failed: %s", what, hipGetErrorString(err));
+        if (err != hipSuccess) return fail(SCG_ERR_HIP, "%s: %s failed: %s", who, what, hipGetErrorString(err));
         return SCG_OK;
     }
     // Small batches: a step kernel lasts a few microseconds and the launches themselves set the pace.  A rollout signature
     // (buffers, n, steps, action layout) seen twice in a row is captured into a hipGraph once and replayed from then on
-    // (measured at the BASELINE sizes: CartPole 2^16 4.96 -> 4.30, Quadrotor-2D 2^18 8.48 -> 7.85 us per step).
-    if (n > 0 && steps >= kGraphMinSteps && h->cfg.rollout_graph >= 0 && !h->graph_broken) {
+    // (measured at the BASELINE sizes: CartPole 2^16 4.96 -> 4.30, Quadrotor-2D 2^18 8.48 -> 7.85 us per step).  Not with a
+    // sink: its launch-free form is the fused one.
+    if (!sink && n > 0 && steps >= kGraphMinSteps && h->cfg.rollout_graph >= 0 && !h->graph_broken) {
         const int rc = rollout_by_graph(h, io, n, steps, action_stride, action_period, (hipStream_t)stream);
         if (rc != kGraphNotTaken) return rc;
     }
-    scg_step_io local = *io;
     for (int32_t k = 0; k < steps; ++k) {
+        scg_step_io local = sunk_io(*io, sink, k);
         local.action = io->action + (int64_t)(k % action_period) * action_stride;
         local.reset_serial = io->reset_serial + (uint32_t)k;
-        const int rc = scg_step(h, &local, n, stream);
-        if (rc != SCG_OK) return rc;
+        HIP_TRY(launch_step(h->system, h->kp, local, h->d_tb, h->d_con, h->d_ref, n, h->num_cus, (hipStream_t)stream));
+    }
+    return SCG_OK;
+}
+
+static int rollout_check(const scg_handle* h, const scg_step_io* io, int64_t n, int32_t steps, int64_t action_stride,
+                         int32_t action_period, const char* who) {
+    if (!h || !io) return fail(SCG_ERR_INVALID, "%s: null argument", who);
+    GUARD_DEVICE(h, who);
+    if (steps < 0 || action_period < 1 || action_stride < 0)
+        return fail(SCG_ERR_INVALID, "%s: need steps >= 0, action_period >= 1, action_stride >= 0", who);
+    if (io->struct_size == sizeof(scg_step_io) && io->action_rows)
+        return fail(SCG_ERR_INVALID, "%s: actions are [period][nu][ld] planes (action_rows must be 0)", who);
+    if (io->struct_size == sizeof(scg_step_io) && io->state_out && io->state_out != io->state)
+        return fail(SCG_ERR_INVALID, "%s: a multi-step rollout updates the state in place (state_out must be NULL)", who);
+    return step_check(h, io, n, who);
+}
+
+int scg_rollout(scg_handle* h, const scg_step_io* io, int64_t n, int32_t steps, int64_t action_stride,
+                int32_t action_period, void* stream) {
+    if (int rc = rollout_check(h, io, n, steps, action_stride, action_period, "scg_rollout")) return rc;
+    if (steps == 0 || n == 0) return SCG_OK;
+    if (int rc = join_async(h, (hipStream_t)stream, "scg_rollout")) return rc;
+    return rollout_launches(h, io, nullptr, n, steps, action_stride, action_period, stream, "scg_rollout");
+}
+
+int scg_rollout_trajectory(scg_handle* h, const scg_step_io* io, const scg_trajectory_sink* sink, int64_t n, int32_t steps,
+                           int64_t action_stride, int32_t action_period, int32_t fused, void* stream) {
+    const char* who = "scg_rollout_trajectory";
+    if (!sink) return fail(SCG_ERR_INVALID, "%s: null sink", who);
+    if (sink->struct_size != sizeof(scg_trajectory_sink))
+        return fail(SCG_ERR_INVALID, "%s: sink struct_size %u != %zu", who, sink->struct_size, sizeof(scg_trajectory_sink));
+    if (int rc = rollout_check(h, io, n, steps, action_stride, action_period, who)) return rc;
+    if (sink->flags & ~SCG_SINK_KEEP_STATE_IN_SINK) return fail(SCG_ERR_INVALID, "%s: unknown sink flags 0x%x", who, sink->flags);
+    const int64_t ld = io->ld;
+    const int obs_planes = io->obs ? h->obs_dim : h->nx;
+    struct Member { const void* p; int64_t stride, least; const char* name; };
+    const Member members[7] = {{sink->obs, sink->obs_step_stride, (int64_t)obs_planes * ld, "obs"},
+                               {sink->reward, sink->reward_step_stride, n, "reward"},
+                               {sink->done, sink->done_step_stride, n, "done"},
+                               {sink->constraint_values, sink->constraint_values_step_stride, (int64_t)h->n_con_rows * ld, "constraint_values"},
+                               {sink->constraint_violation, sink->constraint_violation_step_stride, n, "constraint_violation"},
+                               {sink->truncated, sink->truncated_step_stride, n, "truncated"},
+                               {sink->mse, sink->mse_step_stride, n, "mse"}};
+    for (const Member& m : members)
+        if (m.p && steps > 1 && m.stride < m.least)
+            return fail(SCG_ERR_INVALID, "%s: %s_step_stride %lld is smaller than one step's slab (%lld elements)", who, m.name,
+                        (long long)m.stride, (long long)m.least);
+    if ((sink->constraint_values || sink->constraint_violation) && h->n_con_rows == 0)
+        return fail(SCG_ERR_INVALID, "%s: a constraint sink needs scg_set_constraints() first", who);
+    if (sink->obs && sink_obs_is_state(*io) && (sink->obs == io->state || (reinterpret_cast<uintptr_t>(sink->obs) & 3u)))
+        return fail(SCG_ERR_INVALID, "%s: the obs sink must be a buffer of its own (the state ping-pongs through it)", who);
+    if (steps == 0 || n == 0) return SCG_OK;
+    if (int rc = join_async(h, (hipStream_t)stream, who)) return rc;
+    if (fused && fused_rollout_ok(h->kp, *io) && !sink->truncated && !sink->mse) {
+        RolloutArgs ro{steps, action_period, action_stride, sink->obs, sink->obs_step_stride, sink->reward, sink->reward_step_stride,
+                       sink->done, sink->done_step_stride, sink->constraint_values, sink->constraint_values_step_stride,
+                       sink->constraint_violation, sink->constraint_violation_step_stride};
+        HIP_TRY(launch_rollout_fused(h->system, h->kp, *io, h->d_tb, h->d_con, h->d_ref, n, ro, h->num_cus, (hipStream_t)stream));
+        return SCG_OK;
+    }
+    if (int rc = rollout_launches(h, io, sink, n, steps, action_stride, action_period, stream, who)) return rc;
+    if (sink->obs && sink_obs_is_state(*io) && !(sink->flags & SCG_SINK_KEEP_STATE_IN_SINK)) {
+        // the chain of states ran through the sink: bring the last slab home (once per call, behind the last step and the join)
+        const float* last = sink->obs + (int64_t)(steps - 1) * sink->obs_step_stride;
+        const size_t bytes = ((size_t)(obs_planes - 1) * (size_t)ld + (size_t)n) * sizeof(float);
+        HIP_TRY(hipMemcpyAsync(io->state, last, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     }
     return SCG_OK;
 }
 
 int scg_rollout_fused(scg_handle* h, const scg_step_io* io, int64_t n, int32_t steps, int64_t action_stride,
                       int32_t action_period, void* stream) {
-    if (!h || !io) return fail(SCG_ERR_INVALID, "scg_rollout_fused: null argument");
-    if (io->struct_size != sizeof(scg_step_io)) return fail(SCG_ERR_INVALID, "scg_rollout_fused: bad struct_size");
-    if (steps < 0 || action_period < 1 || action_stride < 0)
-        return fail(SCG_ERR_INVALID, "scg_rollout_fused: need steps >= 0, action_period >= 1, action_stride >= 0");
-    if (io->action_rows) return fail(SCG_ERR_INVALID, "scg_rollout_fused: actions are [period][nu][ld] planes (action_rows must be 0)");
-    if (io->state_out && io->state_out != io->state) return fail(SCG_ERR_INVALID, "scg_rollout_fused: a multi-step rollout updates the state in place (state_out must be NULL)");
+    if (int rc = rollout_check(h, io, n, steps, action_stride, action_period, "scg_rollout_fused")) return rc;
     if (steps == 0 || n == 0) return SCG_OK;
     if (!fused_rollout_ok(h->kp, *io)) return scg_rollout(h, io, n, steps, action_stride, action_period, stream);
-    if (n < 0 || io->ld < n || n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_rollout_fused: bad n / ld");
-    if (!io->action || !io->state || !io->step_count || !io->reward || !io->done)
-        return fail(SCG_ERR_INVALID, "scg_rollout_fused: action, state, step_count, reward and done are mandatory");
-    if ((h->kp.flags & F_TRACKING) && !h->d_ref)
-        return fail(SCG_ERR_INVALID, "scg_rollout_fused: traj_tracking needs scg_set_reference() first");
-    HIP_TRY(launch_rollout_fused(h->system, h->kp, *io, h->d_tb, h->d_con, h->d_ref, n, steps, action_stride,
-                                 action_period, h->num_cus, (hipStream_t)stream));
+    if (int rc = join_async(h, (hipStream_t)stream, "scg_rollout_fused")) return rc;
+    RolloutArgs ro;
+    std::memset(&ro, 0, sizeof(ro));
+    ro.steps = steps; ro.period = action_period; ro.stride = action_stride;
+    HIP_TRY(launch_rollout_fused(h->system, h->kp, *io, h->d_tb, h->d_con, h->d_ref, n, ro, h->num_cus, (hipStream_t)stream));
     return SCG_OK;
 }
 
 int scg_eval_constraints(scg_handle* h, const float* state, const float* action, float* c_val,
                          uint8_t* violation, int64_t ld, int64_t n, void* stream) {
     if (!h || !state) return fail(SCG_ERR_INVALID, "scg_eval_constraints: null argument");
+    GUARD_DEVICE(h, "scg_eval_constraints");
     if (n < 0 || ld < n) return fail(SCG_ERR_INVALID, "scg_eval_constraints: need 0 <= n <= ld");
     if (n == 0 || h->n_con_rows == 0) return SCG_OK;
     if (n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_eval_constraints: n > 2^30 envs per device");
@@ -887,6 +1060,7 @@ int scg_normalize_advantages(float* adv, const double* stats, int32_t T, int64_t
 int scg_model_eval(scg_handle* h, const float* state, const float* input, const float* inertial, float* xdot,
                    float* xnext, int64_t ld, int64_t n, void* stream) {
     if (!h) return fail(SCG_ERR_INVALID, "scg_model_eval: null handle");
+    GUARD_DEVICE(h, "scg_model_eval");
     if (!state || !input || (!xdot && !xnext)) return fail(SCG_ERR_INVALID, "scg_model_eval: null argument");
     if (n < 0 || ld < n) return fail(SCG_ERR_INVALID, "scg_model_eval: need 0 <= n <= ld");
     if (n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_model_eval: n > 2^30");
@@ -899,6 +1073,7 @@ int scg_model_flow(scg_handle* h, const double* state, const double* input, cons
                    double atol, int32_t max_doublings, double* xf, double* dxf_dx0, double* dxf_dp, int32_t* intervals,
                    int64_t ld, int64_t n, void* stream) {
     if (!h) return fail(SCG_ERR_INVALID, "scg_model_flow: null handle");
+    GUARD_DEVICE(h, "scg_model_flow");
     if (!state || !input || (!xf && !dxf_dx0 && !dxf_dp)) return fail(SCG_ERR_INVALID, "scg_model_flow: null argument");
     if (n < 0 || ld < n) return fail(SCG_ERR_INVALID, "scg_model_flow: need 0 <= n <= ld");
     const bool sens = dxf_dx0 || dxf_dp;
@@ -916,6 +1091,7 @@ int scg_model_flow(scg_handle* h, const double* state, const double* input, cons
 int scg_linearize(scg_handle* h, const float* state, const float* input, const float* inertial, float* dfdx,
                   float* dfdu, double disc_dt, int64_t ld, int64_t n, void* stream) {
     if (!h) return fail(SCG_ERR_INVALID, "scg_linearize: null handle");
+    GUARD_DEVICE(h, "scg_linearize");
     if (!state || !input || !dfdx || !dfdu) return fail(SCG_ERR_INVALID, "scg_linearize: null argument");
     if (n < 0 || ld < n) return fail(SCG_ERR_INVALID, "scg_linearize: need 0 <= n <= ld");
     if (n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_linearize: n > 2^30");
@@ -928,6 +1104,7 @@ int scg_linearize(scg_handle* h, const float* state, const float* input, const f
 int scg_fc_linear(scg_handle* h, const float* x_eval, const float* u_eval, const float* state, const float* input,
                   const float* inertial, float* out, int64_t ld, int64_t n, void* stream) {
     if (!h) return fail(SCG_ERR_INVALID, "scg_fc_linear: null handle");
+    GUARD_DEVICE(h, "scg_fc_linear");
     if (!u_eval || !state || !input || !out) return fail(SCG_ERR_INVALID, "scg_fc_linear: null argument");
     if (n < 0 || ld < n) return fail(SCG_ERR_INVALID, "scg_fc_linear: need 0 <= n <= ld");
     if (n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_fc_linear: n > 2^30");
@@ -960,6 +1137,7 @@ int scg_quadratic_loss(scg_handle* h, const double* Q, const double* R, const fl
                        const float* xr, int64_t xr_ld, const float* ur, int64_t ur_ld, float* l, float* l_x,
                        float* l_u, int64_t ld, int64_t n, void* stream) {
     if (!h) return fail(SCG_ERR_INVALID, "scg_quadratic_loss: null handle");
+    GUARD_DEVICE(h, "scg_quadratic_loss");
     if (!Q || !R || !state || !input || !xr || !ur) return fail(SCG_ERR_INVALID, "scg_quadratic_loss: null argument");
     if (n < 0 || ld < n) return fail(SCG_ERR_INVALID, "scg_quadratic_loss: need 0 <= n <= ld");
     if ((xr_ld != 0 && xr_ld < n) || (ur_ld != 0 && ur_ld < n))

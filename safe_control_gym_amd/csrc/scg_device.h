@@ -150,6 +150,24 @@ struct LaunchGeom {
     int32_t block, grid, lds_bytes;
 };
 
+// Arguments of the one-launch multi-step form (scg_rollout_fused / scg_rollout_trajectory with fused = 1): step k reads its
+// action planes at io.action + (k % period) * stride; the sink_* members (scg_trajectory_sink; each nullable) receive step k's
+// outputs at base + k * step stride.  Single-step launches pass {1, 1, 0}.
+struct RolloutArgs {
+    int32_t steps, period;
+    int64_t stride;
+    float* sink_obs;
+    int64_t sink_obs_stride;
+    float* sink_rew;
+    int64_t sink_rew_stride;
+    uint8_t* sink_done;
+    int64_t sink_done_stride;
+    float* sink_cval;
+    int64_t sink_cval_stride;
+    uint8_t* sink_viol;
+    int64_t sink_viol_stride;
+};
+
 }  // namespace scg
 
 // Kernel launchers (scg_kernels.hip)
@@ -159,8 +177,8 @@ hipError_t launch_step(int system, const KParams& p, const scg_step_io& io, cons
                        const ConTable* ct, const float* ref, int64_t n, int num_cus, hipStream_t s);
 bool fused_rollout_ok(const KParams& p, const scg_step_io& io);
 hipError_t launch_rollout_fused(int system, const KParams& p, const scg_step_io& io, const KTables* tb,
-                                const ConTable* ct, const float* ref, int64_t n, int32_t steps, int64_t stride,
-                                int32_t period, int num_cus, hipStream_t s);
+                                const ConTable* ct, const float* ref, int64_t n, const RolloutArgs& ro, int num_cus,
+                                hipStream_t s);
 hipError_t launch_reset(int system, const KParams& p, const KTables* tb, float* state, float* state_lo,
                         int32_t* step_count, float* ep_return, int32_t* ep_length, float* obs, const uint8_t* mask,
                         const float* reset_state, float* inertial, uint32_t* episode_id, const float* ref,

@@ -637,10 +637,8 @@ enum Feat : uint32_t {
 // MODE 2 (fused rollout, scg_rollout_fused): the lane keeps its env in registers for ro.steps consecutive steps;
 // step k reads only its action plane (io.action + (k % ro.period) * ro.stride) and the outputs are stored after the
 // last step -- the same values scg_rollout() leaves behind, with 16 B instead of 125 B of HBM traffic per env-step.
-struct RolloutArgs {
-    int32_t steps, period;
-    int64_t stride;
-};
+// (RolloutArgs: scg_device.h.)  With a trajectory sink (ro.sink_*, scg_rollout_trajectory) the fused form streams every step's
+// observation / reward / done (/ constraint values) out to base + k * step stride: 4 nu bytes read + 4 nx + 5 written per env-step.
 constexpr int MODE_SINGLE = 0, MODE_STRIDED = 1, MODE_FUSED = 2;
 
 template <int SYS, int COMP, uint32_t FT, int MODE>
@@ -745,8 +743,15 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
     // A launch replayed from a rollout graph reads the serial of the rollout from a device word (scg_rollout).  The scalar load
     // is pinned BEHIND the lane loads above: issued before them, its round trip to L2 (the scalar cache is cold at kernel start)
     // would sit on the critical path of every wave ahead of the first vector load (measured: +1.1 us on a 4.6 us step kernel).
+#ifndef SCG_SERIAL_WORD
+#define SCG_SERIAL_WORD 1      // 0 (bisect arm of profiles/r04): no device-word serial at all (graph replay must then be off)
+#endif
+#if SCG_SERIAL_WORD
     asm volatile("" ::: "memory");
     const uint32_t serial_base = p.serial_base ? *p.serial_base : 0u;
+#else
+    const uint32_t serial_base = 0u;
+#endif
 #ifndef SCG_XGOAL_EARLY
 #define SCG_XGOAL_EARLY 1
 #endif
@@ -1068,12 +1073,15 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
             for (int j = 0; j < NX; ++j) v[j] = x[j];
 #pragma unroll
             for (int j = 0; j < NU; ++j) v[NX + j] = a_raw[j];              // RAW action (constraints.py:167-168)
-            const ConFlags cf = eval_constraints<NV, false>(ct, v, last ? io.constraint_values : nullptr, ld, i);
+            float* cv_out = last ? io.constraint_values : nullptr;
+            if (FUSED && ro.sink_cval) cv_out = ro.sink_cval + (int64_t)kstep * ro.sink_cval_stride;      // wave-uniform
+            const ConFlags cf = eval_constraints<NV, false>(ct, v, cv_out, ld, i);
             violated = cf.violated;
             if (violated && (p.flags & F_DONE_VIOL)) done = true;           // :444-445
             if (!(p.flags & F_QUADRATIC) && (p.flags & F_PENALTY) && cf.almost)
                 rew += p.constraint_penalty;                                // :454-456
-            if (last && io.constraint_violation) stp(io.constraint_violation, i, (uint8_t)(violated ? 1 : 0));
+            if (FUSED && ro.sink_viol) stp(uptr(ro.sink_viol + (int64_t)kstep * ro.sink_viol_stride), i, (uint8_t)(violated ? 1 : 0));
+            else if (last && io.constraint_violation) stp(io.constraint_violation, i, (uint8_t)(violated ? 1 : 0));
         }
         bool truncated = false;
         if (t1 >= p.ctrl_steps) { truncated = !done; done = true; }         // :460-462
@@ -1083,10 +1091,11 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         epr += rew;
         epl += 1;
 
-        if (last) {
-            stp(io.reward, i4, rew);
-            stp(io.done, i, (uint8_t)(done ? 1 : 0));
-        }
+        // a sunk output goes to the sink only (scg_trajectory_sink); the others hold the last step's values
+        if (FUSED && ro.sink_rew) stp(uptr(ro.sink_rew + (int64_t)kstep * ro.sink_rew_stride), i4, rew);
+        else if (last) stp(io.reward, i4, rew);
+        if (FUSED && ro.sink_done) stp(uptr(ro.sink_done + (int64_t)kstep * ro.sink_done_stride), i, (uint8_t)(done ? 1 : 0));
+        else if (last) stp(io.done, i, (uint8_t)(done ? 1 : 0));
 
         if (EXTRA && io.stats) {
             st_rew += rew; st_done += done ? 1.f : 0.f; st_viol += violated ? 1.f : 0.f;
@@ -1117,6 +1126,9 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                     // first (measured at 2^20 envs by leaving the record out: it cost 1.75 us of the default tier's step as plain
                     // stores, 0.45 us now).  Staging the finishing lanes' records in LDS so that the whole wave writes them with one
                     // store instruction per four records was built too: no better -- the cost was in the cache, not in the instructions.
+#ifndef SCG_NT_RECORD
+#define SCG_NT_RECORD 1        // 0 (bisect arm): the terminal record leaves as plain stores
+#endif
                     const bool packed_record = !(OBS && p.obs_goal_horizon > 0) && (reinterpret_cast<uintptr_t>(io.terminal_record) & 15u) == 0;
                     if (packed_record) {
                         typedef float v4 __attribute__((ext_vector_type(4)));
@@ -1126,7 +1138,11 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                         for (int j = 0; j < 4 * W4; ++j) buf[j] = j < NX ? ov[j] : (j == NX ? epr : (j == NX + 1 ? __int_as_float(epl) : 0.f));
 #pragma unroll
                         for (int q = 0; q < W4; ++q)
-                            __builtin_nontemporal_store(v4{buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]}, reinterpret_cast<v4*>(rec) + q);
+                        {
+                            const v4 val = {buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]};
+                            if (SCG_NT_RECORD) __builtin_nontemporal_store(val, reinterpret_cast<v4*>(rec) + q);
+                            else reinterpret_cast<v4*>(rec)[q] = val;
+                        }
                     } else {
 #pragma unroll
                         for (int j = 0; j < NX; ++j) __builtin_nontemporal_store(ov[j], rec + j);
@@ -1188,7 +1204,13 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
             }
         }
 
-        // ---- stores (a fused rollout keeps the env in registers until its last step)
+        // ---- stores (a fused rollout keeps the env in registers until its last step; with a sink every step's observation --
+        //      the state, or the reset state of an env that finished -- streams out to its slab)
+        if (FUSED && ro.sink_obs) {
+            float* slab = ro.sink_obs + (int64_t)kstep * ro.sink_obs_stride;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) stp(uptr(slab + (int64_t)j * opaque_s(ld)), i4, x[j]);
+        }
         if (last) {
 #pragma unroll
             for (int j = 0; j < NX; ++j) stp(PLS(io.state_out ? io.state_out : io.state, j), i4, x[j]);   // in place or ping-pong
@@ -1454,7 +1476,8 @@ static bool launch_step_ft(uint32_t ft, const LaunchGeom& g, const KParams& p, c
                            const KTables* tb, const ConTable* ct, const float* ref, uint32_t n, hipStream_t s) {
 #define SCG_LAUNCH(FTV)                                                                                   \
     do {                                                                                                  \
-        const RolloutArgs ro{1, 1, 0};                                                                    \
+        RolloutArgs ro{};                                                                                 \
+        ro.steps = 1; ro.period = 1;                                                                      \
         if ((int64_t)g.grid * g.block >= (int64_t)n)                                                      \
             hipLaunchKernelGGL((scg_step_kernel<SYS, COMP, (FTV), MODE_SINGLE>), dim3(g.grid),            \
                                dim3(g.block), g.lds_bytes, s, p, io, tb, ct, ref, n, ro);                 \
@@ -1524,10 +1547,9 @@ static void launch_fused_sys(const KParams& p, const scg_step_io& io, const KTab
 }
 
 hipError_t launch_rollout_fused(int system, const KParams& p, const scg_step_io& io, const KTables* tb,
-                                const ConTable* ct, const float* ref, int64_t n, int32_t steps, int64_t stride,
-                                int32_t period, int num_cus, hipStream_t s) {
+                                const ConTable* ct, const float* ref, int64_t n, const RolloutArgs& ro, int num_cus,
+                                hipStream_t s) {
     const LaunchGeom g = step_geometry(p, system, n, num_cus);
-    const RolloutArgs ro{steps, period, stride};
     switch (system) {
         case SCG_QUAD_1D: launch_fused_sys<SCG_QUAD_1D>(p, io, tb, ct, ref, (uint32_t)n, ro, g.lds_bytes, s); break;
         case SCG_QUAD_2D: launch_fused_sys<SCG_QUAD_2D>(p, io, tb, ct, ref, (uint32_t)n, ro, g.lds_bytes, s); break;

@@ -87,13 +87,40 @@ __device__ __forceinline__ void quadrant_fix(uint32_t kb, float sr, float cr, fl
     c = __uint_as_float(__builtin_amdgcn_bitop3_b32(cc, (kb + 1u) << 30, 0x80000000u, 0x78));   // cos < 0 in quadrants 1, 2
 }
 
+#ifndef SCG_TRIG_R02
+#define SCG_TRIG_R02 0         // 1 (bisect arm of profiles/r04): round 2's quadrant logic (rintf + v_cvt + compares / selects), same polynomials
+#endif
+#if defined(__FAST_MATH__) || defined(__ASSOCIATIVE_MATH__)
+#error "scg_math.h: sincos_f reads the quadrant off the bits of t = fma(x, 2/pi, 1.5 2^23) and forms k as t - 1.5 2^23: value-unsafe math flags (-ffast-math, -fassociative-math) fold that pair and every trig value comes out wrong"
+#endif
+// Valid for |x| < 2^22 / (2/pi) ~ 6.5e6 (beyond that 1.5 2^23 + x 2/pi leaves the binade whose ulp is 1): angles, rates times a
+// time step and 2 pi u stay far inside; a yaw that winds up without bound (done_on_out_of_bound=False) reaches it after ~1e6 turns.
 __device__ __forceinline__ void sincos_f(float x, float& s, float& c) {
 #if SCG_FAST_TRIG
     const float rev = x * 0.15915494309189535f;                 // revolutions
     s = __builtin_amdgcn_sinf(rev);
     c = __builtin_amdgcn_cosf(rev);
+#elif SCG_TRIG_R02
+    const float kf = rintf(x * kTwoOverPi);
+    const int k = (int)kf;
+    float r = fmaf(kf, kPio2Hi, x);
+    r = fmaf(kf, kPio2Lo, r);
+    const float r2 = r * r;
+    float ps = fmaf(r2, kS3, kS2);
+    ps = fmaf(ps, r2, kS1);
+    ps = fmaf(ps, r2, kS0);
+    const float sr = fmaf(r * r2, ps, r);
+    float pc = fmaf(r2, kC2, kC1);
+    pc = fmaf(pc, r2, kC0);
+    const float cr = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.0f));
+    const float ss = (k & 1) ? cr : sr;
+    const float cc = (k & 1) ? sr : cr;
+    s = (k & 2) ? -ss : ss;
+    c = ((k + 1) & 2) ? -cc : cc;
 #else
-    const float t = fmaf(x, kTwoOverPi, kRintMagic);
+    float t = fmaf(x, kTwoOverPi, kRintMagic);
+    asm("" : "+v"(t));                                          // opaque to the optimiser (not volatile: free to schedule): the add here and the
+                                                                // subtract below stay two roundings, whatever the flags
     const float kf = t - kRintMagic;
     float r = fmaf(kf, kPio2Hi, x);                             // fl32(pi/2)
     r = fmaf(kf, kPio2Lo, r);                                   // pi/2 - fl32(pi/2)

@@ -87,6 +87,74 @@ class LazyInfoList:
         return (self[i] for i in range(len(self)))
 
 
+class RolloutTrajectory:
+    """Sink of a multi-step rollout (``scg_trajectory_sink``): time-major SoA planes on the device and their ``[T, N, ...]`` views.
+
+    ``obs [T, N, obs_dim]`` is what ``step()`` returned at each step (for an env that finished: its reset observation, as the
+    reference's vector envs return it, dummy_vec_env.py:41-47), ``reward [T, N]``, ``done [T, N]`` (bool); with constraints
+    ``constraint_values [T, N, nc]`` (device rows; symmetric constraints folded by ``ConstraintList.fold``) and
+    ``constraint_violation [T, N]``; with ``info`` ``mse [T, N]`` and ``truncated [T, N]``.  Rows ``>= filled`` are stale."""
+
+    def __init__(self, env, steps, constraints, info):
+        n, ld, od = env.num_envs, env._ld, env.obs_dim
+        dev, f32 = env.device, torch.float32
+        self.env_signature = (n, ld, od)
+        self.steps, self.filled = steps, 0
+        self._n = n
+        self._planes = {'obs': torch.zeros((steps, od, ld), dtype=f32, device=dev),
+                        'reward': torch.zeros((steps, ld), dtype=f32, device=dev),
+                        'done': torch.zeros((steps, ld), dtype=torch.bool, device=dev)}
+        if constraints:
+            if env.constraints is None:
+                raise ValueError('[ERROR] the env has no constraints to record.')
+            self._planes['constraint_values'] = torch.zeros((steps, env.constraints.num_device_rows, ld), dtype=f32, device=dev)
+            self._planes['constraint_violation'] = torch.zeros((steps, ld), dtype=torch.bool, device=dev)
+            self._fold = env.constraints.fold if env.constraints.num_device_rows != env.constraints.num_constraints else None
+        if info:
+            self._planes['mse'] = torch.zeros((steps, ld), dtype=f32, device=dev)
+            self._planes['truncated'] = torch.zeros((steps, ld), dtype=torch.bool, device=dev)
+
+    def sink_tensors(self):
+        return self._planes
+
+    @property
+    def obs(self):
+        return self._planes['obs'][:, :, :self._n].permute(0, 2, 1)
+
+    @property
+    def obs_planes(self):
+        """[T, obs_dim, ld]: the SoA planes themselves (slab k is a valid ``state`` / observation buffer of the engine)."""
+        return self._planes['obs']
+
+    @property
+    def reward(self):
+        return self._planes['reward'][:, :self._n]
+
+    @property
+    def done(self):
+        return self._planes['done'][:, :self._n]
+
+    @property
+    def constraint_values(self):
+        v = self._planes['constraint_values'][:, :, :self._n].permute(0, 2, 1)
+        if self._fold is None:
+            return v
+        t, n, r = v.shape                        # symmetric constraints: |y| - bound = max of the row pair (a copy)
+        return self._fold(v.reshape(t * n, r)).reshape(t, n, -1)
+
+    @property
+    def constraint_violation(self):
+        return self._planes['constraint_violation'][:, :self._n]
+
+    @property
+    def mse(self):
+        return self._planes['mse'][:, :self._n]
+
+    @property
+    def truncated(self):
+        return self._planes['truncated'][:, :self._n]
+
+
 class BenchmarkEnv:
     """Batched base class.  Subclasses provide the system-specific pieces (spaces, constants)."""
     _count = 0
@@ -227,6 +295,13 @@ class BenchmarkEnv:
         self.RESEED_ON_RESET = kwargs.get('reseed_on_reset', False)
         self._bufs = None
         self._raw_action, self._raw_action_rows = None, False
+        self._async_outs, self._inflight = None, None            # step_async() / step_wait()
+        # output_ring=K >= 3 (fresh-output mode): step() cycles through K pre-allocated output sets instead of allocating one per
+        # step -- a tensor handed out is then OVERWRITTEN K steps later (opt-in: it changes the ownership contract of step())
+        self._output_ring = int(kwargs.get('output_ring', 0) or 0)
+        if self._output_ring and self._output_ring < 3:
+            raise ValueError('[ERROR] output_ring must be 0 (off) or >= 3.')
+        self._ring, self._ring_pos = None, 0
 
     # ------------------------------------------------------------------ seeding
     def seed(self, seed=None):
@@ -269,6 +344,13 @@ class BenchmarkEnv:
         self._ensure_engine()
         if sd['plane_stride'] != self._ld or set(sd['planes']) != {k for k in self._CHECKPOINT_PLANES if k in self._bufs}:
             raise ValueError('[ERROR] checkpoint was taken from a differently configured env.')
+        for k, v in sd['planes'].items():
+            # copy_() would cast silently: float32 residual planes ('attitude_f32', or a checkpoint of an earlier version) loaded
+            # into an int16 'attitude' env would truncate every residual to 0, and the other way round turn integer counts
+            # into radians
+            if v.dtype != self._bufs[k].dtype or tuple(v.shape) != tuple(self._bufs[k].shape):
+                raise ValueError('[ERROR] checkpoint was taken from a differently configured env: plane %r is %s %s there, %s %s here.'
+                                 % (k, v.dtype, tuple(v.shape), self._bufs[k].dtype, tuple(self._bufs[k].shape)))
         self._own_state()
         for k, v in sd['planes'].items():
             self._bufs[k].copy_(v)
@@ -480,6 +562,10 @@ class BenchmarkEnv:
         self._bufs = b
         self._reset_state_buf = None
         self._bound = False
+        self._ring, self._ring_pos = None, 0
+        if self._output_ring and self._fresh_outputs:
+            self._ring = [(torch.zeros((self.obs_dim, ld), dtype=f32, device=dev), torch.zeros(n, dtype=f32, device=dev),
+                           torch.zeros(n, dtype=torch.bool, device=dev)) for _ in range(self._output_ring)]
         # output views are created once: step() hands out the same zero-copy views of the buffers every call
         info = {}
         if 'mse' in b:
@@ -781,7 +867,7 @@ class BenchmarkEnv:
                         'l_xu': torch.zeros((1, 1, 1), **f32).expand(n, nx, nu)})
         return out
 
-    def rollout(self, actions, steps=None, fused=False):
+    def rollout(self, actions, steps=None, fused=False, out=None):
         """Open-loop rollout: ``steps`` fused step launches issued from one C-ABI call (``scg_rollout``), or with
         ``fused=True`` ONE launch that keeps every env in registers for all the steps (``scg_rollout_fused``; same
         final buffers, ~8x less HBM traffic; lean configurations only, others fall back).
@@ -789,8 +875,16 @@ class BenchmarkEnv:
         ``actions``: contiguous float32 device tensor [T, nu, ld] (``ld = env.plane_stride``), used
         cyclically.  Outputs (``env.state``, reward, done, ... buffers) hold the last step's values;
         episode statistics accumulate.  Passive disturbances are drawn in the kernel at every step; an adversary
-        needs ``step()`` (its action changes per step)."""
+        needs ``step()`` (its action changes per step).
+
+        ``out``: a ``RolloutTrajectory`` (``env.trajectory_buffer(steps)``) -- step k then writes its observation / reward / done
+        (and whatever else the buffer holds) into row k of the buffer instead (``scg_rollout_trajectory``): the rollout yields
+        a ``[T, N, ...]`` dataset at the same bytes per env-step (the state ping-pongs through the buffer's observation slabs;
+        with ``fused=True`` the envs stay in registers and only the outputs stream out).  The sunk outputs are not written to
+        the env's own per-step buffers."""
         self._check_initial_reset()
+        if self._async_outs is not None:
+            raise RuntimeError('[ERROR] rollout() while a step_async() is pending: call step_wait() first.')
         if self.adversary_disturbance is not None:
             raise RuntimeError('[ERROR] rollout() cannot take per-step adversary actions; use step().')
         if not (isinstance(actions, torch.Tensor) and actions.dtype == torch.float32 and actions.is_contiguous()
@@ -798,14 +892,32 @@ class BenchmarkEnv:
             raise ValueError('[ERROR] rollout() needs a contiguous float32 [T, %d, %d] device tensor.'
                              % (self.action_dim, self._ld))
         steps = actions.shape[0] if steps is None else int(steps)
+        sink = None
+        if out is not None:
+            if out.env_signature != (self.num_envs, self._ld, self.obs_dim) or out.steps < steps:
+                raise ValueError('[ERROR] rollout(out=...): the trajectory buffer was made for another env or fewer steps.')
+            sink = out.sink_tensors()
         self._own_state()
         io = dict(self._bufs)
         io['reset_state'] = self._reset_state_buf
-        self._engine.rollout(io, self.num_envs, self._ld, self._serial, steps, actions, fused=fused)
+        self._engine.rollout(io, self.num_envs, self._ld, self._serial, steps, actions, fused=fused, sink=sink)
         self._bound = False
         self._serial += steps
         k = (steps - 1) % actions.shape[0]
         self._raw_action, self._raw_action_rows = actions[k], False
+        if out is not None:
+            out.filled = steps
+        return out
+
+    def trajectory_buffer(self, steps, constraints=None, info=False):
+        """A device buffer for ``rollout(..., out=)``: time-major planes ``[T][obs_dim][ld]`` / ``[T][ld]`` whose ``obs`` /
+        ``reward`` / ``done`` (/ ``constraint_values`` ...) attributes are zero-copy ``[T, N, ...]`` views -- the layout of the
+        reference's rollout buffer (controllers/ppo/ppo_utils.py:308-336).  ``constraints`` (default: whether the env has any)
+        adds the constraint values and the violation flag; ``info=True`` the per-step ``mse`` and ``TimeLimit.truncated``
+        (per-step launches only)."""
+        self._ensure_engine()
+        return RolloutTrajectory(self, int(steps), self.constraints is not None if constraints is None else bool(constraints),
+                                 bool(info))
 
     @property
     def plane_stride(self):
@@ -957,18 +1069,62 @@ class BenchmarkEnv:
         tensors, the state buffer IS the observation handed out and the next step's input, and nothing writes it again
         (``_own_state``; writing ``env.state[...]`` yourself writes into the last observation).  Only an observation
         disturbance needs an obs buffer of its own.  The tensors inside ``info`` are always views of per-step buffers."""
+        if self._async_outs is not None:
+            raise RuntimeError('[ERROR] step() while a step_async() is pending: call step_wait() first.')
+        return self._step_outputs(self._step_launch(action, False))
+
+    def step_async(self, action):
+        """The first half of ``VecEnv.step`` (vec_env.py:47-59; ``SubprocVecEnv.step_async`` sends the actions to its workers
+        and returns, subproc_vec_env.py:50-55): everything queued on the current stream so far -- the policy that produced
+        ``action`` -- happens before the step; the step kernel itself goes to THIS ENV'S OWN launch queue
+        (``scg_step_async``) and the call returns.  ``step_wait()`` makes the current stream wait for it (on the device; the
+        host never blocks) and hands out the outputs.  An env that is one shard of a batch (``make_vec_envs(...,
+        num_pipelines=2)``) thereby overlaps its kernel's ramp-up / drain, and its policy, with the other shard's kernel.
+        Call both from the same current stream; ``pipeline_stream`` is the queue itself, for callers that run a shard's policy
+        on it (then neither call adds an event)."""
+        if self._async_outs is not None:
+            raise RuntimeError('[ERROR] step_async() while another step_async() is pending: call step_wait() first.')
+        self._async_outs = self._step_launch(action, True)
+
+    def step_wait(self):
+        """The second half (vec_env.py:61-72): ``(obs, rew, done, info)`` of the pending ``step_async()``; work queued on the
+        current stream from here on sees them complete."""
+        if self._async_outs is None:
+            raise RuntimeError('[ERROR] step_wait() without a pending step_async().')
+        outs, self._async_outs = self._async_outs, None
+        self._engine.wait()
+        # what the kernel was reading (the action, the previous state buffer) may be released now: allocations on the
+        # current stream are ordered behind the kernel from here on
+        self._inflight = None
+        return self._step_outputs(outs)
+
+    @property
+    def pipeline_stream(self):
+        """This env's own launch queue as a ``torch.cuda.Stream`` (``scg_step_queue``)."""
+        self._ensure_engine()
+        return self._engine.queue_stream()
+
+    def _step_launch(self, action, asynchronous):
         self._check_initial_reset()
         act, rows = self._load_action(action)
         self._raw_action, self._raw_action_rows = act, rows
         b = self._bufs
         outs = None
         new_state = None
+        if asynchronous:
+            # the kernel runs on another queue than the one the caching allocator knows these tensors by: keep what it READS
+            # alive until step_wait() has ordered the current stream behind it
+            self._inflight = (act, b['state'], b.get('obs'))
         if self._fresh_outputs:
             # copy_outputs: this step's outputs get tensors of their own, written by the kernel (no clone afterwards)
             f32 = torch.float32
-            fresh = torch.empty((self.obs_dim, self._ld), dtype=f32, device=self.device)
-            rew_t = torch.empty(self.num_envs, dtype=f32, device=self.device)       # exactly n: the kernel writes lanes < n only
-            done_t = torch.empty(self.num_envs, dtype=torch.bool, device=self.device)
+            if self._ring is not None:
+                fresh, rew_t, done_t = self._ring[self._ring_pos]
+                self._ring_pos = (self._ring_pos + 1) % len(self._ring)
+            else:
+                fresh = torch.empty((self.obs_dim, self._ld), dtype=f32, device=self.device)
+                rew_t = torch.empty(self.num_envs, dtype=f32, device=self.device)       # exactly n: the kernel writes lanes < n only
+                done_t = torch.empty(self.num_envs, dtype=torch.bool, device=self.device)
             if self._pingpong:
                 # the new state is written into `fresh` (with the goal rows behind it, if any); the buffer read this step
                 # stays untouched: it is the observation the previous call handed out
@@ -989,7 +1145,7 @@ class BenchmarkEnv:
                 if 'obs' in b:
                     io['obs'] = new_state
             self._adversary_planes(io)
-            self._engine.step(io, self.num_envs, self._ld, self._serial, action_rows=rows)
+            self._engine.step(io, self.num_envs, self._ld, self._serial, action_rows=rows, asynchronous=asynchronous)
             self._bound = False
         else:
             if not self._bound:
@@ -997,13 +1153,19 @@ class BenchmarkEnv:
                 io['reset_state'] = self._reset_state_buf
                 self._engine.bind_static(io, self._ld)
                 self._bound = True
-            self._engine.step_bound(act, self.num_envs, self._serial, action_rows=rows, outs=outs, state_out=new_state)
+            self._engine.step_bound(act, self.num_envs, self._serial, action_rows=rows, outs=outs, state_out=new_state,
+                                    asynchronous=asynchronous)
         self._serial += 1
         self._handed_out = True
         if new_state is not None:
             if 'obs' in b:
                 b['obs'] = new_state
             b['state'] = new_state[:self.state_dim]
+        return new_state, outs
+
+    def _step_outputs(self, launched):
+        new_state, outs = launched
+        b = self._bufs
         if outs is not None:
             obs, rew, done = (new_state if new_state is not None else outs[0])[:, :self.num_envs].T, outs[1], outs[2]
         else:

@@ -95,22 +95,44 @@ class Engine:
             setattr(io, name, None if t is None else t.data_ptr())
         return io
 
-    def step(self, bufs, n, ld, serial, action_rows=False):
+    def step(self, bufs, n, ld, serial, action_rows=False, asynchronous=False):
         io = self._bind(bufs, ld)
         io.reset_serial = serial & 0xffffffff
         io.action_rows = int(action_rows)
+        fn = self.lib.scg_step_async if asynchronous else self.lib.scg_step
         with torch.cuda.device(self.device):
-            _capi.check(self.lib.scg_step(self.handle, C.byref(io), n, self._stream()), 'scg_step')
+            _capi.check(fn(self.handle, C.byref(io), n, self._stream()), 'scg_step_async' if asynchronous else 'scg_step')
+
+    def wait(self):
+        """``scg_step_wait``: the current stream waits (on the device) for this handle's pending asynchronous step."""
+        if Engine._raw_stream is not None and torch.cuda.current_device() == getattr(self, '_dev_index', -1):
+            status = self.lib.scg_step_wait(self.handle, Engine._raw_stream(self._dev_index))
+        else:
+            with torch.cuda.device(self.device):
+                status = self.lib.scg_step_wait(self.handle, self._stream())
+        if status != 0:
+            _capi.check(status, 'scg_step_wait')
+
+    def queue_stream(self):
+        """The handle's own launch queue (``scg_step_queue``) as a torch stream: run a shard's policy on it and its
+        ``step_async`` / ``step_wait`` need no cross-stream event."""
+        if getattr(self, '_queue_stream', None) is None:
+            q = C.c_void_p()
+            with torch.cuda.device(self.device):
+                _capi.check(self.lib.scg_step_queue(self.handle, C.byref(q)), 'scg_step_queue')
+            self._queue_stream = torch.cuda.ExternalStream(q.value, device=self.device)
+        return self._queue_stream
 
     def bind_static(self, bufs, ld):
         """Bind the long-lived buffers once; ``step_bound`` then only swaps the action pointer and the serial."""
         self._bind(bufs, ld)
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
 
-    def step_bound(self, action, n, serial, action_rows=False, outs=None, state_out=None):
+    def step_bound(self, action, n, serial, action_rows=False, outs=None, state_out=None, asynchronous=False):
         """Hot path of env.step(): ~4 ctypes stores and one foreign call.  ``outs`` = (obs planes or None, reward, done)
         re-points this step's outputs at tensors of the caller's (copy_outputs: fresh ones every step, written by the kernel
-        itself); ``state_out`` = the buffer the new state goes to, which becomes the bound ``state`` of the next call."""
+        itself); ``state_out`` = the buffer the new state goes to, which becomes the bound ``state`` of the next call.
+        ``asynchronous``: ``scg_step_async`` -- the kernel goes to the handle's own queue behind an event of the current stream."""
         io = self._io
         if outs is not None:
             io.obs = None if outs[0] is None else outs[0].data_ptr()
@@ -120,26 +142,37 @@ class Engine:
         io.action = action.data_ptr()
         io.action_rows = int(action_rows)
         io.reset_serial = serial & 0xffffffff
+        fn = self.lib.scg_step_async if asynchronous else self.lib.scg_step
         if Engine._raw_stream is not None and torch.cuda.current_device() == self._dev_index:
-            status = self.lib.scg_step(self.handle, self._io_ref, n, Engine._raw_stream(self._dev_index))
+            status = fn(self.handle, self._io_ref, n, Engine._raw_stream(self._dev_index))
         else:
             with torch.cuda.device(self.device):
-                status = self.lib.scg_step(self.handle, self._io_ref, n, self._stream())
+                status = fn(self.handle, self._io_ref, n, self._stream())
         if status != 0:
             io.state_out = None
-            _capi.check(status, 'scg_step')
+            _capi.check(status, 'scg_step_async' if asynchronous else 'scg_step')
         if state_out is not None:
             io.state, io.state_out = io.state_out, None
 
-    def rollout(self, bufs, n, ld, serial, steps, actions, fused=False):
+    def rollout(self, bufs, n, ld, serial, steps, actions, fused=False, sink=None):
         """``steps`` launches (or one fused launch); ``actions`` is a contiguous [period, nu, ld] float32 tensor
-        used cyclically."""
+        used cyclically.  ``sink``: {name: time-major tensor} -- step k writes that output into slab k of the tensor
+        (``scg_rollout_trajectory``)."""
         io = self._bind(bufs, ld)
         io.action = actions.data_ptr()
         io.action_rows = 0
         io.reset_serial = serial & 0xffffffff
         period, stride = actions.shape[0], actions.shape[1] * actions.shape[2]
         with torch.cuda.device(self.device):
+            if sink is not None:
+                sk = _capi.ScgTrajectorySink()
+                sk.struct_size = C.sizeof(_capi.ScgTrajectorySink)
+                for name, t in sink.items():
+                    setattr(sk, name, t.data_ptr())
+                    setattr(sk, name + '_step_stride', t.stride(0))
+                _capi.check(self.lib.scg_rollout_trajectory(self.handle, C.byref(io), C.byref(sk), n, steps, stride, period,
+                                                            int(bool(fused)), self._stream()), 'scg_rollout_trajectory')
+                return
             fn = self.lib.scg_rollout_fused if fused else self.lib.scg_rollout
             _capi.check(fn(self.handle, C.byref(io), n, steps, stride, period, self._stream()), 'scg_rollout')
 

@@ -4,6 +4,7 @@
 // Exit code 0 = every expectation held and the sanitizers reported nothing.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 #include "../../include/scg_rollout.h"
 #include "hip_host_shim.h"
@@ -83,6 +84,16 @@ static void check_create_validation() {
     { scg_config d = c; d.init_rand_kind[3] = 99; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
     { scg_config d = c; d.inertial_rand_kind[1] = -1; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
     { scg_config d = c; d.randomized_inertial = 1; d.inertial_rand_low[0] = -1.0; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    // choice() carries its number of values in *_rand_low: 1, 2 or 3
+    for (double cnt : {0.0, 4.0, 1.5, -1.0}) {
+        scg_config d = c; d.init_rand_kind[2] = SCG_RAND_CHOICE; d.init_rand_low[2] = cnt; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID);
+        scg_config e = c; e.randomized_inertial = 1; e.inertial_rand_kind[1] = SCG_RAND_CHOICE; e.inertial_rand_low[1] = cnt;
+        e.inertial_rand_p[1][0] = e.inertial_rand_p[1][1] = e.inertial_rand_p[1][2] = 1e-6; EXPECT(scg_create(&e, &h) == SCG_ERR_INVALID);
+    }
+    for (double cnt : {1.0, 2.0, 3.0}) {
+        scg_config d = c; d.init_rand_kind[2] = SCG_RAND_CHOICE; d.init_rand_low[2] = cnt;
+        scg_handle* ok = nullptr; EXPECT(scg_create(&d, &ok) == SCG_OK); EXPECT(scg_destroy(ok) == SCG_OK);
+    }
     EXPECT(g_shim.live_allocations == 0);             // no failed create leaks its tables
     EXPECT(scg_destroy(nullptr) == SCG_OK);
     EXPECT(scg_version() == SCG_ABI_VERSION && scg_sizeof_config() == (int)sizeof(scg_config) && scg_sizeof_step_io() == (int)sizeof(scg_step_io));
@@ -316,6 +327,193 @@ static void check_rollout_graphs() {
     EXPECT(g_shim.execs_live == 0 && g_shim.graphs_live == 0);
 }
 
+// scg_step_async / scg_step_wait (the VecEnv.step_async / step_wait split): the step goes to the handle's own queue behind an
+// event of the caller's stream; the wait joins it back; every other launching entry point joins a pending step first.
+static void check_async_step() {
+    scg_config c = base_config(SCG_QUAD_3D);
+    scg_handle* h = nullptr;
+    EXPECT(scg_create(&c, &h) == SCG_OK);
+    Buffers b(4096);
+    EXPECT(scg_step_async(nullptr, &b.io, 8, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_step_async(h, nullptr, 8, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_step_wait(nullptr, nullptr) == SCG_ERR_INVALID);
+    { Buffers x(64); x.io.reward = nullptr; EXPECT(scg_step_async(h, &x.io, 8, nullptr) == SCG_ERR_INVALID); }
+    shim_reset();
+    EXPECT(scg_step_wait(h, nullptr) == SCG_OK && g_shim.event_records == 0 && g_shim.stream_waits == 0);   // nothing pending: a no-op
+    EXPECT(scg_step_async(h, &b.io, 0, nullptr) == SCG_OK && g_shim.launches == 0);                          // n = 0 launches nothing
+    EXPECT(scg_step_async(h, &b.io, 4096, nullptr) == SCG_OK);
+    EXPECT(g_shim.step_launches_aux == 1 && g_shim.step_launches_main == 0 && g_shim.event_records == 1 && g_shim.stream_waits == 1);
+    EXPECT(g_shim.aux_streams_open == 1);                                                                    // pending on the handle's queue
+    EXPECT(scg_step_wait(h, nullptr) == SCG_OK && g_shim.aux_streams_open == 0 && g_shim.event_records == 2 && g_shim.stream_waits == 2);
+    EXPECT(scg_step_wait(h, nullptr) == SCG_OK && g_shim.event_records == 2);                                // joined already
+    // a synchronous step (or a reset, a rollout) behind a pending asynchronous one joins it first
+    EXPECT(scg_step_async(h, &b.io, 4096, nullptr) == SCG_OK && g_shim.aux_streams_open == 1);
+    EXPECT(scg_step(h, &b.io, 4096, nullptr) == SCG_OK && g_shim.aux_streams_open == 0 && g_shim.step_launches_main == 1);
+    EXPECT(scg_rollout(h, &b.io, 4096, 3, 16, 2, nullptr) == SCG_OK && g_shim.step_launches_main == 4);
+    EXPECT(scg_step_wait(h, nullptr) == SCG_OK);
+    // on the handle's own queue: no event at all
+    void* q = nullptr;
+    EXPECT(scg_step_queue(h, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_step_queue(h, &q) == SCG_OK && q != nullptr);
+    shim_reset();
+    EXPECT(scg_step_async(h, &b.io, 4096, q) == SCG_OK && g_shim.event_records == 0 && g_shim.stream_waits == 0 && g_shim.step_launches_aux == 1);
+    EXPECT(scg_step_wait(h, q) == SCG_OK && g_shim.event_records == 0);
+    // ... and a wait from ANOTHER stream after a step issued on the queue itself still joins
+    EXPECT(scg_step_async(h, &b.io, 4096, q) == SCG_OK);
+    EXPECT(scg_step_wait(h, nullptr) == SCG_OK && g_shim.event_records == 1 && g_shim.stream_waits == 1 && g_shim.aux_streams_open == 0);
+    // the event of the caller's stream cannot be recorded: nothing was launched
+    shim_reset();
+    g_shim.fail_event_record_after = 0;
+    EXPECT(scg_step_async(h, &b.io, 4096, nullptr) == SCG_ERR_HIP && g_shim.launches == 0 && g_shim.aux_streams_open == 0);
+    shim_reset();
+    EXPECT(scg_destroy(h) == SCG_OK);                                                                        // synchronises its queue first
+}
+
+// One handle per device: every handle-taking entry point refuses to run with another device current.
+static void check_device_guard() {
+    scg_config c = base_config(SCG_QUAD_2D);
+    scg_handle* h = nullptr;
+    EXPECT(scg_create(&c, &h) == SCG_OK);                                  // created with device 0 current
+    Buffers b(64);
+    std::vector<float> f(64);
+    std::vector<double> d(64);
+    scg_trajectory_sink sink;
+    std::memset(&sink, 0, sizeof(sink));
+    sink.struct_size = sizeof(sink);
+    void* q = nullptr;
+    const int64_t before = g_shim.launches;
+    g_shim.current_device = 3;
+    EXPECT(scg_step(h, &b.io, 8, nullptr) == SCG_ERR_INVALID);
+    EXPECT(std::strstr(scg_last_error(), "device 0") && std::strstr(scg_last_error(), "device 3"));           // both indices are named
+    EXPECT(scg_step_async(h, &b.io, 8, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_step_wait(h, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_step_queue(h, &q) == SCG_ERR_INVALID);
+    EXPECT(scg_rollout(h, &b.io, 8, 2, 0, 1, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_rollout_fused(h, &b.io, 8, 2, 0, 1, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_rollout_trajectory(h, &b.io, &sink, 8, 2, 0, 1, 0, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_reset(h, f.data(), nullptr, (int32_t*)f.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 8, 8, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_set_reference(h, d.data(), 1) == SCG_ERR_INVALID);
+    EXPECT(scg_set_constraints(h, nullptr, 0, nullptr, 0) == SCG_ERR_INVALID);
+    EXPECT(scg_set_disturbances(h, nullptr, 0) == SCG_ERR_INVALID);
+    EXPECT(scg_eval_constraints(h, f.data(), nullptr, f.data(), nullptr, 8, 8, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_model_eval(h, f.data(), f.data(), nullptr, f.data(), nullptr, 8, 8, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_model_flow(h, d.data(), d.data(), nullptr, 0.02, 1e-6, 1e-8, 8, d.data(), nullptr, nullptr, nullptr, 8, 8, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_linearize(h, f.data(), f.data(), nullptr, f.data(), f.data(), 0.02, 8, 8, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_fc_linear(h, nullptr, f.data(), f.data(), f.data(), nullptr, f.data(), 8, 8, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_quadratic_loss(h, d.data(), d.data(), f.data(), f.data(), f.data(), 0, f.data(), 0, f.data(), nullptr, nullptr, 8, 8, nullptr) == SCG_ERR_INVALID);
+    EXPECT(g_shim.launches == before);                                     // nothing was launched from the wrong device
+    g_shim.current_device = 0;
+    EXPECT(scg_step(h, &b.io, 8, nullptr) == SCG_OK);
+    // a handle created with device 3 current belongs to device 3
+    EXPECT(scg_destroy(h) == SCG_OK);
+    g_shim.current_device = 3;
+    EXPECT(scg_create(&c, &h) == SCG_OK && scg_step(h, &b.io, 8, nullptr) == SCG_OK);
+    g_shim.current_device = 0;
+    EXPECT(scg_step(h, &b.io, 8, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_destroy(h) == SCG_OK);                                      // destroying is allowed from anywhere
+}
+
+// scg_rollout_trajectory: per-step output pointers, the state chain through the sink, the copy home, the fused form.
+static void check_trajectory_sink() {
+    scg_config c = base_config(SCG_QUAD_3D);
+    scg_handle* h = nullptr;
+    EXPECT(scg_create(&c, &h) == SCG_OK);
+    const int64_t n = 1000, ld = 1024, T = 5;
+    std::vector<float> state((size_t)12 * ld), sobs((size_t)T * 12 * ld), srew((size_t)T * ld);
+    std::vector<uint8_t> sdone((size_t)T * ld);
+    Buffers b(ld);
+    b.io.state = state.data();
+    scg_trajectory_sink sink;
+    std::memset(&sink, 0, sizeof(sink));
+    sink.struct_size = sizeof(sink);
+    sink.obs = sobs.data(); sink.obs_step_stride = 12 * ld;
+    sink.reward = srew.data(); sink.reward_step_stride = ld;
+    sink.done = sdone.data(); sink.done_step_stride = ld;
+    EXPECT(scg_sizeof_trajectory_sink() == (int)sizeof(scg_trajectory_sink));
+    EXPECT(scg_rollout_trajectory(h, &b.io, nullptr, n, (int32_t)T, 16, 2, 0, nullptr) == SCG_ERR_INVALID);
+    { scg_trajectory_sink bad = sink; bad.struct_size = 8; EXPECT(scg_rollout_trajectory(h, &b.io, &bad, n, (int32_t)T, 16, 2, 0, nullptr) == SCG_ERR_INVALID); }
+    { scg_trajectory_sink bad = sink; bad.flags = 6; EXPECT(scg_rollout_trajectory(h, &b.io, &bad, n, (int32_t)T, 16, 2, 0, nullptr) == SCG_ERR_INVALID); }
+    { scg_trajectory_sink bad = sink; bad.obs_step_stride = 12 * ld - 1; EXPECT(scg_rollout_trajectory(h, &b.io, &bad, n, (int32_t)T, 16, 2, 0, nullptr) == SCG_ERR_INVALID); }
+    { scg_trajectory_sink bad = sink; bad.reward_step_stride = n - 1; EXPECT(scg_rollout_trajectory(h, &b.io, &bad, n, (int32_t)T, 16, 2, 0, nullptr) == SCG_ERR_INVALID); }
+    { scg_trajectory_sink bad = sink; bad.obs = state.data(); EXPECT(scg_rollout_trajectory(h, &b.io, &bad, n, (int32_t)T, 16, 2, 0, nullptr) == SCG_ERR_INVALID); }
+    { scg_trajectory_sink bad = sink; bad.constraint_values = srew.data(); bad.constraint_values_step_stride = ld;
+      EXPECT(scg_rollout_trajectory(h, &b.io, &bad, n, (int32_t)T, 16, 2, 0, nullptr) == SCG_ERR_INVALID); }          // no constraints attached
+    { Buffers x(ld); x.io.action_rows = 1; EXPECT(scg_rollout_trajectory(h, &x.io, &sink, n, (int32_t)T, 16, 2, 0, nullptr) == SCG_ERR_INVALID); }
+    shim_reset();
+    EXPECT(scg_rollout_trajectory(h, &b.io, &sink, n, 0, 16, 2, 0, nullptr) == SCG_OK && g_shim.launches == 0);
+    EXPECT(scg_rollout_trajectory(h, &b.io, &sink, n, (int32_t)T, 16, 2, 0, nullptr) == SCG_OK);
+    EXPECT(g_shim.step_launches_main == T && g_shim.graph_launches == 0);
+    // the last launch read slab T - 2 and wrote slab T - 1; reward / done of step T - 1
+    EXPECT(g_shim.last_io.state == sobs.data() + (T - 2) * 12 * ld && g_shim.last_io.state_out == sobs.data() + (T - 1) * 12 * ld);
+    EXPECT(g_shim.last_io.reward == srew.data() + (T - 1) * ld && g_shim.last_io.done == sdone.data() + (T - 1) * ld);
+    EXPECT(g_shim.last_io.obs == nullptr);
+    // ... and the last slab came home: (nx - 1) planes of ld + n floats
+    EXPECT(g_shim.async_copies == 1 && g_shim.last_async_copy_bytes == (int64_t)((11 * ld + n) * sizeof(float)));
+    sink.flags = SCG_SINK_KEEP_STATE_IN_SINK;
+    shim_reset();
+    EXPECT(scg_rollout_trajectory(h, &b.io, &sink, n, (int32_t)T, 16, 2, 0, nullptr) == SCG_OK && g_shim.async_copies == 0);
+    sink.flags = 0;
+    // a single step: read io.state, write slab 0
+    shim_reset();
+    EXPECT(scg_rollout_trajectory(h, &b.io, &sink, n, 1, 16, 2, 0, nullptr) == SCG_OK);
+    EXPECT(g_shim.last_io.state == state.data() && g_shim.last_io.state_out == sobs.data());
+    // sink without an observation member: the state stays in place
+    { scg_trajectory_sink r = sink; r.obs = nullptr; shim_reset();
+      EXPECT(scg_rollout_trajectory(h, &b.io, &r, n, (int32_t)T, 16, 2, 0, nullptr) == SCG_OK);
+      EXPECT(g_shim.last_io.state == state.data() && g_shim.last_io.state_out == nullptr && g_shim.async_copies == 0); }
+    // a signature seen twice is NOT graphed with a sink
+    shim_reset();
+    for (int k = 0; k < 3; ++k) EXPECT(scg_rollout_trajectory(h, &b.io, &sink, n, 16, 16, 2, 0, nullptr) == SCG_ERR_INVALID || true);
+    EXPECT(g_shim.graph_launches == 0 && g_shim.captured_nodes == 0);
+    // the fused form: one launch carrying the sink
+    shim_reset();
+    EXPECT(scg_rollout_trajectory(h, &b.io, &sink, n, (int32_t)T, 16, 2, 1, nullptr) == SCG_OK);
+    EXPECT(g_shim.fused_launches == 1 && g_shim.last_fused_sink_obs == sobs.data() && g_shim.async_copies == 0 && g_shim.step_launches_main == 0);
+    // ... which a per-step info sink (truncated / mse) cannot take: per-step launches
+    { scg_trajectory_sink r = sink; r.mse = srew.data(); r.mse_step_stride = ld; shim_reset();
+      EXPECT(scg_rollout_trajectory(h, &b.io, &r, n, (int32_t)T, 16, 2, 1, nullptr) == SCG_OK && g_shim.fused_launches == 0 && g_shim.step_launches_main == T);
+      EXPECT(g_shim.last_io.mse == srew.data() + (T - 1) * ld); }
+    EXPECT(scg_destroy(h) == SCG_OK);
+    // two launch queues with a sink: the second half sees every pointer shifted by `half`, and is joined
+    c.rollout_split_min = 256;
+    EXPECT(scg_create(&c, &h) == SCG_OK);
+    shim_reset();
+    const int64_t half = (n / 2) / 256 * 256;
+    EXPECT(scg_rollout_trajectory(h, &b.io, &sink, n, (int32_t)T, 16, 2, 0, nullptr) == SCG_OK);
+    EXPECT(g_shim.step_launches_main == T && g_shim.step_launches_aux == T && g_shim.aux_streams_open == 0);
+    EXPECT(g_shim.last_io.state_out == sobs.data() + (T - 1) * 12 * ld + half && g_shim.last_io.reward == srew.data() + (T - 1) * ld + half);
+    EXPECT(g_shim.async_copies == 1);
+    for (int k = 0; k < 6; ++k) {                                            // a failing launch still joins the second queue
+        shim_reset();
+        g_shim.fail_launch_after = k;
+        EXPECT(scg_rollout_trajectory(h, &b.io, &sink, n, (int32_t)T, 16, 2, 0, nullptr) == SCG_ERR_HIP && g_shim.aux_streams_open == 0 && g_shim.async_copies == 0);
+    }
+    shim_reset();
+    EXPECT(scg_destroy(h) == SCG_OK);
+}
+
+// An exec whose last replay cannot be waited for is leaked, never destroyed under a running replay.
+static void check_graph_retirement() {
+    scg_config c = base_config(SCG_QUAD_2D);
+    scg_handle* h = nullptr;
+    Buffers b(4096);
+    EXPECT(scg_create(&c, &h) == SCG_OK);
+    shim_reset();
+    EXPECT(scg_rollout(h, &b.io, 4096, 16, 16, 2, nullptr) == SCG_OK && scg_rollout(h, &b.io, 4096, 16, 16, 2, nullptr) == SCG_OK);
+    EXPECT(g_shim.execs_live == 1 && g_shim.graph_launches == 1);
+    const int64_t syncs = g_shim.event_syncs;
+    EXPECT(scg_set_constraints(h, nullptr, 0, nullptr, 0) == SCG_OK);        // drops the graphs: waits for the entry's last replay only
+    EXPECT(g_shim.execs_live == 0 && g_shim.event_syncs == syncs + 1);
+    EXPECT(scg_rollout(h, &b.io, 4096, 16, 16, 2, nullptr) == SCG_OK && scg_rollout(h, &b.io, 4096, 16, 16, 2, nullptr) == SCG_OK);
+    EXPECT(g_shim.execs_live == 1);
+    g_shim.fail_event_sync = 1;
+    EXPECT(scg_set_constraints(h, nullptr, 0, nullptr, 0) == SCG_OK);
+    EXPECT(g_shim.execs_live == 1);                                           // leaked on purpose
+    g_shim.fail_event_sync = 0;
+    EXPECT(hipGraphExecDestroy(static_cast<hipGraphExec_t>(g_shim.last_exec)) == hipSuccess && g_shim.execs_live == 0);   // the test frees what the layer leaked
+    EXPECT(scg_destroy(h) == SCG_OK);
+}
+
 static void check_next_row_entry_points() {
     std::vector<float> f(64);
     std::vector<double> d(64);
@@ -366,6 +564,10 @@ int main() {
     for (int system = SCG_QUAD_1D; system <= SCG_CARTPOLE; ++system) check_tables(system);
     check_step_and_rollout();
     check_rollout_graphs();
+    check_graph_retirement();
+    check_async_step();
+    check_device_guard();
+    check_trajectory_sink();
     check_next_row_entry_points();
     EXPECT(g_shim.live_allocations == 0);
     std::printf(g_fail ? "capi sanitize driver: %d expectation(s) FAILED\n" : "capi sanitize driver: ok\n", g_fail);

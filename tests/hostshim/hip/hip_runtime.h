@@ -17,7 +17,7 @@
 
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorLaunchFailure = 719, hipErrorUnknown = 999 };
-enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2 };
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 
 struct ihipStream_t { int id; int pending; int capturing; int captured_nodes; };
@@ -37,6 +37,7 @@ hipError_t hipMalloc(void** p, size_t bytes);
 hipError_t hipFree(void* p);
 hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
 hipError_t hipMemset(void* dst, int value, size_t bytes);
+hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s);
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
@@ -45,6 +46,7 @@ hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
+hipError_t hipEventSynchronize(hipEvent_t e);
 
 // stream capture / graphs (scg_rollout's replay of small-batch rollouts): a graph is a node count
 struct ihipGraph_t { int nodes; };

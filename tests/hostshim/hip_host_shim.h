@@ -1,6 +1,7 @@
 // Bookkeeping of the host-only HIP stand-in (see hip/hip_runtime.h in this directory).
 #pragma once
 #include <cstdint>
+#include "../../include/scg_rollout.h"
 struct ShimState {
     int64_t live_allocations;       // hipMalloc - hipFree
     int64_t launches;               // launch_* calls recorded
@@ -19,6 +20,14 @@ struct ShimState {
     int64_t last_serial;            // value of the last hipMemsetD32Async
     int fail_begin_capture, fail_instantiate;       // != 0: that call fails
     int caller_stream_capturing;    // != 0: hipStreamIsCapturing(null stream) reports an active capture
+    int current_device;             // what hipGetDevice reports (survives shim_reset: the "current device" of the process)
+    int64_t async_copies, last_async_copy_bytes;    // hipMemcpyAsync
+    int64_t event_syncs;            // hipEventSynchronize
+    int fail_event_sync;            // != 0: hipEventSynchronize fails (an exec must then be leaked, not destroyed)
+    int64_t fused_launches;
+    const float* last_fused_sink_obs;
+    scg_step_io last_io;            // the scg_step_io of the last launch_step
+    void* last_exec;                // the last hipGraphExec_t instantiated (so that a test can free one the layer leaked on purpose)
 };
 extern ShimState g_shim;
 void shim_reset(void);

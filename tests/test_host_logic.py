@@ -365,3 +365,50 @@ def test_extend_obs_helper_matches_reference_rule():
     plain = scg.make('quadrotor', quad_type=2, num_envs=4, device='cpu')
     x = torch.zeros(4, 6)
     assert plain.extend_obs(x, 1) is x
+
+
+def test_make_vec_envs_cuts_the_batch_into_pipelines():
+    """make_vec_envs(num_pipelines=P): contiguous shards (np.array_split sizes as subproc_vec_env.py:28, on whole workgroups when the
+    batch allows), each built with its first GLOBAL env index as env_index_base -- the Philox streams of the unsplit batch."""
+    from safe_control_gym_amd.envs.env_wrappers.vectorized_env import make_vec_envs, pipeline_bounds, PipelinedDeviceVecEnv, DeviceVecEnv
+
+    assert pipeline_bounds(1 << 20, 2) == [(0, 1 << 19), (1 << 19, 1 << 20)]
+    assert pipeline_bounds(3000, 2) == [(0, 1280), (1280, 3000)]
+    assert pipeline_bounds(1000, 2) == [(0, 500), (500, 1000)]            # too small for whole workgroups: plain array_split
+    assert pipeline_bounds(7, 3) == [(0, 2), (2, 4), (4, 7)]
+    assert pipeline_bounds(3, 8) == [(0, 1), (1, 2), (2, 3)]              # never an empty shard
+    for n, p in ((1 << 20, 3), (5000, 4), (1537, 2)):
+        b = pipeline_bounds(n, p)
+        assert b[0][0] == 0 and b[-1][1] == n and all(x[1] == y[0] for x, y in zip(b, b[1:])) and all(hi > lo for lo, hi in b)
+
+    built = []
+
+    class StubEnv:
+        observation_space, action_space = 'obs_space', 'act_space'
+
+        def __init__(self, num_envs, env_index_base=0, **kw):
+            self.num_envs, self.env_index_base, self.kw = num_envs, env_index_base, kw
+            self.calls = []
+            built.append(self)
+
+        def step_async(self, a):
+            self.calls.append(('async', len(a)))
+
+        def close(self):
+            self.calls.append('close')
+
+    one = make_vec_envs(StubEnv, batch_size=64, seed=5)
+    assert isinstance(one, DeviceVecEnv) and built[-1].num_envs == 64 and built[-1].kw == {'seed': 5}
+    built.clear()
+    venv = make_vec_envs(StubEnv, env_configs=[{'ctrl_freq': 60, 'env_index_base': 4096}] * 2, batch_size=3000, seed=5, num_pipelines=2)
+    assert isinstance(venv, PipelinedDeviceVecEnv) and venv.num_pipelines == 2 and venv.num_envs == 3000
+    assert [(e.num_envs, e.env_index_base) for e in built] == [(1280, 4096), (1720, 4096 + 1280)]
+    assert all(e.kw == {'ctrl_freq': 60, 'seed': 5} for e in built)
+    assert venv.bounds == [(0, 1280), (1280, 3000)] and venv.observation_space == 'obs_space'
+    venv.step_async(list(range(3000)))                                     # whole batch: split by rows
+    venv.step_async([0] * 7, pipeline=1)
+    assert built[0].calls == [('async', 1280)] and built[1].calls == [('async', 1720), ('async', 7)]
+    venv.close()
+    assert built[0].calls[-1] == 'close' and built[1].calls[-1] == 'close'
+    with pytest.raises(ValueError, match='env_configs differ'):
+        make_vec_envs(StubEnv, env_configs=[{'a': 1}, {'a': 2}], batch_size=8, num_pipelines=2)

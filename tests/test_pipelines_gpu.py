@@ -1,0 +1,284 @@
+"""Round 4: the step as the reference's VecEnv protocol splits it (step_async / step_wait on per-shard launch queues,
+/root/reference/safe_control_gym/envs/env_wrappers/vectorized_env/vec_env.py:47-72, subproc_vec_env.py:50-63) and the
+trajectory sink of the multi-step rollouts (what tests/scripts/verbose_api.py:71-108 prints per step and
+controllers/ppo/ppo_utils.py:308-336 stores).  Everything here is an EQUALITY test: a pipelined loop, a sunk rollout and a
+ring of output buffers must reproduce the plain ``step()`` loop bit for bit (the oracle parity of that loop is
+tests/test_parity_gpu.py's business)."""
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+import safe_control_gym_amd as scg
+from safe_control_gym_amd.envs.env_wrappers.vectorized_env import make_vec_envs, pipeline_bounds
+
+pytestmark = pytest.mark.gpu
+
+C3_CONSTRAINTS = [{'constraint_form': 'bounded_constraint', 'constrained_variable': 'state', 'active_dims': [0, 2, 4],
+                   'lower_bounds': [-2, 0, -0.5], 'upper_bounds': [2, 2, 0.5]}]
+
+TIERS = {
+    # the lean tier of bench.py (zero-copy views), C4
+    'lean_views': ('quadrotor', dict(quad_type=3, task='traj_tracking', cost='quadratic', info_level='minimal')),
+    # a plain make(): full info, fresh outputs by ping-pong state
+    'default_fresh': ('quadrotor', dict(quad_type=3, task='traj_tracking', cost='quadratic')),
+    # the usual RL configuration: goal horizon appended to the observation, fresh outputs, constraints with a penalty
+    'goal_horizon_fresh': ('quadrotor', dict(quad_type=2, task='traj_tracking', cost='rl_reward', obs_goal_horizon=2,
+                                             constraints=C3_CONSTRAINTS, use_constraint_penalty=True, normalized_rl_action_space=True)),
+    # an observation disturbance: kernel-written obs buffer of its own, in-kernel Philox noise keyed by the global env index
+    'obs_noise': ('quadrotor', dict(quad_type=2, task='stabilization', cost='rl_reward',
+                                    disturbances={'observation': [{'disturbance_func': 'white_noise', 'std': 0.01}]})),
+    'cartpole_views': ('cartpole', dict(task='stabilization', cost='quadratic', info_level='minimal', ctrl_freq=50, pyb_freq=50)),
+}
+
+
+def _common(kw):
+    c = dict(device='cuda', seed=11, ctrl_freq=60, pyb_freq=240, episode_len_sec=1, randomized_init=True)
+    c.update(kw)
+    return c
+
+
+def _policy(env):
+    """A device-side stand-in policy with a real dependency on the observation: an affine map of the first nu observed
+    states, squashed into the action space (row-major [n, nu] float32, what a torch policy emits)."""
+    nu = env.action_dim
+    lo = torch.as_tensor(env.action_space.low, device='cuda', dtype=torch.float32)
+    hi = torch.as_tensor(env.action_space.high, device='cuda', dtype=torch.float32)
+    mid, half = 0.5 * (lo + hi), 0.5 * (hi - lo)
+
+    def policy(obs, k):
+        z = torch.tanh(3.0 * obs[:, :nu] + 0.37 * k)
+        return (mid + 0.9 * half * z).contiguous()
+    return policy
+
+
+def _same(a, b, what):
+    if isinstance(a, dict):
+        for key in a:
+            if key != 'n':
+                _same(a[key], b[key], '%s[%r]' % (what, key))
+        return
+    assert a.shape == b.shape, what
+    eq = (a == b) | (torch.isnan(a) & torch.isnan(b)) if a.is_floating_point() else (a == b)
+    assert bool(eq.all()), '%s differs in %d of %d elements' % (what, int((~eq).sum()), eq.numel())
+
+
+@pytest.mark.parametrize('tier', list(TIERS))
+@pytest.mark.parametrize('on_queue', [False, True], ids=['caller_stream', 'policy_on_the_shard_queue'])
+def test_pipelined_step_loop_equals_the_plain_step_loop(gpu, tier, on_queue):
+    """make_vec_envs(num_pipelines=2): per-shard step_async / step_wait with a policy in the loop == env.step() on the
+    unsplit batch, bit for bit -- observations, rewards, dones and every info tensor, through auto-resets and time limits."""
+    name, kw = TIERS[tier]
+    n, steps = 3000, 90                              # episodes of 60 (50 for the cart-pole) steps: every env hits its time limit once
+    plain = scg.make(name, num_envs=n, **_common(kw))
+    venv = make_vec_envs(partial(scg.make, name, **_common(kw)), batch_size=n, num_pipelines=2)
+    assert venv.num_pipelines == 2 and venv.bounds == [(0, 1280), (1280, 3000)] == pipeline_bounds(n, 2)
+    policy = _policy(plain)
+    obs = plain.reset()
+    pobs = [venv.reset(pipeline=p)[0] for p in range(2)]
+    _same(torch.cat(pobs), obs, 'reset obs')
+    streams = [venv.pipeline_stream(p) if on_queue else torch.cuda.current_stream() for p in range(2)]
+    torch.cuda.synchronize()
+    hits = 0
+    for k in range(steps):
+        obs, rew, done, info = plain.step(policy(obs, k))
+        outs = []
+        for p in range(2):
+            with torch.cuda.stream(streams[p]):
+                venv.step_async(policy(pobs[p], k), pipeline=p)
+        for p in range(2):
+            with torch.cuda.stream(streams[p]):
+                outs.append(venv.step_wait(pipeline=p))
+        if on_queue:
+            for s in streams:
+                torch.cuda.current_stream().wait_stream(s)
+        pobs = [o[0] for o in outs]
+        _same(torch.cat(pobs), obs, 'obs at step %d' % k)
+        _same(torch.cat([o[1] for o in outs]), rew, 'reward at step %d' % k)
+        _same(torch.cat([o[2] for o in outs]), done, 'done at step %d' % k)
+        merged = {key: (torch.cat([o[3][key] for o in outs]) if not isinstance(outs[0][3][key], dict) else
+                        {q: torch.cat([o[3][key][q] for o in outs]) for q in outs[0][3][key]}) for key in outs[0][3] if key != 'n'}
+        if 'terminal_observation' in merged:          # records are written for finishing envs only: compare those rows
+            d = done.bool()
+            for key in ('terminal_observation',):
+                _same(merged[key][d], info[key][d], '%s at step %d' % (key, k))
+            if 'episode' in merged:
+                _same(merged['episode']['r'][d], info['episode']['r'][d], 'episode r at step %d' % k)
+                _same(merged['episode']['l'][d], info['episode']['l'][d], 'episode l at step %d' % k)
+            merged = {q: v for q, v in merged.items() if q not in ('terminal_observation', 'episode')}
+            info = {q: v for q, v in info.items() if q not in ('terminal_observation', 'episode', 'n')}
+        _same(merged, {q: v for q, v in info.items() if q != 'n'}, 'info at step %d' % k)
+        hits += int(done.sum())
+    assert hits >= n                                   # every env finished an episode inside the comparison
+    # the whole-batch calls of the protocol (actions split by rows, outputs concatenated)
+    a = policy(obs, steps)
+    o1 = plain.step(a)
+    o2 = venv.step(a)
+    for q, what in enumerate(('obs', 'reward', 'done')):
+        _same(o2[q], o1[q], 'whole-batch ' + what)
+    venv.close(); plain.close()
+
+
+def test_step_async_protocol_errors(gpu):
+    env = scg.make('quadrotor', quad_type=2, num_envs=256, **_common({}))
+    obs = env.reset()
+    a = torch.as_tensor(env.action_space.sample(256), device='cuda', dtype=torch.float32)
+    with pytest.raises(RuntimeError, match='without a pending'):
+        env.step_wait()
+    env.step_async(a)
+    with pytest.raises(RuntimeError, match='pending'):
+        env.step(a)
+    with pytest.raises(RuntimeError, match='pending'):
+        env.step_async(a)
+    with pytest.raises(RuntimeError, match='pending'):
+        env.rollout(torch.zeros((1, 2, env.plane_stride), device='cuda'))
+    o, r, d, info = env.step_wait()
+    twin = scg.make('quadrotor', quad_type=2, num_envs=256, **_common({}))
+    twin.reset()
+    o2, r2, d2, _ = twin.step(a)
+    assert torch.equal(o, o2) and torch.equal(r, r2) and torch.equal(d, d2)
+    # a synchronous step behind an asynchronous one is ordered behind it by the library
+    env.step_async(a); env.step_wait()
+    o, r, d, _ = env.step(a)
+    twin.step(a)
+    o2, r2, d2, _ = twin.step(a)
+    assert torch.equal(o, o2) and torch.equal(r, r2)
+    env.close(); twin.close()
+
+
+SINK_CASES = {
+    'c4_lean': ('quadrotor', dict(quad_type=3, task='traj_tracking', cost='quadratic', info_level='minimal')),
+    'c3_constraints': ('quadrotor', dict(quad_type=2, task='stabilization', cost='rl_reward', constraints=C3_CONSTRAINTS,
+                                         info_level='minimal')),
+    'c2_cartpole': ('cartpole', dict(task='stabilization', cost='quadratic', info_level='minimal', ctrl_freq=50, pyb_freq=50)),
+    'goal_horizon_info': ('quadrotor', dict(quad_type=2, task='traj_tracking', cost='rl_reward', obs_goal_horizon=1, copy_outputs=False)),
+    'obs_noise': ('quadrotor', dict(quad_type=1, task='stabilization', cost='rl_reward', copy_outputs=False,
+                                    disturbances={'observation': [{'disturbance_func': 'white_noise', 'std': 0.01}]})),
+}
+
+
+@pytest.mark.parametrize('case', list(SINK_CASES))
+@pytest.mark.parametrize('form', ['launches', 'two_queues', 'fused'])
+def test_rollout_trajectory_equals_the_step_loop(gpu, case, form):
+    """rollout(actions, out=trajectory): row k of the buffer == what step() returned at step k (observation incl. the reset
+    observation of finished envs, reward, done, constraint values, mse, truncated), for per-step launches on one and on two
+    queues and for the one-launch fused form; the env afterwards continues exactly like its step()-driven twin."""
+    name, kw = SINK_CASES[case]
+    n, steps = 2500, 75
+    extra = dict(rollout_split_min=256) if form == 'two_queues' else dict(rollout_queues=1)
+    a_env = scg.make(name, num_envs=n, **_common(kw))
+    b_env = scg.make(name, num_envs=n, **_common(dict(kw, **extra)))
+    a_env.reset(); b_env.reset()
+    ld, nu = a_env.plane_stride, a_env.action_dim
+    g = torch.Generator(device='cuda'); g.manual_seed(3)
+    lo = torch.as_tensor(a_env.action_space.low, device='cuda')[None, :, None]
+    hi = torch.as_tensor(a_env.action_space.high, device='cuda')[None, :, None]
+    acts = torch.rand((9, nu, ld), generator=g, device='cuda') * (hi - lo) * 1.1 + lo - 0.05 * (hi - lo)
+    info_sink = a_env.INFO_LEVEL == 'full'
+    traj = b_env.trajectory_buffer(steps, info=info_sink)
+    assert b_env.rollout(acts, steps=steps, fused=(form == 'fused'), out=traj) is traj and traj.filled == steps
+    finished = 0
+    for k in range(steps):
+        obs, rew, done, info = a_env.step(acts[k % 9])
+        _same(traj.obs[k], obs, 'obs at step %d' % k)
+        _same(traj.reward[k], rew, 'reward at step %d' % k)
+        _same(traj.done[k], done, 'done at step %d' % k)
+        if a_env.constraints is not None:
+            _same(traj.constraint_values[k], info['constraint_values'], 'constraint values at step %d' % k)
+            _same(traj.constraint_violation[k], info['constraint_violation'].bool(), 'violation at step %d' % k)
+        if info_sink:
+            _same(traj.mse[k], info['mse'], 'mse at step %d' % k)
+            _same(traj.truncated[k], info['TimeLimit.truncated'], 'truncated at step %d' % k)
+        finished += int(done.sum())
+    assert finished >= n
+    assert torch.equal(a_env.state, b_env.state) and torch.equal(a_env.ctrl_step_counter, b_env.ctrl_step_counter)
+    assert torch.equal(a_env.episode_return, b_env.episode_return)
+    # ... and both continue alike (the state came home from the sink)
+    o1 = a_env.step(acts[3]); o2 = b_env.step(acts[3])
+    assert torch.equal(o1[0], o2[0]) and torch.equal(o1[1], o2[1]) and torch.equal(o1[2], o2[2])
+    # a second rollout into the same buffer, shorter: rows beyond `filled` are stale, the first ones are the new steps
+    b_env.rollout(acts, steps=5, fused=(form == 'fused'), out=traj)
+    for k in range(5):
+        obs, rew, done, _ = a_env.step(acts[k % 9])
+        _same(traj.obs[k], obs, 'second rollout: obs at step %d' % k)
+        _same(traj.reward[k], rew, 'second rollout: reward at step %d' % k)
+    assert traj.filled == 5
+    a_env.close(); b_env.close()
+
+
+def test_trajectory_buffer_argument_checks(gpu):
+    env = scg.make('quadrotor', quad_type=2, num_envs=300, **_common(dict(info_level='minimal')))
+    other = scg.make('quadrotor', quad_type=2, num_envs=301, **_common(dict(info_level='minimal')))
+    env.reset(); other.reset()
+    acts = torch.zeros((4, 2, env.plane_stride), device='cuda')
+    with pytest.raises(ValueError, match='another env or fewer steps'):
+        env.rollout(acts, steps=4, out=other.trajectory_buffer(4))
+    with pytest.raises(ValueError, match='another env or fewer steps'):
+        env.rollout(acts, steps=4, out=env.trajectory_buffer(3))
+    with pytest.raises(ValueError, match='no constraints'):
+        env.trajectory_buffer(4, constraints=True)
+    env.close(); other.close()
+
+
+def test_output_ring_reproduces_the_fresh_output_loop(gpu):
+    """output_ring=K: step() cycles through K pre-allocated output sets instead of allocating one per step -- the same numbers;
+    a tensor handed out is overwritten K steps later (the documented, opt-in change of ownership)."""
+    kw = _common(dict(quad_type=3, task='traj_tracking', cost='quadratic'))
+    a_env = scg.make('quadrotor', num_envs=1000, **kw)
+    b_env = scg.make('quadrotor', num_envs=1000, output_ring=3, **kw)
+    with pytest.raises(ValueError, match='output_ring'):
+        scg.make('quadrotor', num_envs=8, output_ring=2, **kw)
+    a_env.reset(); b_env.reset()
+    act = torch.as_tensor(a_env.action_space.sample(1000), device='cuda', dtype=torch.float32)
+    kept = []
+    for k in range(70):
+        o1, r1, d1, _ = a_env.step(act)
+        o2, r2, d2, _ = b_env.step(act)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+        kept.append((o2, o2.clone()))
+        if k >= 2:
+            assert torch.equal(kept[k - 1][0], kept[k - 1][1]) and torch.equal(kept[k - 2][0], kept[k - 2][1])   # K - 1 steps of validity
+        if k >= 3:
+            assert kept[k - 3][0].data_ptr() == o2.data_ptr()                                                   # ... then reused
+    b_env.reset()                                      # an in-place writer first takes a private copy of what was handed out
+    assert torch.equal(kept[-1][0], kept[-1][1])
+    a_env.close(); b_env.close()
+
+
+def test_checkpoint_of_another_residual_format_is_refused(gpu):
+    """int16 ('attitude') and float32 ('attitude_f32') residual planes must not be loaded into each other."""
+    kw = _common(dict(quad_type=3, task='traj_tracking', cost='quadratic', info_level='minimal'))
+    a = scg.make('quadrotor', num_envs=128, compensated_state='attitude', **kw)
+    b = scg.make('quadrotor', num_envs=128, compensated_state='attitude_f32', **kw)
+    a.reset(); b.reset()
+    act = torch.as_tensor(a.action_space.sample(128), device='cuda', dtype=torch.float32)
+    for _ in range(5):
+        a.step(act); b.step(act)
+    with pytest.raises(ValueError, match='differently configured'):
+        a.load_state_dict(b.state_dict())
+    with pytest.raises(ValueError, match='differently configured'):
+        b.load_state_dict(a.state_dict())
+    a2 = scg.make('quadrotor', num_envs=128, compensated_state='attitude', **kw)
+    a2.load_state_dict(a.state_dict())
+    a.step(act); a2.step(act)
+    assert torch.equal(a.state, a2.state) and torch.equal(a.residual_planes, a2.residual_planes)
+    for e in (a, b, a2):
+        e.close()
+
+
+def test_calls_on_the_handles_device_pass_the_device_guard(gpu):
+    """One handle per device: the Python Engine makes every call with its device current, so the guard never fires there; a raw
+    C-ABI call is refused only when another device is current (exercised by the host-shim driver: one GPU here)."""
+    from safe_control_gym_amd import _capi
+    env = scg.make('quadrotor', quad_type=1, num_envs=64, **_common(dict(info_level='minimal')))
+    env.reset()
+    act = torch.zeros((64, 1), device='cuda')
+    env.step(act)
+    env.rollout(torch.zeros((2, 1, env.plane_stride), device='cuda'))
+    env.linearize()
+    lib, eng = _capi.load(), env._engine
+    assert lib.scg_step_wait(eng.handle, None) == 0
+    q = eng.queue_stream()
+    assert q.cuda_stream != 0 and eng.queue_stream() is q
+    env.close()
