@@ -303,8 +303,223 @@ def sub_record(args, timer, workload, n, steps, track=False, extra=None, note=No
     if fused_too:
         fm = timer.measure(lambda k: env.rollout(acts, steps=k, fused=True), steps, min(args.warmup, 20) + 5, 3)
         rec['open_loop_fused_us_per_step'] = fm['ms'] * 1e3 / steps
+        # the same rollouts WITH the Gym outputs of every step (scg_rollout_trajectory): rows of at most 128 steps into time-major
+        # planes -- per-step launches (the state ping-pongs through the observation slabs: the bytes of the plain step) and the
+        # one-launch fused form (envs in registers, outputs streamed out: 4 nu read + 4 nx + 5 (+ 4 nc + 1) written per env-step)
+        rows = min(steps, 128)
+        traj = env.trajectory_buffer(rows)
+
+        def sunk(fused):
+            def run(k):
+                done = 0
+                while done < k:
+                    c = min(rows, k - done)
+                    env.rollout(acts, steps=c, fused=fused, out=traj)
+                    done += c
+            return run
+        sm = timer.measure(sunk(False), steps, min(args.warmup, 20) + 5, 3)
+        fo = timer.measure(sunk(True), steps, min(args.warmup, 20) + 5, 3)
+        nc = env.constraints.num_device_rows if env.constraints is not None else 0
+        fbytes = 4 * env.action_dim + 4 * env.state_dim + 5 + ((4 * nc + 1) if nc else 0)
+        fus = fo['ms'] * 1e3 / steps
+        rec.update({'with_trajectory_sink_us_per_step': sm['ms'] * 1e3 / steps,
+                    'fused_with_outputs_us_per_step': fus, 'fused_with_outputs_value': n / (fus * 1e-6),
+                    'fused_with_outputs_bytes_per_env_step': fbytes,
+                    'fused_with_outputs_frac': fbytes * n / (fus * 1e-6) / 1e9 / HBM_PEAK_GBS})
+        del traj
     env.close()
     del env, acts
+    torch.cuda.empty_cache()
+    return rec
+
+
+class _AffinePolicy:
+    """Stand-in policy for the step-API records: act = mid + gain * obs[:nu], ONE elementwise kernel that reads nu observation
+    planes and writes the SoA action planes the step kernel reads in place -- a real data dependency from each step's observation
+    to the next step's action (32 bytes per env-step of its own: 4 nu read + 4 nu written)."""
+
+    def __init__(self, env):
+        import torch
+        self.torch, self.nu = torch, env.action_dim
+        lo = torch.as_tensor(env.action_space.low, device=env.device, dtype=torch.float32)
+        hi = torch.as_tensor(env.action_space.high, device=env.device, dtype=torch.float32)
+        self.bias, self.gain = (0.5 * (lo + hi)).reshape(-1, 1), (0.02 * (hi - lo)).reshape(-1, 1)
+        self.act = torch.zeros((self.nu, env.plane_stride), dtype=torch.float32, device=env.device)
+        self.out = self.act[:, :env.num_envs]
+
+    def __call__(self, obs):
+        self.torch.addcmul(self.bias, obs.T[:self.nu], self.gain, out=self.out)     # obs [n, obs_dim] is a transposed view of planes
+        return self.act
+
+
+def step_api_record(args, n, steps):
+    """The drop-in protocol with a consumer between the steps (controllers/ppo/ppo.py:256-259: policy(obs) -> env.step(act)), driven
+    from Python at 2^20 envs: the plain ``env.step()`` loop and the pipelined per-shard ``step_async`` / ``step_wait`` loop of
+    ``make_vec_envs(num_pipelines=2)`` (each shard's policy on its own launch queue), for the lean tier (views) and for a plain
+    ``make()`` (full info, fresh outputs).  us per step of the WHOLE batch on the host clock (synchronize -> K steps -> synchronize):
+    what a caller sees."""
+    import torch
+    from functools import partial
+    import safe_control_gym_amd as scg
+    from safe_control_gym_amd.envs.env_wrappers.vectorized_env import make_vec_envs
+    base = dict(quad_type=3, device='cuda', seed=1337, randomized_init=True, task='traj_tracking', cost='quadratic', ctrl_freq=60,
+                pyb_freq=240, episode_len_sec=5)
+    warmup = 40
+
+    def timed(loop):
+        loop(warmup)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loop(steps)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e6
+
+    def plain(kw, with_policy):
+        env = scg.make('quadrotor', num_envs=n, **kw)
+        pol = _AffinePolicy(env)
+        box = [env.reset()]
+        fixed = pol(box[0]).clone()
+
+        def loop(k):
+            obs = box[0]
+            for _ in range(k):
+                obs = env.step(pol(obs) if with_policy else fixed)[0]
+            box[0] = obs
+        us = timed(loop)
+        env.close()
+        return us
+
+    def pipelined(kw, shards):
+        venv = make_vec_envs(partial(scg.make, 'quadrotor', **kw), batch_size=n, num_pipelines=shards)
+        envs = venv.envs
+        pols = [_AffinePolicy(e) for e in envs]
+        obs = [e.reset() for e in envs]
+        queues = [e.pipeline_stream for e in envs]
+        pending = [False] * len(envs)
+        torch.cuda.synchronize()
+
+        def loop(k):
+            cur = torch.cuda.current_stream()
+            for q in queues:
+                q.wait_stream(cur)
+            for _ in range(k):
+                for p, e in enumerate(envs):
+                    torch.cuda.set_stream(queues[p])                       # shard p's policy AND step on shard p's queue: no event
+                    if pending[p]:
+                        obs[p] = e.step_wait()[0]
+                    e.step_async(pols[p](obs[p]))
+                    pending[p] = True
+            for p, e in enumerate(envs):
+                torch.cuda.set_stream(queues[p])
+                obs[p] = e.step_wait()[0]
+                pending[p] = False
+            torch.cuda.set_stream(cur)
+            for q in queues:
+                cur.wait_stream(q)
+        us = timed(loop)
+        venv.close()
+        return us
+
+    rec = {'workload': 'C4 (Quadrotor-3D tracking, 2^20 envs) stepped from Python with a device-side affine policy between the steps',
+           'envs': n, 'steps': steps, 'unit': 'us per step of the whole batch, host clock',
+           'policy': 'act = mid + gain * obs[:nu]: one elementwise kernel, 32 B per env-step of its own'}
+    for tier, kw in (('lean', dict(base, info_level='minimal')), ('default_make', dict(base))):
+        t = {'step_only': plain(kw, False), 'plain': plain(kw, True), 'pipelined_2': pipelined(kw, 2), 'pipelined_3': pipelined(kw, 3)}
+        t['plain_env_steps_per_s'] = n / (t['plain'] * 1e-6)
+        best = min(t['pipelined_2'], t['pipelined_3'])
+        t['pipelined_env_steps_per_s'] = n / (best * 1e-6)
+        rec[tier] = t
+        torch.cuda.empty_cache()
+    rec['note'] = ('step_only = env.step() with a fixed action tensor (no policy kernel); plain = policy(obs) -> env.step(act), one dependent '
+                   'chain; pipelined_P = make_vec_envs(num_pipelines=P): P shards, per shard step_wait -> policy -> step_async on the shard\'s own '
+                   'queue.  Each shard is still a dependent chain policy -> step -> policy with ~3 us between dependent kernels, so two shards '
+                   'overlap one chain\'s gaps and policy with the other\'s step kernel but do not reach the two-queue rollout\'s rate, where a '
+                   'queue carries step kernels only (profiles/r04/step_api_timeline.txt)')
+    return rec
+
+
+def rl_pipeline_record(args, n, T):
+    """The rollout half of PPO.train_step (controllers/ppo/ppo.py:247-293) on the device at n x T: stand-in policy + critic ->
+    env.step -> MeanStdNormalizer -> RewardStdNormalizer -> time-limit bootstrap -> plane-layout PPOBuffer -> returns / GAE + advantage
+    normalisation.  Nothing is copied between the stages: the policy writes act / v into the buffer's rows and the env reads the
+    actions from there, the step kernel writes done into the buffer, the normalisers' kernels write the normalised observation /
+    reward into the buffer's planes, GAE reads the planes (and the done bytes) in place.  env-steps/s on the host clock, and a
+    per-stage breakdown by HIP events (a second pass: the events themselves cost host time)."""
+    import torch
+    import safe_control_gym_amd as scg
+    from safe_control_gym_amd.controllers.ppo.ppo_utils import PPOBuffer, compute_returns_and_advantages
+    from safe_control_gym_amd.math_and_models.normalization import MeanStdNormalizer, RewardStdNormalizer
+    env = scg.make('quadrotor', quad_type=3, num_envs=n, device='cuda', seed=1337, randomized_init=True, task='traj_tracking',
+                   cost='rl_reward', normalized_rl_action_space=True, ctrl_freq=60, pyb_freq=240, episode_len_sec=5)
+    od, nu, gamma = env.obs_dim, env.action_dim, 0.99
+    buf = PPOBuffer(env.observation_space, env.action_space, T, n, env=env)
+    obs_norm, rew_norm = MeanStdNormalizer(shape=(od,), clip=10.0), RewardStdNormalizer(gamma=gamma, clip=10.0)
+    dev = env.device
+    w_act = torch.tensor([[0.3, -0.2, 0.1, 0.25]], device=dev)
+    w_v = torch.tensor([0.3, -0.2, 0.05], device=dev)
+    zeros = torch.zeros(n, 1, device=dev)
+
+    def actor(obs, out):                       # [n, nu] rows written straight into the buffer's action row: the env reads them there
+        torch.tanh(torch.mul(obs[:, :nu], w_act, out=out), out=out)
+
+    def critic(obs, out=None):                 # a value "network": one fused elementwise expression of three observed states
+        return torch.addcmul(obs[:, 0:1] * w_v[0] + w_v[2], obs[:, 4:5], w_v[1], out=out)
+
+    stages = ('policy', 'env_step', 'obs_normalizer', 'reward_normalizer', 'terminal_value', 'returns_gae')
+    box = {'obs': obs_norm(env.reset(), out=buf.obs_planes[0])}
+
+    def rollout(marks=None):
+        def mark():
+            if marks is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append(ev)
+        obs = buf.obs_at(0)
+        if obs.data_ptr() != box['obs'].data_ptr():
+            obs = buf.start(box['obs'])
+        for t in range(T):
+            mark()
+            actor(obs, buf.act[t]); critic(obs, buf.v[t])
+            mark()
+            raw, rew, done, info = env.step(buf.act[t], out=buf.step_out(t, obs=False, reward=False))
+            mark()
+            obs = obs_norm(raw, out=buf.obs_planes[t + 1])
+            mark()
+            rew_norm(rew, done, out=buf.rew_planes[t])
+            mark()
+            torch.where(info['TimeLimit.truncated'][:, None], critic(info['terminal_observation']), zeros, out=buf.terminal_v[t])
+        mark()
+        ret, adv = compute_returns_and_advantages(buf.rew, buf.v, None, buf.terminal_v, critic(obs), gamma=gamma, use_gae=True,
+                                                  gae_lambda=0.95, normalize_advantages=True, dones=buf.done)
+        mark()
+        box['obs'] = obs
+        return ret, adv
+
+    rollout()
+    torch.cuda.synchronize()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        rollout()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    marks = []
+    rollout(marks)
+    torch.cuda.synchronize()
+    per = dict.fromkeys(stages, 0.0)
+    for t in range(T):
+        for q in range(5):
+            per[stages[q]] += marks[5 * t + q].elapsed_time(marks[5 * t + q + 1])
+    per['returns_gae'] = marks[5 * T].elapsed_time(marks[5 * T + 1])
+    rec = {'workload': 'Quadrotor-3D tracking, rl_reward, normalised actions, default make() info (time-limit bootstrap); %d envs x %d steps per '
+                       'rollout: stand-in policy + critic -> env.step -> MeanStdNormalizer -> RewardStdNormalizer -> terminal value -> '
+                       'PPOBuffer(env=...) rows -> scg_gae + advantage normalisation' % (n, T),
+           'envs': n, 'rollout_steps': T, 'value': n * T / wall, 'unit': 'env-steps/s', 'us_per_step': wall / T * 1e6,
+           'stage_us_per_step': {k: (v * 1e3 / T) for k, v in per.items()},
+           'note': 'value / us_per_step: host clock over %d rollouts (sync -> rollouts -> sync), GAE included (its time is spread over the T steps in '
+                   'stage_us_per_step); stages by HIP events in one more rollout (the events add host time: their sum may exceed us_per_step)' % reps}
+    env.close()
+    del buf
     torch.cuda.empty_cache()
     return rec
 
@@ -580,21 +795,30 @@ def run_rank(args):
             note="compensated_state='attitude': int16 residual planes (40 significant bits) and double accumulation for attitude + body "
                  'rates only (states 6..11), float32 sin / cos and positions / velocities; same drift bound, measured on hover and on this workload '
                  '(tests/test_parity_gpu.py::test_precise_mode_open_loop_1000_step_drift)')
-        out['c3'] = sub_record(args, timer, 'c3', 1 << 18, max(sub_steps, 1000))
-        out['c2'] = sub_record(args, timer, 'c2', 1 << 16, max(sub_steps, 1000))
+        out['step_api'] = step_api_record(args, n, 300)
+        out['rl_pipeline'] = rl_pipeline_record(args, n, 128)
+        out['c3'] = sub_record(args, timer, 'c3', 1 << 18, max(sub_steps, 1000), fused_too=True)
+        out['c2'] = sub_record(args, timer, 'c2', 1 << 16, max(sub_steps, 1000), fused_too=True)
         # the north-star's N in {1k ... 1M}: the bare C4 step at each batch size, same clock (a few ms apiece)
         sweep = []
         for e in range(10, 21, 2):
             r = sub_record(args, timer, 'c4', 1 << e, max(sub_steps, 1000 if e < 18 else 300), fused_too=True)
             fus = r['open_loop_fused_us_per_step']
             sweep.append({'envs': r['envs'], 'steps': r['steps'], 'us_per_step': r['us_per_step'], 'value': r['value'], 'frac': r['frac'],
-                          'open_loop_fused_us_per_step': fus, 'open_loop_fused_value': r['envs'] / (fus * 1e-6)})
+                          'open_loop_fused_us_per_step': fus, 'open_loop_fused_value': r['envs'] / (fus * 1e-6),
+                          'with_trajectory_sink_us_per_step': r['with_trajectory_sink_us_per_step'],
+                          'fused_with_outputs_us_per_step': r['fused_with_outputs_us_per_step'],
+                          'fused_with_outputs_value': r['fused_with_outputs_value'], 'fused_with_outputs_frac': r['fused_with_outputs_frac']})
         out['n_sweep'] = {'workload': 'bare C4 step (125 B moved per env-step), scg_rollout; below the two-queue threshold the launches are '
                                       'replayed from a hipGraph (scg_config.rollout_graph)', 'unit': 'env-steps/s', 'points': sweep,
                           'open_loop_fused': 'the same action sequence through scg_rollout_fused: ONE launch for all steps, the envs stay in '
                                              'registers (same states, rewards, auto-resets and episode statistics; per-step observations are '
                                              'not written: 16 B per env-step, so no roofline fraction) -- what a sampling planner that scores '
-                                             'open-loop action sequences calls; a policy in the loop needs the per-step form'}
+                                             'open-loop action sequences calls; a policy in the loop needs the per-step form',
+                          'with_outputs': 'with_trajectory_sink_* / fused_with_outputs_*: the same rollouts through scg_rollout_trajectory, every '
+                                          'step\'s observation / reward / done written to time-major [T][...][N] planes (rows of <= 128 steps per call): per-step '
+                                          'launches with the state ping-ponging through the observation slabs (the bytes of the plain step), and the '
+                                          'one-launch fused form with its own byte count, 4 nu read + 4 nx + 5 written = 69 B per env-step (frac is on those)'}
     if rank == 0 and 'precise_mode_attitude' in out:
         att = out['precise_mode_attitude']
         out['north_star_target'] = {

@@ -145,6 +145,14 @@ typedef struct scg_config {
     int64_t rollout_split_min;
     int32_t grid_cap_per_cu;
     int32_t rollout_graph;
+    /* lone_launch_forms: 0 = default (on), 1 = on, -1 = off.  On: a step issued by scg_step / scg_step_async -- ONE dependent launch,
+     *   a policy between it and the next -- runs the kernel forms that measured faster for a launch with nothing of its kind
+     *   overlapping it (per-wave instead of workgroup-pooled reset draws: no workgroup barrier; plain instead of nontemporal
+     *   terminal-record stores), the launches queued by scg_rollout keep the forms that are faster back to back; 1 extends the
+     *   lone forms to scg_rollout's single-queue launches (dependent launches on one queue do not overlap either).  Results are
+     *   bit-identical either way. */
+    int32_t lone_launch_forms;
+    int32_t reserved3;
 } scg_config;
 
 /* np.random.RandomState methods the reset path can draw from on the device (benchmark_env.py:297-307); u, u2 are
@@ -403,12 +411,14 @@ int scg_eval_constraints(scg_handle* h, const float* state, const float* action,
 /* ---- next row: returns / GAE over a device-resident rollout ------------------
  * Replaces compute_returns_and_advantages (controllers/ppo/ppo_utils.py:428-456).  All arrays are device
  * pointers, time-major planes [T][ld] (the PPOBuffer scheme's (T, N, 1) arrays, ppo_utils.py:308-336);
- * last_val is [n].  term_val may be NULL (no time-limit bootstrap).  rew_out (nullable) receives
+ * last_val is [n].  Exactly one of mask / done: mask = the buffer's float (1 - done) planes (ppo.py:262), or done = the step
+ * kernel's own byte planes [T][ld] (scg_step_io.done written straight into the rollout buffer: mask = 1 - done is formed in
+ * the kernel, 1 byte instead of 4 read per transition and no conversion pass).  term_val may be NULL (no time-limit bootstrap).  rew_out (nullable) receives
  * rew + gamma * term_val, the reference's in-place update (:443).  stats (nullable, [2] doubles, zeroed by the
  * caller) accumulates sum(adv) and sum(adv^2) for the advantage normalisation of ppo.py:288. */
-int scg_gae(const float* rew, const float* val, const float* mask, const float* term_val, const float* last_val,
-            float* ret, float* adv, float* rew_out, double* stats, int32_t T, int64_t n, int64_t ld, float gamma,
-            float gae_lambda, int32_t use_gae, void* stream);
+int scg_gae(const float* rew, const float* val, const float* mask, const uint8_t* done, const float* term_val,
+            const float* last_val, float* ret, float* adv, float* rew_out, double* stats, int32_t T, int64_t n, int64_t ld,
+            float gamma, float gae_lambda, int32_t use_gae, void* stream);
 /* adv <- (adv - mean) / (std + eps), population statistics from `stats` (device memory, no host sync). */
 int scg_normalize_advantages(float* adv, const double* stats, int32_t T, int64_t n, int64_t ld, float eps,
                              void* stream);

@@ -69,6 +69,7 @@ class ScgConfig(C.Structure):
         ('inertial_rand_kind', _i32 * 4), ('inertial_rand_p', (_dbl * 3) * 4),
         ('rollout_queues', _i32), ('ref_in_lds', _i32), ('rollout_split_min', C.c_int64),
         ('grid_cap_per_cu', _i32), ('rollout_graph', _i32),
+        ('lone_launch_forms', _i32), ('reserved3', _i32),
     ]
 
 
@@ -177,7 +178,7 @@ def load():
     lib.scg_rollout_trajectory.argtypes = [C.c_void_p, C.POINTER(ScgStepIO), C.POINTER(ScgTrajectorySink), C.c_int64, _i32, C.c_int64,
                                            _i32, _i32, C.c_void_p]
     lib.scg_eval_constraints.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, C.c_int64, C.c_int64, C.c_void_p]
-    lib.scg_gae.argtypes = [_fp] * 9 + [_i32, C.c_int64, C.c_int64, C.c_float, C.c_float, _i32, C.c_void_p]
+    lib.scg_gae.argtypes = [_fp] * 10 + [_i32, C.c_int64, C.c_int64, C.c_float, C.c_float, _i32, C.c_void_p]
     lib.scg_normalize_advantages.argtypes = [_fp, _fp, _i32, C.c_int64, C.c_int64, C.c_float, C.c_void_p]
     lib.scg_model_eval.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int64, C.c_void_p]
     lib.scg_model_flow.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_double, C.c_double, C.c_double, _i32, _fp, _fp, _fp, _fp,

@@ -362,6 +362,8 @@ int scg_create(const scg_config* cfg, scg_handle** out) {
         return fail(SCG_ERR_INVALID, "scg_create: rollout_queues %d out of {0 (default), 1, 2}", cfg->rollout_queues);
     if (cfg->rollout_graph < -1 || cfg->rollout_graph > 1)
         return fail(SCG_ERR_INVALID, "scg_create: rollout_graph %d out of {-1 (off), 0 (default: on), 1 (on)}", cfg->rollout_graph);
+    if (cfg->lone_launch_forms < -1 || cfg->lone_launch_forms > 1)
+        return fail(SCG_ERR_INVALID, "scg_create: lone_launch_forms %d out of {-1 (off), 0 (default: on), 1 (on)}", cfg->lone_launch_forms);
     if (cfg->rollout_split_min < 0 || cfg->grid_cap_per_cu < 0)
         return fail(SCG_ERR_INVALID, "scg_create: rollout_split_min and grid_cap_per_cu must be >= 0");
     for (int j = 0; j < SCG_MAX_NX; ++j)
@@ -710,7 +712,9 @@ int scg_step(scg_handle* h, const scg_step_io* io, int64_t n, void* stream) {
     if (int rc = step_check(h, io, n, "scg_step")) return rc;
     if (n == 0) return SCG_OK;
     if (int rc = join_async(h, (hipStream_t)stream, "scg_step")) return rc;
-    HIP_TRY(launch_step(h->system, h->kp, *io, h->d_tb, h->d_con, h->d_ref, n, h->num_cus, (hipStream_t)stream));
+    KParams kp = h->kp;
+    if (h->cfg.lone_launch_forms >= 0) kp.flags |= F_LONE;      // a single dependent launch: the forms that are faster alone
+    HIP_TRY(launch_step(h->system, kp, *io, h->d_tb, h->d_con, h->d_ref, n, h->num_cus, (hipStream_t)stream));
     return SCG_OK;
 }
 
@@ -724,7 +728,9 @@ int scg_step_async(scg_handle* h, const scg_step_io* io, int64_t n, void* stream
         HIP_TRY(hipEventRecord(h->ev_async_in, s));
         HIP_TRY(hipStreamWaitEvent(q, h->ev_async_in, 0));
     }
-    HIP_TRY(launch_step(h->system, h->kp, *io, h->d_tb, h->d_con, h->d_ref, n, h->num_cus, q));
+    KParams kp = h->kp;
+    if (h->cfg.lone_launch_forms >= 0) kp.flags |= F_LONE;
+    HIP_TRY(launch_step(h->system, kp, *io, h->d_tb, h->d_con, h->d_ref, n, h->num_cus, q));
     h->async_pending = true;
     return SCG_OK;
 }
@@ -825,7 +831,9 @@ static int rollout_by_graph(scg_handle* h, const scg_step_io* io, int64_t n, int
             return kGraphNotTaken;
         }
         KParams kp = h->kp;
+        if (h->cfg.lone_launch_forms > 0) kp.flags |= F_LONE;            // single-queue launches are dependent: each runs alone
         kp.serial_base = slot->d_serial;                                // the nodes read the serial of the rollout being replayed
+        kp.flags |= F_SERIAL_WORD;
         scg_step_io local = *io;
         hipError_t err = hipSuccess;
         for (int32_t k = 0; k < steps && err == hipSuccess; ++k) {
@@ -937,11 +945,13 @@ static int rollout_launches(scg_handle* h, const scg_step_io* io, const scg_traj
         const int rc = rollout_by_graph(h, io, n, steps, action_stride, action_period, (hipStream_t)stream);
         if (rc != kGraphNotTaken) return rc;
     }
+    KParams kp1 = h->kp;
+    if (h->cfg.lone_launch_forms > 0) kp1.flags |= F_LONE;               // single-queue launches are dependent: each runs alone
     for (int32_t k = 0; k < steps; ++k) {
         scg_step_io local = sunk_io(*io, sink, k);
         local.action = io->action + (int64_t)(k % action_period) * action_stride;
         local.reset_serial = io->reset_serial + (uint32_t)k;
-        HIP_TRY(launch_step(h->system, h->kp, local, h->d_tb, h->d_con, h->d_ref, n, h->num_cus, (hipStream_t)stream));
+        HIP_TRY(launch_step(h->system, kp1, local, h->d_tb, h->d_con, h->d_ref, n, h->num_cus, (hipStream_t)stream));
     }
     return SCG_OK;
 }
@@ -1036,14 +1046,15 @@ int scg_eval_constraints(scg_handle* h, const float* state, const float* action,
     return SCG_OK;
 }
 
-int scg_gae(const float* rew, const float* val, const float* mask, const float* term_val, const float* last_val,
-            float* ret, float* adv, float* rew_out, double* stats, int32_t T, int64_t n, int64_t ld, float gamma,
-            float gae_lambda, int32_t use_gae, void* stream) {
-    if (!rew || !val || !mask || !last_val || !ret || !adv) return fail(SCG_ERR_INVALID, "scg_gae: null argument");
+int scg_gae(const float* rew, const float* val, const float* mask, const uint8_t* done, const float* term_val,
+            const float* last_val, float* ret, float* adv, float* rew_out, double* stats, int32_t T, int64_t n, int64_t ld,
+            float gamma, float gae_lambda, int32_t use_gae, void* stream) {
+    if (!rew || !val || !last_val || !ret || !adv) return fail(SCG_ERR_INVALID, "scg_gae: null argument");
+    if ((mask == nullptr) == (done == nullptr)) return fail(SCG_ERR_INVALID, "scg_gae: exactly one of mask (float planes) and done (byte planes) must be given");
     if (T < 1 || n < 0 || ld < n) return fail(SCG_ERR_INVALID, "scg_gae: need T >= 1 and 0 <= n <= ld");
     if (n == 0) return SCG_OK;
     if (n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_gae: n > 2^30");
-    HIP_TRY(launch_gae(rew, val, mask, term_val, last_val, ret, adv, rew_out, stats, T, n, ld, gamma, gae_lambda,
+    HIP_TRY(launch_gae(rew, val, mask, done, term_val, last_val, ret, adv, rew_out, stats, T, n, ld, gamma, gae_lambda,
                        use_gae, (hipStream_t)stream));
     return SCG_OK;
 }

@@ -27,6 +27,12 @@ enum Flags : uint32_t {
     F_DRAG = 1u << 15,          // drag (Physics.PYB_DRAG)
     F_W_STATE_UNIT = 1u << 17,  // every diagonal state weight of the cost is exactly 1 (Q = I / rew_state_weight = 1)
     F_RAND_GENERAL = 1u << 16,  // some reset-time quantity is drawn from a non-uniform distribution (scg_distribution)
+    F_LONE = 1u << 18,          // launch policy, set per launch by scg_step / scg_step_async: this kernel runs alone on its queue with
+                                // nothing of its own kind overlapping it (a policy sits between two steps).  Same results bit for bit;
+                                // it selects the forms that measured faster for a lone launch (profiles/r04/lone_launch_arms.txt): the
+                                // per-wave cooperative reset instead of the workgroup-pooled one (two workgroup barriers per step),
+                                // plain instead of nontemporal terminal-record stores
+    F_SERIAL_WORD = 1u << 19,   // serial_base is set: add *serial_base to the reset serial (launches replayed from a rollout graph)
 };
 
 // Physical constants of the model, in the real type the integrator runs in: float in the kernarg block for
@@ -183,7 +189,7 @@ hipError_t launch_reset(int system, const KParams& p, const KTables* tb, float* 
                         int32_t* step_count, float* ep_return, int32_t* ep_length, float* obs, const uint8_t* mask,
                         const float* reset_state, float* inertial, uint32_t* episode_id, const float* ref,
                         uint32_t reset_serial, int64_t ld, int64_t n, hipStream_t s);
-hipError_t launch_gae(const float* rew, const float* val, const float* mask, const float* term_val,
+hipError_t launch_gae(const float* rew, const float* val, const float* mask, const uint8_t* done, const float* term_val,
                       const float* last_val, float* ret, float* adv, float* rew_out, double* stats, int T, int64_t n,
                       int64_t ld, float gamma, float lam, int use_gae, hipStream_t s);
 hipError_t launch_normalize(float* adv, const double* stats, int T, int64_t n, int64_t ld, float eps, hipStream_t s);

@@ -62,13 +62,32 @@ __device__ __forceinline__ void gae_store(const float (&in)[W], float* p) {
     __builtin_nontemporal_store(v, reinterpret_cast<VT*>(p));
 }
 
+// mask = 1 - done from the step kernel's byte planes (W consecutive bytes per lane), or the float mask planes
+template <int W>
+__device__ __forceinline__ void gae_load_mask(const float* mask, const uint8_t* done, int64_t o, float (&m)[W]) {
+    if (done) {
+        if constexpr (W == 1) m[0] = 1.0f - (float)__builtin_nontemporal_load(done + o);
+        else if constexpr (W == 2) {
+            const uint16_t d = __builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(done + o));
+            m[0] = 1.0f - (float)(d & 0xffu); m[1] = 1.0f - (float)(d >> 8);
+        } else {
+            const uint32_t d = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(done + o));
+#pragma unroll
+            for (int c = 0; c < W; ++c) m[c] = 1.0f - (float)((d >> (8 * c)) & 0xffu);
+        }
+    } else {
+        gae_load<W>(mask + o, m);
+    }
+}
+
 // rew and rew_out carry NO __restrict__: the reference updates the rewards in place (ppo_utils.py:443) and callers pass the
 // same buffer for both; each element is loaded before the same lane stores it.
 // W envs per lane (adjacent columns of every plane): W = 2 makes every access an 8-byte one -- half the memory instructions
 // for the same bytes, twice the bytes in flight per lane of the sequential scan.
 template <int W>
 __global__ __launch_bounds__(256) void scg_gae_kernel(const float* rew, const float* __restrict__ val,
-                                                      const float* __restrict__ mask, const float* __restrict__ term_val,
+                                                      const float* __restrict__ mask, const uint8_t* __restrict__ done,
+                                                      const float* __restrict__ term_val,
                                                       const float* __restrict__ last_val, float* __restrict__ ret_out,
                                                       float* __restrict__ adv_out, float* rew_out,
                                                       double* __restrict__ stats, int T, uint32_t n, int64_t ld,
@@ -92,7 +111,7 @@ __global__ __launch_bounds__(256) void scg_gae_kernel(const float* rew, const fl
                 const int64_t o = (int64_t)(t - k) * ld + i;
                 gae_load<W>(rew + o, r[k]);
                 gae_load<W>(val + o, v[k]);
-                gae_load<W>(mask + o, m[k]);
+                gae_load_mask<W>(mask, done, o, m[k]);
                 if (term_val) gae_load<W>(term_val + o, tv[k]);
                 else {
 #pragma unroll
@@ -128,7 +147,7 @@ __global__ __launch_bounds__(256) void scg_gae_kernel(const float* rew, const fl
             float r[W], v[W], m[W], tv[W], rr[W];
             gae_load<W>(rew + o, r);
             gae_load<W>(val + o, v);
-            gae_load<W>(mask + o, m);
+            gae_load_mask<W>(mask, done, o, m);
             if (term_val) gae_load<W>(term_val + o, tv);
 #pragma unroll
             for (int c = 0; c < W; ++c) {
@@ -194,7 +213,7 @@ __global__ __launch_bounds__(256) void scg_normalize_kernel(float* __restrict__ 
     }
 }
 
-hipError_t launch_gae(const float* rew, const float* val, const float* mask, const float* term_val,
+hipError_t launch_gae(const float* rew, const float* val, const float* mask, const uint8_t* done, const float* term_val,
                       const float* last_val, float* ret, float* adv, float* rew_out, double* stats, int T, int64_t n,
                       int64_t ld, float gamma, float lam, int use_gae, hipStream_t s) {
     // W envs per lane when every plane row starts on a W * 4-byte boundary and n is a multiple of W; one otherwise
@@ -203,13 +222,13 @@ hipError_t launch_gae(const float* rew, const float* val, const float* mask, con
     for (const void* ptr : {(const void*)rew, (const void*)val, (const void*)mask, (const void*)term_val, (const void*)last_val,
                             (const void*)ret, (const void*)adv, (const void*)rew_out})
         bits |= reinterpret_cast<uintptr_t>(ptr);
-    const bool wide = W > 1 && (bits & (uintptr_t)(W * 4 - 1)) == 0;
+    const bool wide = W > 1 && (bits & (uintptr_t)(W * 4 - 1)) == 0 && (reinterpret_cast<uintptr_t>(done) & (uintptr_t)(W - 1)) == 0;
     int64_t blocks = ((wide ? n / W : n) + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 65536) blocks = 65536;
-    if (wide) hipLaunchKernelGGL(scg_gae_kernel<W>, dim3((unsigned)blocks), dim3(256), 0, s, rew, val, mask, term_val, last_val, ret,
+    if (wide) hipLaunchKernelGGL(scg_gae_kernel<W>, dim3((unsigned)blocks), dim3(256), 0, s, rew, val, mask, done, term_val, last_val, ret,
                                  adv, rew_out, stats, T, (uint32_t)n, ld, gamma, lam, use_gae);
-    else hipLaunchKernelGGL(scg_gae_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, rew, val, mask, term_val, last_val, ret,
+    else hipLaunchKernelGGL(scg_gae_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, rew, val, mask, done, term_val, last_val, ret,
                             adv, rew_out, stats, T, (uint32_t)n, ld, gamma, lam, use_gae);
     return hipGetLastError();
 }

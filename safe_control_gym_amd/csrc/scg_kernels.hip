@@ -668,7 +668,11 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
     // per-wave LDS scratch of the cooperative reset, placed after the (16-B padded) reference table
     float* wg_scratch = s_tab + ((tracking && (p.flags & F_REF_IN_LDS)) ? (((p.ref_rows * NX + 3) >> 2) << 2) : 0);
     float* coop_scratch = wg_scratch + (threadIdx.x >> 6) * kCoopFloats;      // per-wave form: aliases the pooled form's scratch
-    const bool pooled_reset = SCG_WG_RESET && (SCG_WG_RESET_FUSED || MODE != MODE_FUSED) && (p.flags & F_AUTO_RESET) &&
+#ifndef SCG_LONE_FORMS
+#define SCG_LONE_FORMS 1       // 0 (A/B arm): F_LONE launches keep the forms of the queued launches
+#endif
+    const bool lone = SCG_LONE_FORMS && MODE == MODE_SINGLE && (p.flags & F_LONE);             // wave-uniform (kernarg)
+    const bool pooled_reset = SCG_WG_RESET && (SCG_WG_RESET_FUSED || MODE != MODE_FUSED) && !lone && (p.flags & F_AUTO_RESET) &&
                               (p.flags & F_RAND_INIT) && !(p.flags & F_RAND_GENERAL);
     if (pooled_reset) {
         // list counters of the workgroup-pooled reset; visible to every wave after the first barrier each of them takes
@@ -736,6 +740,12 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         }
     };
 
+#ifndef SCG_STAGGER
+#define SCG_STAGGER 0          // > 0 (experiment, profiles/r04): every other workgroup of a CU sleeps SCG_STAGGER x 64 cycles before its
+#endif                         // first load, so that a LONE launch's load / compute / store phases do not run in step across the chip
+#if SCG_STAGGER > 0
+    if (MODE == MODE_SINGLE && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(SCG_STAGGER);
+#endif
     const uint32_t stride = gridDim.x * kBlock;
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     LaneIn cur;
@@ -747,8 +757,11 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
 #define SCG_SERIAL_WORD 1      // 0 (bisect arm of profiles/r04): no device-word serial at all (graph replay must then be off)
 #endif
 #if SCG_SERIAL_WORD
-    asm volatile("" ::: "memory");
-    const uint32_t serial_base = p.serial_base ? *p.serial_base : 0u;
+    uint32_t serial_base = 0u;
+    if (p.flags & F_SERIAL_WORD) {                   // (the wave-uniform branch is itself the fence: nothing is scheduled across it)
+        asm volatile("" ::: "memory");
+        serial_base = *p.serial_base;
+    }
 #else
     const uint32_t serial_base = 0u;
 #endif
@@ -1140,7 +1153,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                         for (int q = 0; q < W4; ++q)
                         {
                             const v4 val = {buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]};
-                            if (SCG_NT_RECORD) __builtin_nontemporal_store(val, reinterpret_cast<v4*>(rec) + q);
+                            if (SCG_NT_RECORD && !lone) __builtin_nontemporal_store(val, reinterpret_cast<v4*>(rec) + q);
                             else reinterpret_cast<v4*>(rec)[q] = val;
                         }
                     } else {
@@ -1174,7 +1187,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
             float xr[NX];
             if (wg_full) reset_state_wg<NX>(p, tb, io.reset_state, ld, i, serial, need_reset, wg_scratch, kstep & 1, xr);
 #if SCG_WG_RESET
-            else if (!SCG_WG_RESET_FUSED && MODE == MODE_FUSED) reset_state_coop<NX, EXTRA>(p, tb, io.reset_state, ld, i, serial, need_reset, coop_scratch, xr);
+            else if ((!SCG_WG_RESET_FUSED && MODE == MODE_FUSED) || lone) reset_state_coop<NX, EXTRA>(p, tb, io.reset_state, ld, i, serial, need_reset, coop_scratch, xr);
             else if (need_reset) reset_state_of<NX, EXTRA>(p, tb, io.reset_state, ld, i, serial, xr);   // ragged last workgroup / no randomisation / non-uniform draws
 #else
             else reset_state_coop<NX, EXTRA>(p, tb, io.reset_state, ld, i, serial, need_reset, coop_scratch, xr);

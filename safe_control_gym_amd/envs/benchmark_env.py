@@ -181,7 +181,7 @@ class BenchmarkEnv:
                  num_envs=1, device='cuda', physics='rk4', integration_substeps=1, motor_map=True,
                  auto_reset=True, info_level='full', compensated_state=False, track_episode_stats=True,
                  env_index_base=0, rollout_queues=None, rollout_split_min=None, ref_in_lds=None, grid_cap_per_cu=None, rollout_graph=None,
-                 plane_pad=None, copy_outputs=None,
+                 plane_pad=None, copy_outputs=None, lone_launch_forms=None,
                  **kwargs):
         self.id = self.__class__._count
         self.__class__._count += 1
@@ -255,6 +255,7 @@ class BenchmarkEnv:
         self.GRID_CAP_PER_CU = _knob(grid_cap_per_cu, 'SCG_GRID_CAP_PER_CU', 0)
         self.ROLLOUT_GRAPH = _knob(rollout_graph, 'SCG_ROLLOUT_GRAPH', 0)           # 0 / 1: hipGraph replay of small-batch rollouts; -1 off
         self.PLANE_PAD = _knob(plane_pad, 'SCG_LD_PAD', 17)                         # units of 64 lanes (256 B)
+        self.LONE_LAUNCH_FORMS = _knob(lone_launch_forms, 'SCG_LONE_LAUNCH_FORMS', 0)   # 0 / 1: step() launches use the lone-launch kernel forms; -1 off
         # initial state / randomisation
         self.INIT_STATE = init_state
         self.RANDOMIZED_INIT = randomized_init
@@ -296,6 +297,7 @@ class BenchmarkEnv:
         self._bufs = None
         self._raw_action, self._raw_action_rows = None, False
         self._async_outs, self._inflight = None, None            # step_async() / step_wait()
+        self._state_external, self._bound_dirty = False, False   # step(out=...) in views mode
         # output_ring=K >= 3 (fresh-output mode): step() cycles through K pre-allocated output sets instead of allocating one per
         # step -- a tensor handed out is then OVERWRITTEN K steps later (opt-in: it changes the ownership contract of step())
         self._output_ring = int(kwargs.get('output_ring', 0) or 0)
@@ -491,6 +493,7 @@ class BenchmarkEnv:
         cfg.ref_in_lds = self.REF_IN_LDS
         cfg.grid_cap_per_cu = self.GRID_CAP_PER_CU
         cfg.rollout_graph = self.ROLLOUT_GRAPH
+        cfg.lone_launch_forms = self.LONE_LAUNCH_FORMS
         self._fill_system_config(cfg)
         return Engine(cfg, x_goal_table=self._x_goal_table(), constraint_list=constraint_list, device=self.device,
                       disturbances=[e for mode, dl in self.disturbances.items() for e in dl.compile(mode)])
@@ -959,10 +962,22 @@ class BenchmarkEnv:
         load_state_dict) first gives the engine private copies of everything the last ``step()`` / ``reset()`` handed out --
         the state buffer in ping-pong mode (it IS the last observation), a kernel-written observation buffer (observation
         disturbance), and the reward / done tensors -- so that a tensor, once returned, is never written again."""
-        if not self._fresh_outputs or not self._handed_out:
+        if not (self._fresh_outputs or self._state_external) or not self._handed_out:
             return                      # nothing of the engine's buffers is in a caller's hands (e.g. rollout() after rollout())
         self._handed_out = False
         b = self._bufs
+        if self._state_external and not self._fresh_outputs:
+            # views mode after step(out={'obs': ...}): the state (or the observation buffer) lives in the caller's tensor
+            self._state_external = False
+            if 'obs' in b:
+                b['obs'] = b['obs'].clone()
+                if 'observation' not in self.disturbances:
+                    b['state'] = b['obs'][:self.state_dim]
+            else:
+                b['state'] = b['state'].clone()
+            self._out_views = None
+            self._bound = False
+            return
         if self._pingpong:
             if 'obs' in b:
                 b['obs'] = b['obs'].clone()
@@ -1057,8 +1072,14 @@ class BenchmarkEnv:
                              % (n, nu, tuple(a.shape)))
         return buf, False
 
-    def step(self, action):
+    def step(self, action, out=None):
         """Advance every env by one control step (quadrotor.py:507-558 + benchmark_env.py:422-463).
+
+        ``out`` (optional): ``{'obs': planes, 'reward': t, 'done': t}`` (any subset) -- tensors of the CALLER's that this step's
+        outputs are written into by the kernel itself, e.g. row t of a device rollout buffer (``PPOBuffer(env=...)``:
+        controllers/ppo/ppo_utils.py:308-336 without the per-step copy of ``push``): ``obs`` a contiguous float32
+        ``[obs_dim, plane_stride]`` plane buffer (it becomes the env's state buffer: the state ping-pongs into it),
+        ``reward`` float32 ``[>= N]``, ``done`` bool / uint8 ``[>= N]``.  The returned ``obs`` / ``rew`` / ``done`` are views of them.
 
         OWNERSHIP OF THE OUTPUTS.  With ``copy_outputs=True`` (the default of ``info_level='full'``, i.e. of a plain
         ``make()``) ``obs``, ``rew`` and ``done`` are fresh tensors, as the reference's are: the usual RL loop keeps the
@@ -1071,9 +1092,9 @@ class BenchmarkEnv:
         disturbance needs an obs buffer of its own.  The tensors inside ``info`` are always views of per-step buffers."""
         if self._async_outs is not None:
             raise RuntimeError('[ERROR] step() while a step_async() is pending: call step_wait() first.')
-        return self._step_outputs(self._step_launch(action, False))
+        return self._step_outputs(self._step_launch(action, False, out))
 
-    def step_async(self, action):
+    def step_async(self, action, out=None):
         """The first half of ``VecEnv.step`` (vec_env.py:47-59; ``SubprocVecEnv.step_async`` sends the actions to its workers
         and returns, subproc_vec_env.py:50-55): everything queued on the current stream so far -- the policy that produced
         ``action`` -- happens before the step; the step kernel itself goes to THIS ENV'S OWN launch queue
@@ -1084,7 +1105,7 @@ class BenchmarkEnv:
         on it (then neither call adds an event)."""
         if self._async_outs is not None:
             raise RuntimeError('[ERROR] step_async() while another step_async() is pending: call step_wait() first.')
-        self._async_outs = self._step_launch(action, True)
+        self._async_outs = self._step_launch(action, True, out)
 
     def step_wait(self):
         """The second half (vec_env.py:61-72): ``(obs, rew, done, info)`` of the pending ``step_async()``; work queued on the
@@ -1104,7 +1125,27 @@ class BenchmarkEnv:
         self._ensure_engine()
         return self._engine.queue_stream()
 
-    def _step_launch(self, action, asynchronous):
+    def _check_out(self, out):
+        """Validated (obs planes | None, reward | None, done | None) of step(out=...)."""
+        n, f32 = self.num_envs, torch.float32
+        obs_t, rew_t, done_t = out.get('obs'), out.get('reward'), out.get('done')
+        if set(out) - {'obs', 'reward', 'done'}:
+            raise ValueError("[ERROR] step(out=...): keys are 'obs', 'reward', 'done'.")
+        if obs_t is not None and not (isinstance(obs_t, torch.Tensor) and obs_t.dtype == f32 and obs_t.is_contiguous()
+                                      and tuple(obs_t.shape) == (self.obs_dim, self._ld) and obs_t.device == self._bufs['state'].device):
+            raise ValueError('[ERROR] step(out=...): obs must be a contiguous float32 (%d, %d) device tensor (obs_dim planes of '
+                             'env.plane_stride).' % (self.obs_dim, self._ld))
+        if rew_t is not None and not (isinstance(rew_t, torch.Tensor) and rew_t.dtype == f32 and rew_t.ndim == 1 and rew_t.is_contiguous()
+                                      and rew_t.shape[0] >= n and rew_t.device == self._bufs['state'].device):
+            raise ValueError('[ERROR] step(out=...): reward must be a contiguous float32 (>= %d,) device tensor.' % n)
+        if done_t is not None and not (isinstance(done_t, torch.Tensor) and done_t.dtype in (torch.bool, torch.uint8) and done_t.ndim == 1
+                                       and done_t.is_contiguous() and done_t.shape[0] >= n and done_t.device == self._bufs['state'].device):
+            raise ValueError('[ERROR] step(out=...): done must be a contiguous bool / uint8 (>= %d,) device tensor.' % n)
+        if obs_t is not None and (self.COMPENSATED_STATE or self.adversary_disturbance is not None):
+            raise ValueError('[ERROR] step(out=...): an obs target is not available in the precise modes or with an adversary.')
+        return obs_t, rew_t, done_t
+
+    def _step_launch(self, action, asynchronous, out=None):
         self._check_initial_reset()
         act, rows = self._load_action(action)
         self._raw_action, self._raw_action_rows = act, rows
@@ -1115,7 +1156,36 @@ class BenchmarkEnv:
             # the kernel runs on another queue than the one the caching allocator knows these tensors by: keep what it READS
             # alive until step_wait() has ordered the current stream behind it
             self._inflight = (act, b['state'], b.get('obs'))
-        if self._fresh_outputs:
+        if out is not None:
+            # the caller's tensors receive this step's outputs (a row of a rollout buffer): the fresh-output mechanism with the
+            # allocation done by the caller
+            obs_t, rew_t, done_t = self._check_out(out)
+            if rew_t is None:
+                rew_t = torch.empty(self.num_envs, dtype=torch.float32, device=self.device) if self._fresh_outputs else b['reward']
+            if done_t is None:
+                done_t = torch.empty(self.num_envs, dtype=torch.bool, device=self.device) if self._fresh_outputs else b['done']
+            if obs_t is None and self._fresh_outputs:
+                obs_t = torch.empty((self.obs_dim, self._ld), dtype=torch.float32, device=self.device)
+            if obs_t is None:
+                outs = (b.get('obs'), rew_t, done_t)           # state / obs stay where they are (views)
+            elif 'observation' in self.disturbances:
+                outs = (obs_t, rew_t, done_t)                  # a kernel-written observation buffer of its own; the state stays in place
+                b['obs'] = obs_t
+            else:
+                new_state = obs_t                              # the state ping-pongs into the caller's planes
+                outs = (obs_t if 'obs' in b else None, rew_t, done_t)
+            if self._fresh_outputs:
+                b['reward'], b['done'] = rew_t, done_t
+            else:
+                # views mode: the env keeps its own reward / done planes for later plain steps (the io is re-bound), and a state /
+                # observation that now lives in the caller's tensor is copied home before anything writes it in place
+                self._bound_dirty = True
+                self._state_external = self._state_external or obs_t is not None
+            self._out_views = None                             # the cached views of the lean tier point at the old buffers
+        elif self._state_external:
+            self._own_state()                                  # a plain (in-place) step after step(out=...): private planes first
+            b = self._bufs
+        elif self._fresh_outputs:
             # copy_outputs: this step's outputs get tensors of their own, written by the kernel (no clone afterwards)
             f32 = torch.float32
             if self._ring is not None:
@@ -1140,6 +1210,8 @@ class BenchmarkEnv:
             io = dict(b)
             io['action'] = act
             io['reset_state'] = self._reset_state_buf
+            if outs is not None:
+                io['reward'], io['done'] = outs[1], outs[2]
             if new_state is not None:
                 io['state_out'] = new_state
                 if 'obs' in b:
@@ -1161,14 +1233,21 @@ class BenchmarkEnv:
             if 'obs' in b:
                 b['obs'] = new_state
             b['state'] = new_state[:self.state_dim]
+        if self._bound_dirty:
+            self._bound, self._bound_dirty = False, False      # the next call binds the env's own reward / done planes again
         return new_state, outs
 
     def _step_outputs(self, launched):
         new_state, outs = launched
         b = self._bufs
         if outs is not None:
-            obs, rew, done = (new_state if new_state is not None else outs[0])[:, :self.num_envs].T, outs[1], outs[2]
+            src = new_state if new_state is not None else outs[0]
+            obs = (src if src is not None else (b['obs'] if 'obs' in b else b['state']))[:, :self.num_envs].T
+            rew, done = outs[1][:self.num_envs], outs[2][:self.num_envs]
         else:
+            if self._out_views is None:
+                self._out_views = ((b['obs'] if 'obs' in b else b['state'])[:, :self.num_envs].T, b['reward'][:self.num_envs],
+                                   b['done'][:self.num_envs])
             obs, rew, done = self._out_views
             if self.COPY_OUTPUTS:
                 obs, rew, done = obs.clone(), rew.clone(), done.clone()

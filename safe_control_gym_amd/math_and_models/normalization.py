@@ -209,7 +209,9 @@ class RewardStdNormalizer(MeanStdNormalizer):
         self.ret = None
         self.legacy_index_reset = legacy_index_reset
 
-    def __call__(self, x, dones):
+    def __call__(self, x, dones, out=None):
+        """``out`` (optional): a contiguous float32 [>= N] device tensor that receives the normalised rewards (e.g. row t of a
+        rollout buffer's reward planes); its [N] head is returned."""
         x = torch.as_tensor(x, dtype=torch.float32, device=self.device).reshape(-1).contiguous()
         n = x.shape[0]
         if n == 0:
@@ -220,7 +222,11 @@ class RewardStdNormalizer(MeanStdNormalizer):
         dones = dones.contiguous()
         if not self.read_only and self.ret is None:
             self.ret = torch.zeros(n, dtype=torch.float32, device=self.device)
-        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty(n, dtype=torch.float32, device=self.device)
+        elif not (isinstance(out, torch.Tensor) and out.dtype == torch.float32 and out.ndim == 1 and out.is_contiguous()
+                  and out.shape[0] >= n and out.device == x.device):
+            raise ValueError('[ERROR] out must be a contiguous float32 (>= %d,) device tensor' % n)
         state_in, state_out = self.rms._records(not self.read_only)
         with torch.cuda.device(self.device):
             _capi.check(self.lib.scg_reward_normalize(x.data_ptr(), dones.data_ptr(), _capi.ptr(self.ret), out.data_ptr(),
@@ -228,7 +234,7 @@ class RewardStdNormalizer(MeanStdNormalizer):
                                                       self.rms._moments.data_ptr(), float(self.gamma), float(self.clip),
                                                       float(self.epsilon), int(self.legacy_index_reset),
                                                       _stream(self.device)), 'scg_reward_normalize')
-        return out
+        return out[:n]
 
 
 class RescaleNormalizer(BaseNormalizer):

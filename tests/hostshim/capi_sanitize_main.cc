@@ -324,6 +324,8 @@ static void check_rollout_graphs() {
     EXPECT(g_shim.step_launches_main == 32 && g_shim.graph_launches == 0 && g_shim.captured_nodes == 0);
     EXPECT(scg_destroy(h) == SCG_OK);
     { scg_config d = c; d.rollout_graph = 2; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = c; d.lone_launch_forms = 2; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = c; d.lone_launch_forms = -2; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
     EXPECT(g_shim.execs_live == 0 && g_shim.graphs_live == 0);
 }
 
@@ -547,8 +549,12 @@ static void check_next_row_entry_points() {
     EXPECT(scg_discretize_exact(f.data(), f.data(), 6, 2, 0.02, f.data(), f.data(), f.data(), nullptr, f.data(), 4, nullptr) == SCG_OK);
     EXPECT(scg_quadratic_loss(h, d.data(), d.data(), f.data(), f.data(), f.data(), 4, f.data(), 0, f.data(), nullptr, nullptr, 8, 8, nullptr) == SCG_ERR_INVALID);
     EXPECT(scg_quadratic_loss(h, d.data(), d.data(), f.data(), f.data(), f.data(), 0, f.data(), 0, f.data(), nullptr, nullptr, 8, 8, nullptr) == SCG_OK);
-    EXPECT(scg_gae(f.data(), f.data(), f.data(), nullptr, f.data(), f.data(), f.data(), nullptr, nullptr, 0, 8, 8, 0.99f, 0.95f, 1, nullptr) == SCG_ERR_INVALID);
-    EXPECT(scg_gae(f.data(), f.data(), f.data(), nullptr, f.data(), f.data(), f.data(), f.data(), nullptr, 4, 8, 8, 0.99f, 0.95f, 1, nullptr) == SCG_OK);
+    EXPECT(scg_gae(f.data(), f.data(), f.data(), nullptr, nullptr, f.data(), f.data(), f.data(), nullptr, nullptr, 0, 8, 8, 0.99f, 0.95f, 1, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_gae(f.data(), f.data(), f.data(), nullptr, nullptr, f.data(), f.data(), f.data(), f.data(), nullptr, 4, 8, 8, 0.99f, 0.95f, 1, nullptr) == SCG_OK);
+    // exactly one of the float mask planes and the step kernel's done byte planes
+    EXPECT(scg_gae(f.data(), f.data(), nullptr, u.data(), nullptr, f.data(), f.data(), f.data(), f.data(), nullptr, 4, 8, 8, 0.99f, 0.95f, 1, nullptr) == SCG_OK);
+    EXPECT(scg_gae(f.data(), f.data(), f.data(), u.data(), nullptr, f.data(), f.data(), f.data(), f.data(), nullptr, 4, 8, 8, 0.99f, 0.95f, 1, nullptr) == SCG_ERR_INVALID);
+    EXPECT(scg_gae(f.data(), f.data(), nullptr, nullptr, nullptr, f.data(), f.data(), f.data(), f.data(), nullptr, 4, 8, 8, 0.99f, 0.95f, 1, nullptr) == SCG_ERR_INVALID);
     EXPECT(scg_normalize_advantages(f.data(), nullptr, 4, 8, 8, 1e-6f, nullptr) == SCG_ERR_INVALID);
     EXPECT(scg_mean_std_normalize(f.data(), f.data(), 0, 8, 8, 8, d.data(), d.data() + 32, d.data(), 10.f, 1e-8, nullptr) == SCG_ERR_INVALID);
     EXPECT(scg_mean_std_normalize(f.data(), f.data(), 3, 8, 8, 8, d.data(), d.data(), d.data(), 10.f, 1e-8, nullptr) == SCG_ERR_INVALID);

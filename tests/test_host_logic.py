@@ -265,7 +265,7 @@ def test_c_abi_rejects_bad_arguments_without_gpu_work():
     assert lib.scg_quadratic_loss(None, None, None, None, None, None, 0, None, 0, None, None, None, 0, 0, None) == -1
     assert lib.scg_mean_std_normalize(None, None, 3, 8, 8, 4, None, None, None, 10.0, 1e-8, None) == -1
     assert lib.scg_reward_normalize(None, None, None, None, 4, None, None, None, 0.99, 10.0, 1e-8, 0, None) == -1
-    assert lib.scg_gae(None, None, None, None, None, None, None, None, None, 4, 4, 4, 0.99, 0.95, 1, None) == -1
+    assert lib.scg_gae(None, None, None, None, None, None, None, None, None, None, 4, 4, 4, 0.99, 0.95, 1, None) == -1
     assert b'null' in lib.scg_last_error()
 
 

@@ -24,11 +24,30 @@ first)
   echo "== GPU suite"; timeout -k 10 1500 python -m pytest tests -m gpu -q > "$out/gpu_tests.log" 2>&1; grep -E "^(FAILED|ERROR)|passed|failed" "$out/gpu_tests.log" | tail -15
   echo "== driver's command"; timeout -k 10 600 python bench.py --gpus 1 --steps 20 --warmup 5 > "$out/bench_driver_cmd.json" 2> "$out/bench_driver_cmd.err"; tail -c 600 "$out/bench_driver_cmd.json"
   ;;
+second)
+  echo "== new GPU tests"; timeout -k 10 900 python -m pytest tests/test_pipelines_gpu.py tests/test_gae.py -m gpu -q -x > "$out/gpu_tests_new.log" 2>&1; tail -15 "$out/gpu_tests_new.log"
+  echo "== driver's command"; timeout -k 10 900 python bench.py --gpus 1 --steps 20 --warmup 5 > "$out/bench_driver_cmd.json" 2> "$out/bench_driver_cmd.err"; tail -5 "$out/bench_driver_cmd.err"
+  python - "$out/bench_driver_cmd.json" <<'PY'
+import json, sys
+j = json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1])
+print('value %.4g  ms_per_step %.5f  frac %.3f' % (j['value'], j['ms_per_step'], j['roofline']['frac']))
+for k in ('step_api', 'rl_pipeline', 'c3', 'c2'):
+    print(k, json.dumps(j.get(k))[:1500])
+for pt in j['n_sweep']['points']:
+    print(pt)
+PY
+  for t in gae; do
+    d="$out/trace_$t"; rm -rf "$d"
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$d" -- python3 tools/bench_$t.py > "$out/bench_$t.txt" 2> "$d.err"
+    s=$(find "$d" -name '*kernel_stats.csv' | head -1); [ -n "$s" ] && cp "$s" "$out/${t}_kernel_stats.csv" && grep scg_ "$s" | cut -c1-200
+    tail -3 "$out/bench_$t.txt"; rm -rf "$d"
+  done
+  ;;
 probe)
   timeout -k 10 900 python tools/step_api_probe.py "$@" 2>&1 | tee "$out/step_api_probe.txt"
   ;;
 lone)
-  arms="${ARMS:-shipped noserial trig_r02 perwave_reset}"
+  arms="${ARMS:-shipped noserial trig_r02 perwave_reset stagger32 stagger64 stagger127}"
   tbl="$out/lone_launch_arms.txt"; : > "$tbl"
   for round in 1 2; do
     for arm in $arms r02; do
@@ -98,5 +117,47 @@ evidence)
     tail -3 "$out/bench_$t.txt"; rm -rf "$d"
   done
   ;;
-*) echo "usage: $0 first|probe|lone|evidence <tag>"; exit 2 ;;
+loneab)
+  # the lone-launch kernel forms (scg_config.lone_launch_forms: per-wave reset, plain record stores) on / off: Python step loops by
+  # kernel trace, then the queued forms must not have moved: headline two-queue rollout, default tier rollout, C3 / C2 single queue
+  tbl="$out/lone_forms_ab.txt"; : > "$tbl"
+  for round in 1 2; do
+    for tier in lean default; do
+      for forms in 0 -1; do
+        d="$out/trace_${tier}_${forms}_$round"; rm -rf "$d"
+        SCG_LONE_LAUNCH_FORMS=$forms timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$d" -- python3 tools/step_loop_only.py 1500 $tier > "$d.log" 2>&1
+        echo "$tier round $round lone_launch_forms=$forms: $(trace_of "$d")" | tee -a "$tbl"
+        rm -rf "$d"
+      done
+    done
+  done
+  B="python bench.py --no-cpu-baseline --no-sub-records"
+  pr() { python -c "import sys,json; j=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('%s  %.2f us/step (min %.2f max %.2f)' % ('$1', j['ms_per_step']*1e3, j['ms_per_step_min_max'][0]*1e3, j['ms_per_step_min_max'][1]*1e3))"; }
+  for round in 1 2; do
+    $B --steps 1500 2>/dev/null | pr "headline two queues" | tee -a "$tbl"
+    $B --steps 1000 --env-kw info_level=full 2>/dev/null | pr "default tier two queues" | tee -a "$tbl"
+    for f in 0 1; do
+      $B --steps 1500 --queues 1 --env-kw lone_launch_forms=$f 2>/dev/null | pr "C4 one queue lone_launch_forms=$f" | tee -a "$tbl"
+      $B --steps 1000 --queues 1 --env-kw info_level=full --env-kw lone_launch_forms=$f 2>/dev/null | pr "default tier one queue lone_launch_forms=$f" | tee -a "$tbl"
+      $B --workload c3 --envs-per-gpu 262144 --steps 2000 --queues 1 --env-kw lone_launch_forms=$f 2>/dev/null | pr "C3 one queue lone_launch_forms=$f" | tee -a "$tbl"
+      $B --workload c2 --envs-per-gpu 65536 --steps 2000 --env-kw lone_launch_forms=$f 2>/dev/null | pr "C2 lone_launch_forms=$f" | tee -a "$tbl"
+    done
+  done
+  ;;
+timeline)
+  # kernel timelines of the policy-in-the-loop step loop: plain, two / three shards on their own queues, two shards joined to the
+  # caller's stream by events; then the same loops replayed from a HIP graph (no host in the loop)
+  tl="$out/step_api_timeline.txt"; : > "$tl"
+  for g in 0 50; do
+    for mode in plain pipe2_queue pipe3_queue pipe2; do
+      d="$out/trace_${mode}_g$g"; rm -rf "$d"
+      timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$d" -- python3 tools/step_api_probe.py --tiers lean --modes $mode --steps 400 --rounds 1 --graph $g > "$d.log" 2>&1
+      f=$(find "$d" -name '*kernel_trace.csv' | head -1)
+      grep "^round" "$d.log" | tee -a "$tl"
+      [ -n "$f" ] && python tools/pipeline_timeline.py "$f" "$tl" "lean tier, 2^20 envs, $mode$([ $g != 0 ] && echo ', replayed from a HIP graph of 50 steps')"
+      rm -rf "$d"
+    done
+  done
+  ;;
+*) echo "usage: $0 first|probe|lone|evidence|timeline <tag>"; exit 2 ;;
 esac

@@ -39,8 +39,24 @@ class AffinePolicy:
         return self.act
 
 
-def timed(loop, steps, warmup):
+def timed(loop, steps, warmup, graph=0):
     loop(warmup)
+    if graph:
+        # the host out of the loop: `graph` steps of the loop captured once (policy kernels, events, step kernels on their queues)
+        # and replayed; the Philox serials repeat per replay (timing only)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            loop(2)
+            with torch.cuda.graph(g, stream=side):
+                loop(graph)
+        torch.cuda.synchronize()
+        body, reps = loop, max(1, steps // graph)
+        loop = lambda k: [g.replay() for _ in range(max(1, k // graph))]
+        steps = reps * graph
+        loop(graph)
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -108,6 +124,7 @@ def main():
     ap.add_argument('--tiers', default='lean,default')
     ap.add_argument('--modes', default='plain_nopolicy,plain,pipe2,pipe2_queue,pipe3,pipe4')
     ap.add_argument('--rounds', type=int, default=2)
+    ap.add_argument('--graph', type=int, default=0, help='capture this many steps of each loop in a HIP graph and time replays')
     ap.add_argument('--env-kw', action='append', default=[])
     a = ap.parse_args()
     import yaml
@@ -128,7 +145,7 @@ def main():
                 else:
                     p = int(mode[4])
                     loop, close = pipelined_loop(a.envs, kw, p, mode.endswith('_queue'))
-                wall, dev = timed(loop, a.steps, a.warmup)
+                wall, dev = timed(loop, a.steps, a.warmup, a.graph)
                 close()
                 torch.cuda.empty_cache()
                 res.setdefault('%s/%s' % (tier, mode), []).append((wall, dev))
