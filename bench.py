@@ -455,15 +455,22 @@ def rl_pipeline_record(args, n, T):
     buf = PPOBuffer(env.observation_space, env.action_space, T, n, env=env)
     obs_norm, rew_norm = MeanStdNormalizer(shape=(od,), clip=10.0), RewardStdNormalizer(gamma=gamma, clip=10.0)
     dev = env.device
-    w_act = torch.tensor([[0.3, -0.2, 0.1, 0.25]], device=dev)
-    w_v = torch.tensor([0.3, -0.2, 0.05], device=dev)
-    zeros = torch.zeros(n, 1, device=dev)
+    w_act = torch.tensor([0.3, -0.2, 0.1, 0.25], device=dev).reshape(nu, 1)
+    b_act = torch.tensor([0.05, -0.05, 0.02, 0.0], device=dev).reshape(nu, 1)
+    w0, w1, bias = torch.tensor(0.3, device=dev), torch.tensor(-0.2, device=dev), torch.tensor([0.05], device=dev)
+    zeros = torch.zeros(n, device=dev)
+    rec = env._bufs['terminal_record']         # row-major [ld, stride]: the terminal observation of a finishing env in columns 0 .. od - 1
 
-    def actor(obs, out):                       # [n, nu] rows written straight into the buffer's action row: the env reads them there
-        torch.tanh(torch.mul(obs[:, :nu], w_act, out=out), out=out)
+    def actor(obs, out):                       # obs [n, od] is a transposed view of planes; out = the buffer's action planes [nu, ld]: ONE
+        torch.addcmul(b_act, obs.T[:nu], w_act, out=out[:, :n])          # kernel, coalesced (the env clips the normalised action itself)
 
-    def critic(obs, out=None):                 # a value "network": one fused elementwise expression of three observed states
-        return torch.addcmul(obs[:, 0:1] * w_v[0] + w_v[2], obs[:, 4:5], w_v[1], out=out)
+    def critic(obs, out=None):                 # a value "network": a linear read-out of two observed states (two kernels on planes)
+        planes = obs.T
+        return torch.addcmul(torch.add(bias, planes[0], alpha=0.3), planes[4], w1, out=out)
+
+    def terminal_value(info, out):             # critic(terminal_observation) where TimeLimit.truncated (ppo.py:264-273): the same read-out
+        tv = torch.addcmul(torch.add(bias, rec[:n, 0], alpha=0.3), rec[:n, 4], w1)     # over columns of the row-major terminal records
+        torch.where(info['TimeLimit.truncated'], tv, zeros, out=out)
 
     stages = ('policy', 'env_step', 'obs_normalizer', 'reward_normalizer', 'terminal_value', 'returns_gae')
     box = {'obs': obs_norm(env.reset(), out=buf.obs_planes[0])}
@@ -479,17 +486,17 @@ def rl_pipeline_record(args, n, T):
             obs = buf.start(box['obs'])
         for t in range(T):
             mark()
-            actor(obs, buf.act[t]); critic(obs, buf.v[t])
+            actor(obs, buf.act_planes[t]); critic(obs, buf.v[t, :, 0])
             mark()
-            raw, rew, done, info = env.step(buf.act[t], out=buf.step_out(t, obs=False, reward=False))
+            raw, rew, done, info = env.step(buf.act_planes[t], out=buf.step_out(t, obs=False, reward=False))
             mark()
             obs = obs_norm(raw, out=buf.obs_planes[t + 1])
             mark()
             rew_norm(rew, done, out=buf.rew_planes[t])
             mark()
-            torch.where(info['TimeLimit.truncated'][:, None], critic(info['terminal_observation']), zeros, out=buf.terminal_v[t])
+            terminal_value(info, buf.terminal_v[t, :, 0])
         mark()
-        ret, adv = compute_returns_and_advantages(buf.rew, buf.v, None, buf.terminal_v, critic(obs), gamma=gamma, use_gae=True,
+        ret, adv = compute_returns_and_advantages(buf.rew, buf.v, None, buf.terminal_v, critic(obs).reshape(n, 1), gamma=gamma, use_gae=True,
                                                   gae_lambda=0.95, normalize_advantages=True, dones=buf.done)
         mark()
         box['obs'] = obs
@@ -516,8 +523,12 @@ def rl_pipeline_record(args, n, T):
                        'PPOBuffer(env=...) rows -> scg_gae + advantage normalisation' % (n, T),
            'envs': n, 'rollout_steps': T, 'value': n * T / wall, 'unit': 'env-steps/s', 'us_per_step': wall / T * 1e6,
            'stage_us_per_step': {k: (v * 1e3 / T) for k, v in per.items()},
+           'library_stages_us_per_step': sum(per[k] for k in ('env_step', 'obs_normalizer', 'reward_normalizer', 'returns_gae')) * 1e3 / T,
+           'stand_in_stages_us_per_step': sum(per[k] for k in ('policy', 'terminal_value')) * 1e3 / T,
            'note': 'value / us_per_step: host clock over %d rollouts (sync -> rollouts -> sync), GAE included (its time is spread over the T steps in '
-                   'stage_us_per_step); stages by HIP events in one more rollout (the events add host time: their sum may exceed us_per_step)' % reps}
+                   'stage_us_per_step); stages by HIP events in one more rollout (the events add host time: their sum may exceed us_per_step); library stages = the '
+                   'engine\'s own kernels (step, normalisers, GAE), stand-in stages = the torch policy / critic / time-limit bootstrap (3 + 3 small '
+                   'elementwise kernels per step: launch-bound)' % reps}
     env.close()
     del buf
     torch.cuda.empty_cache()

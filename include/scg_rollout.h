@@ -156,8 +156,8 @@ typedef struct scg_config {
 } scg_config;
 
 /* np.random.RandomState methods the reset path can draw from on the device (benchmark_env.py:297-307); u, u2 are
- * Philox uniforms in [0, 1).  Rejection samplers (gamma, beta, vonmises ...), multivariate draws and choice() with probabilities or more
- * than three values are rejected by the Python layer. */
+ * Philox uniforms in [0, 1).  Multivariate draws, vonmises / f / standard_t ... and choice() over more than three values are rejected by the
+ * Python layer. */
 typedef enum scg_distribution {
     SCG_RAND_UNIFORM = 0,        /* uniform(low, high): low + (high - low) u              (fields *_rand_low / high) */
     SCG_RAND_NORMAL = 1,         /* normal(loc = p0, scale = p1): Box-Muller on (u, u2); standard_normal: p = (0, 1) */
@@ -173,9 +173,17 @@ typedef enum scg_distribution {
     SCG_RAND_PARETO = 11,        /* pareto(a = p0) (Lomax, as numpy): (1 - u)^(-1 / p0) - 1 */
     SCG_RAND_POWER = 12,         /* power(a = p0): u^(1 / p0) */
     SCG_RAND_LOGNORMAL = 13,     /* lognormal(mean = p0, sigma = p1): exp(normal(p0, p1)) on (u, u2) */
-    SCG_RAND_CAUCHY = 14         /* standard_cauchy(): tan(pi (u - 1/2)) */
+    SCG_RAND_CAUCHY = 14,        /* standard_cauchy(): tan(pi (u - 1/2)) */
+    /* Rejection samplers: a bounded loop over Philox blocks of their own, counter (env, serial, word0 + attempt) with word0 = 256 + 16 dim
+     * (initial state) / 512 + 16 q (inertial property) -- the draw of one quantity never shifts another's.  8 attempts per gamma variate
+     * (Marsaglia-Tsang accepts with probability > 0.95: all 8 fail once in 1e10 draws, the last candidate is then used). */
+    SCG_RAND_GAMMA = 15,         /* gamma(shape = p0, scale = p1) (standard_gamma: p1 = 1; chisquare(df): shape df / 2, scale 2): Marsaglia-Tsang
+                                    on (normal, uniform) pairs; shape < 1 by the boost gamma(shape + 1) u^(1 / shape) */
+    SCG_RAND_BETA = 16,          /* beta(a = p0, b = p1): x / (x + y) of two gamma variates (words word0 .. +7 and word0 + 8 .. +15) */
+    SCG_RAND_CHOICE_P = 17       /* choice(a, p = ...) over up to three values p0, p1, p2 with probabilities: *_rand_low = P(p0),
+                                    *_rand_high = P(p0) + P(p1) (cumulative; two values: high = 1): u < low ? p0 : u < high ? p1 : p2 */
 } scg_distribution;
-#define SCG_RAND_KIND_MAX 14
+#define SCG_RAND_KIND_MAX 17
 
 /* One scalar constraint g(v) <= 0 over v = [state ; RAW action] (constraints.py:160-172).
  * LinearConstraint / BoundedConstraint / DefaultConstraint (constraints.py:226-368) compile to

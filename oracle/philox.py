@@ -51,12 +51,48 @@ def uniform01(words):
 
 # scg_distribution (include/scg_rollout.h): the np.random.RandomState methods the reference may name in its yaml
 # (envs/benchmark_env.py:297-307), as transforms of the Philox uniforms -- shared with csrc/scg_kernels.hip::draw_distribution
-UNIFORM, NORMAL, EXPONENTIAL, LAPLACE, LOGISTIC, TRIANGULAR, RANDINT, CHOICE, RAYLEIGH, GUMBEL, WEIBULL, PARETO, POWER, LOGNORMAL, CAUCHY = range(15)
+(UNIFORM, NORMAL, EXPONENTIAL, LAPLACE, LOGISTIC, TRIANGULAR, RANDINT, CHOICE, RAYLEIGH, GUMBEL, WEIBULL, PARETO, POWER, LOGNORMAL, CAUCHY,
+ GAMMA, BETA, CHOICE_P) = range(18)
+REJECT_WORD_INIT, REJECT_WORD_INERTIAL, GAMMA_ATTEMPTS = 256, 512, 8
 
 
-def draw(kind, u, u2, p, low=0.0, high=1.0):
-    """One draw, float64.  u, u2 in [0, 1); p = (p0, p1, p2) as documented for scg_distribution."""
+def gamma_variate(a, ctx):
+    """gamma(shape a, 1) by Marsaglia-Tsang on Philox blocks (seed, env, serial, word0 + attempt) -- the twin of
+    csrc/scg_kernels.hip::gamma_variate (same words, same order, float64 arithmetic: an acceptance that falls within float32
+    rounding of its threshold may differ from the device's)."""
+    seed, env_index, serial, word0 = ctx
+    ab = a + 1.0 if a < 1.0 else a
+    d = ab - 1.0 / 3.0
+    c = 1.0 / np.sqrt(9.0 * d)
+    cand, boost = d, 0.5
+    for k in range(GAMMA_ATTEMPTS):
+        w = _uniform_block(seed, env_index, serial, word0 + k)
+        u0, u1, u2 = w[0] + 2.0 ** -25, w[1], w[2] + 2.0 ** -25
+        if k == 0:
+            boost = w[3] + 2.0 ** -25
+        x = np.sqrt(-2.0 * np.log(u0)) * np.cos(2.0 * np.pi * u1)
+        v = (1.0 + c * x) ** 3
+        if v > 0.0:
+            cand = d * v
+            if np.log(u2) < 0.5 * x * x + d - cand + d * np.log(v):
+                break
+    if a < 1.0:
+        cand *= boost ** (1.0 / a)
+    return cand
+
+
+def draw(kind, u, u2, p, low=0.0, high=1.0, ctx=None):
+    """One draw, float64.  u, u2 in [0, 1); p = (p0, p1, p2) as documented for scg_distribution; ctx = (seed, env index, serial,
+    word0) for the rejection samplers."""
     uo = u + 2.0 ** -25
+    if kind == GAMMA:
+        return p[1] * gamma_variate(p[0], ctx)
+    if kind == BETA:
+        x = gamma_variate(p[0], ctx)
+        y = gamma_variate(p[1], (ctx[0], ctx[1], ctx[2], ctx[3] + GAMMA_ATTEMPTS))
+        return x / (x + y)
+    if kind == CHOICE_P:                                     # low = P(p0), high = P(p0) + P(p1)
+        return p[0] if u < low else (p[1] if u < high else p[2])
     if kind == NORMAL:
         return p[0] + p[1] * np.sqrt(-2.0 * np.log(uo)) * np.cos(2.0 * np.pi * u2)
     if kind == EXPONENTIAL:
@@ -110,7 +146,8 @@ def reset_offsets(seed, env_index, reset_serial, low, high, kinds=None, params=N
         for w in range(4):
             d = 4 * j + w
             if d < nx:
-                out[d] = draw(int(kinds[d]), u[w], u2[w], params[d], low[d], high[d]) if general else low[d] + (high[d] - low[d]) * u[w]
+                out[d] = draw(int(kinds[d]), u[w], u2[w], params[d], low[d], high[d],
+                              (seed, env_index, reset_serial, REJECT_WORD_INIT + 16 * d)) if general else low[d] + (high[d] - low[d]) * u[w]
     return out
 
 
@@ -122,4 +159,5 @@ def inertial_offsets(seed, env_index, reset_serial, low, high, kinds=None, param
     if kinds is None or all(int(k) == UNIFORM for k in kinds):
         return low + (high - low) * u
     u2 = _uniform_block(seed, env_index, reset_serial, 14)
-    return np.array([draw(int(kinds[q]), u[q], u2[q], params[q], low[q], high[q]) for q in range(4)])
+    return np.array([draw(int(kinds[q]), u[q], u2[q], params[q], low[q], high[q], (seed, env_index, reset_serial, REJECT_WORD_INERTIAL + 16 * q))
+                     for q in range(4)])

@@ -24,7 +24,7 @@ SCG_DIST_ACTION, SCG_DIST_DYNAMICS, SCG_DIST_OBSERVATION = 0, 1, 2
 SCG_DIST_IMPULSE, SCG_DIST_STEP, SCG_DIST_UNIFORM, SCG_DIST_WHITE_NOISE, SCG_DIST_PERIODIC = 0, 1, 2, 3, 4
 (SCG_RAND_UNIFORM, SCG_RAND_NORMAL, SCG_RAND_EXPONENTIAL, SCG_RAND_LAPLACE, SCG_RAND_LOGISTIC, SCG_RAND_TRIANGULAR,
  SCG_RAND_RANDINT, SCG_RAND_CHOICE, SCG_RAND_RAYLEIGH, SCG_RAND_GUMBEL, SCG_RAND_WEIBULL, SCG_RAND_PARETO, SCG_RAND_POWER,
- SCG_RAND_LOGNORMAL, SCG_RAND_CAUCHY) = range(15)
+ SCG_RAND_LOGNORMAL, SCG_RAND_CAUCHY, SCG_RAND_GAMMA, SCG_RAND_BETA, SCG_RAND_CHOICE_P) = range(18)
 
 _dbl = C.c_double
 _i32 = C.c_int32

@@ -50,7 +50,7 @@ class PPOBuffer:
 
     def reset(self):
         for k, info in self.scheme.items():
-            if self.planes and k in self._ENGINE_KEYS:
+            if self.planes and (k in self._ENGINE_KEYS or k == 'act'):
                 continue
             init = info.get('init', torch.zeros)
             if self.planes and info['vshape'][2:] == (1,):
@@ -66,6 +66,10 @@ class PPOBuffer:
             self.done_planes = torch.zeros((T, ld), dtype=torch.bool, device=self.device)
             self.__dict__['obs'] = self.obs_planes[:T, :, :N].permute(0, 2, 1)                 # (T, N, obs_dim), zero copy
             self.__dict__['rew'] = self.rew_planes[:, :N].unsqueeze(-1)                        # (T, N, 1), zero copy
+            # the actions as planes too: a policy that writes act_planes[t] (coalesced) hands the env its action planes in place
+            # (env.step(buf.act_planes[t])); push({'act': rows}) transposes into them
+            self.act_planes = torch.zeros((T, self.scheme['act']['vshape'][2], ld), dtype=torch.float32, device=self.device)
+            self.__dict__['act'] = self.act_planes[:, :, :N].permute(0, 2, 1)                  # (T, N, act_dim), zero copy
         self.t = 0
 
     # ---- the engine-written rows (env=...) ---------------------------------------------------------------------------

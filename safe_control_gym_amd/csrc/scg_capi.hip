@@ -373,6 +373,19 @@ int scg_create(const scg_config* cfg, scg_handle** out) {
         if (cfg->inertial_rand_kind[q] < SCG_RAND_UNIFORM || cfg->inertial_rand_kind[q] > SCG_RAND_KIND_MAX)
             return fail(SCG_ERR_INVALID, "scg_create: inertial_rand_kind[%d] = %d is not a scg_distribution", q, cfg->inertial_rand_kind[q]);
 
+    // parameter ranges of the rejection samplers and of the weighted choice (the kernel divides by / takes roots of them)
+    auto bad_params = [](int kind, const double* prm, double low, double high) -> const char* {
+        if (kind == SCG_RAND_GAMMA && !(prm[0] > 0.0 && prm[1] >= 0.0)) return "gamma needs shape > 0 and scale >= 0";
+        if (kind == SCG_RAND_BETA && !(prm[0] > 0.0 && prm[1] > 0.0)) return "beta needs a > 0 and b > 0";
+        if (kind == SCG_RAND_CHOICE_P && !(low >= 0.0 && high >= low && high <= 1.0 + 1e-9)) return "weighted choice needs 0 <= P(p0) <= P(p0) + P(p1) <= 1 in rand_low / rand_high";
+        return nullptr;
+    };
+    for (int j = 0; j < nx && cfg->randomized_init; ++j)
+        if (const char* why = bad_params(cfg->init_rand_kind[j], cfg->init_rand_p[j], cfg->init_rand_low[j], cfg->init_rand_high[j]))
+            return fail(SCG_ERR_INVALID, "scg_create: init_rand_kind[%d]: %s", j, why);
+    for (int q = 0; q < 4 && cfg->randomized_inertial; ++q)
+        if (const char* why = bad_params(cfg->inertial_rand_kind[q], cfg->inertial_rand_p[q], cfg->inertial_rand_low[q], cfg->inertial_rand_high[q]))
+            return fail(SCG_ERR_INVALID, "scg_create: inertial_rand_kind[%d]: %s", q, why);
     // SCG_RAND_CHOICE carries its number of values in *_rand_low: 1, 2 or 3 (the kernel selects among p[0..2])
     for (int j = 0; j < nx; ++j)
         if (cfg->randomized_init && cfg->init_rand_kind[j] == SCG_RAND_CHOICE &&
@@ -401,7 +414,15 @@ int scg_create(const scg_config* cfg, scg_handle** out) {
                     return fail(SCG_ERR_INVALID, "scg_create: randomised inertial property %d has high < low", q);
             } else if (kind == SCG_RAND_TRIANGULAR || kind == SCG_RAND_RANDINT) lowest = cfg->inertial_rand_p[q][0];
             else if (kind == SCG_RAND_EXPONENTIAL || kind == SCG_RAND_RAYLEIGH || kind == SCG_RAND_WEIBULL || kind == SCG_RAND_PARETO ||
-                     kind == SCG_RAND_POWER || kind == SCG_RAND_LOGNORMAL) lowest = 0.0;
+                     kind == SCG_RAND_POWER || kind == SCG_RAND_LOGNORMAL || kind == SCG_RAND_GAMMA || kind == SCG_RAND_BETA) lowest = 0.0;
+            else if (kind == SCG_RAND_CHOICE_P) {
+                // values with a non-zero probability: p0 if low > 0, p1 if high > low, p2 if high < 1
+                const double lo = cfg->inertial_rand_low[q], hi = cfg->inertial_rand_high[q];
+                lowest = 1e300;
+                if (lo > 0.0) lowest = cfg->inertial_rand_p[q][0];
+                if (hi > lo && cfg->inertial_rand_p[q][1] < lowest) lowest = cfg->inertial_rand_p[q][1];
+                if (hi < 1.0 && cfg->inertial_rand_p[q][2] < lowest) lowest = cfg->inertial_rand_p[q][2];
+            }
             else if (kind == SCG_RAND_CHOICE) {
                 const int cnt = (int)cfg->inertial_rand_low[q];
                 lowest = cfg->inertial_rand_p[q][0];

@@ -159,9 +159,52 @@ __device__ __forceinline__ void apply_disturbances(const KParams& p, const DistT
 // One draw of a reset-time distribution (scg_distribution; benchmark_env.py:297-307 calls np_random.<distrib>) as a
 // transform of the Philox uniforms u, u2 in [0, 1).  Shared with oracle/philox.py::draw.  The log-based kinds read
 // u + 2^-25 in (0, 1) so that neither log(0) nor log(1 - 1) occurs.
-__device__ __forceinline__ float draw_distribution(int kind, float u, float u2, const float (&p)[3], float lo, float span) {
+// Where a rejection sampler finds Philox blocks of its own: counter (env lo, env hi, serial, word0 + attempt).
+struct RandCtx {
+    uint32_t g_lo, g_hi, serial, k0, k1, word0;
+};
+constexpr uint32_t kRejectWordInit = 256u, kRejectWordInertial = 512u;      // + 16 * (dim | property)
+constexpr int kGammaAttempts = 8;
+
+// gamma(shape a, scale 1) by Marsaglia & Tsang (2000): d = a' - 1/3, c = 1 / sqrt(9 d), candidate d (1 + c x)^3 for a normal x,
+// accepted when ln u < x^2 / 2 + d - d v + d ln v; a < 1 through gamma(a + 1) u^(1 / a).  One Philox block per attempt (normal from
+// words 0, 1; acceptance uniform word 2; the boost uniform is word 3 of attempt 0, which no acceptance test reads).  A real function:
+// it sits behind a wave-uniform kind test of the catch-all tier and must not be inlined into every dimension's draw.
+__device__ __noinline__ float gamma_variate(float a, RandCtx rc) {
+    const float ab = a < 1.0f ? a + 1.0f : a;
+    const float d = ab - 0.3333333333333333f, c = rcp_f(sqrt_f(9.0f * d));
+    float cand = d, boost = 0.5f;
+    for (int k = 0; k < kGammaAttempts; ++k) {
+        uint32_t w[4];
+        philox4x32_10(rc.g_lo, rc.g_hi, rc.serial, rc.word0 + (uint32_t)k, rc.k0, rc.k1, w);
+        const float u0 = (float)(w[0] >> 8) * 5.9604644775390625e-8f + 2.9802322387695312e-8f;
+        const float u1 = (float)(w[1] >> 8) * 5.9604644775390625e-8f;
+        const float u2 = (float)(w[2] >> 8) * 5.9604644775390625e-8f + 2.9802322387695312e-8f;
+        if (k == 0) boost = (float)(w[3] >> 8) * 5.9604644775390625e-8f + 2.9802322387695312e-8f;
+        float sn, cs;
+        sincos_f(6.283185307179586f * u1, sn, cs);
+        const float x = sqrt_f(-2.0f * logf(u0)) * cs;
+        const float t = fmaf(c, x, 1.0f), v = t * t * t;
+        if (v > 0.0f) {
+            cand = d * v;
+            if (logf(u2) < fmaf(0.5f * x, x, d - cand + d * logf(v))) break;
+        }
+    }
+    if (a < 1.0f) cand *= powf(boost, 1.0f / a);
+    return cand;
+}
+
+__device__ __forceinline__ float draw_distribution(int kind, float u, float u2, const float (&p)[3], float lo, float span, const RandCtx& rc) {
     const float uo = u + 2.9802322387695312e-8f;                       // 2^-25
     switch (kind) {
+        case SCG_RAND_GAMMA: return p[1] * gamma_variate(p[0], rc);
+        case SCG_RAND_BETA: {
+            RandCtx ry = rc;
+            ry.word0 += (uint32_t)kGammaAttempts;
+            const float x = gamma_variate(p[0], rc), y = gamma_variate(p[1], ry);
+            return x / (x + y);
+        }
+        case SCG_RAND_CHOICE_P: return u < lo ? p[0] : (u < lo + span ? p[1] : p[2]);       // lo = P(p0), lo + span = P(p0) + P(p1)
         case SCG_RAND_NORMAL: {                                          // Box-Muller, accurate sin / cos
             const float r = sqrt_f(-2.0f * logf(uo));
             float sn, cs;
@@ -228,8 +271,9 @@ __device__ __forceinline__ void reset_state_of(const KParams& p, const KTables* 
                     const float u = (float)(w[q] >> 8) * 5.9604644775390625e-8f;   // 2^-24
                     if (general) {
                         const float pr[3] = {tb->init_p[d][0], tb->init_p[d][1], tb->init_p[d][2]};
+                        const RandCtx rc{(uint32_t)g, (uint32_t)(g >> 32), serial, p.seed_lo, p.seed_hi, kRejectWordInit + 16u * (uint32_t)d};
                         x[d] += draw_distribution(tb->init_kind[d], u, (float)(w2[q] >> 8) * 5.9604644775390625e-8f, pr,
-                                                  tb->init_lo[d], tb->init_span[d]);
+                                                  tb->init_lo[d], tb->init_span[d], rc);
                     } else {
                         x[d] += fmaf(tb->init_span[d], u, tb->init_lo[d]);
                     }
@@ -567,8 +611,9 @@ __device__ __forceinline__ void draw_inertial(const KParams& p, const KTables* _
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float pr[3] = {tb->inertial_p[q][0], tb->inertial_p[q][1], tb->inertial_p[q][2]};
+                const RandCtx rc{(uint32_t)g, (uint32_t)(g >> 32), serial, p.seed_lo, p.seed_hi, kRejectWordInertial + 16u * (uint32_t)q};
                 prop[q] += draw_distribution(tb->inertial_kind[q], (float)(w[q] >> 8) * 5.9604644775390625e-8f,
-                                             (float)(w2[q] >> 8) * 5.9604644775390625e-8f, pr, tb->inertial_lo[q], tb->inertial_span[q]);
+                                             (float)(w2[q] >> 8) * 5.9604644775390625e-8f, pr, tb->inertial_lo[q], tb->inertial_span[q], rc);
                 prop[q] = fmaxf(prop[q], 1e-3f * tb->inertial_nominal[q]);
             }
         } else {

@@ -3,10 +3,10 @@
 The reference draws every randomised quantity with ``getattr(self.np_random, info['distrib'])(*args, **kwargs)``
 (/root/reference/safe_control_gym/envs/benchmark_env.py:297-307): any ``numpy.random.RandomState`` method name is legal in the
 yaml.  On the device the draw is a transform of one or two Philox uniforms per quantity (``scg_distribution`` in
-include/scg_rollout.h); this module maps the RandomState signatures of the supported methods onto it.  Methods that are
-not a transform of a fixed number of uniforms (``permutation``, ``multivariate_normal``, rejection samplers such as ``gamma`` /
-``beta`` / ``vonmises`` ...) raise ``NotImplementedError`` naming the method; so does ``choice`` with probabilities or more than
-three values (the device record of a quantity holds three parameters).
+include/scg_rollout.h); this module maps the RandomState signatures of the supported methods onto it.  ``gamma`` (and ``standard_gamma``, ``chisquare``) and
+``beta`` are bounded-iteration rejection samplers on Philox blocks of their own.  What stays out raises ``NotImplementedError`` naming
+the method: array-valued draws (``permutation``, ``multivariate_normal`` ...), ``vonmises`` / ``f`` / ``standard_t`` ..., and ``choice``
+over more than three values (the device record of a quantity holds three parameters).
 """
 from safe_control_gym_amd import _capi
 
@@ -32,6 +32,11 @@ _SIGNATURES = {
     'random_sample': (_capi.SCG_RAND_UNIFORM, ()), 'random': (_capi.SCG_RAND_UNIFORM, ()), 'ranf': (_capi.SCG_RAND_UNIFORM, ()),
     'sample': (_capi.SCG_RAND_UNIFORM, ()), 'rand': (_capi.SCG_RAND_UNIFORM, ()),
     'choice': (_capi.SCG_RAND_CHOICE, (('a', None), ('size', None), ('replace', True), ('p', None))),
+    # rejection samplers (Marsaglia-Tsang gamma; beta from two gammas)
+    'gamma': (_capi.SCG_RAND_GAMMA, (('shape', None), ('scale', 1.0))),
+    'standard_gamma': (_capi.SCG_RAND_GAMMA, (('shape', None),)),
+    'chisquare': (_capi.SCG_RAND_GAMMA, (('df', None),)),
+    'beta': (_capi.SCG_RAND_BETA, (('a', None), ('b', None))),
 }
 SUPPORTED = tuple(sorted(_SIGNATURES))
 
@@ -73,6 +78,16 @@ def parse_distribution(info, what=''):
         v = [0.0, 1.0]
     if name == 'standard_exponential':
         v = [1.0]
+    if name == 'standard_gamma':
+        v = [v[0], 1.0]
+    if name == 'chisquare':                                              # chisquare(df) = gamma(df / 2, scale 2)
+        if not v[0] > 0:
+            raise ValueError('[ERROR] df <= 0 in chisquare().')
+        v = [0.5 * v[0], 2.0]
+    if kind == _capi.SCG_RAND_GAMMA and (not v[0] > 0 or v[1] < 0):
+        raise ValueError('[ERROR] %s() needs shape > 0 and scale >= 0%s.' % (name, ' for ' + what if what else ''))
+    if kind == _capi.SCG_RAND_BETA and not (v[0] > 0 and v[1] > 0):
+        raise ValueError('[ERROR] beta() needs a > 0 and b > 0%s.' % (' for ' + what if what else ''))
     if kind == _capi.SCG_RAND_UNIFORM:
         return (kind, v[0], v[1], (0.0, 0.0, 0.0)) if v else (kind, 0.0, 1.0, (0.0, 0.0, 0.0))
     if kind in (_capi.SCG_RAND_RAYLEIGH,) and v[0] < 0 or kind in (_capi.SCG_RAND_GUMBEL, _capi.SCG_RAND_LOGNORMAL) and v[1] < 0:
@@ -108,17 +123,31 @@ def _parse_choice(args, info, what):
         raise TypeError('[ERROR] choice() is missing a required argument%s.' % (' for ' + what if what else ''))
     if vals.get('size') is not None:
         raise NotImplementedError('[ERROR] choice(size=...) draws an array; a randomised quantity is a scalar.')
-    if vals.get('p') is not None:
-        raise NotImplementedError('[ERROR] choice() with probabilities is not available on the device (equiprobable values only).')
-    a = vals['a']
+    a, prob = vals['a'], vals.get('p')
     if isinstance(a, (int, float)) and not isinstance(a, bool):
         if int(a) != a or a < 1:
             raise ValueError('[ERROR] choice(a): a must be a positive integer or a sequence.')
-        return _capi.SCG_RAND_RANDINT, 0.0, 0.0, (0.0, float(a), 0.0)
+        if prob is None:
+            return _capi.SCG_RAND_RANDINT, 0.0, 0.0, (0.0, float(a), 0.0)
+        a = list(range(int(a)))                                          # choice(3, p=...) draws from arange(3)
     a = [float(v) for v in a]
     if not 1 <= len(a) <= 3:
         raise NotImplementedError('[ERROR] choice() over %d values is not available on the device (at most 3).' % len(a))
-    return _capi.SCG_RAND_CHOICE, float(len(a)), 0.0, tuple(a + [0.0] * (3 - len(a)))
+    if prob is None:
+        return _capi.SCG_RAND_CHOICE, float(len(a)), 0.0, tuple(a + [0.0] * (3 - len(a)))
+    prob = [float(q) for q in prob]
+    if len(prob) != len(a):
+        raise ValueError("[ERROR] choice(): 'a' and 'p' must have same size")                     # numpy's own messages
+    if any(q < 0 for q in prob):
+        raise ValueError('[ERROR] choice(): probabilities are not non-negative')
+    if abs(sum(prob) - 1.0) > 1e-8:
+        raise ValueError('[ERROR] choice(): probabilities do not sum to 1')
+    # weighted choice: low = P(a0), high = P(a0) + P(a1) (cumulative); unused value slots repeat the last value
+    c1 = prob[0]
+    c2 = 1.0 if len(a) <= 2 else prob[0] + prob[1]
+    if len(a) == 1:
+        c1 = 1.0
+    return _capi.SCG_RAND_CHOICE_P, c1, c2, tuple(a + [a[-1]] * (3 - len(a)))
 
 
 def lower_bound(kind, low, p):
@@ -134,4 +163,8 @@ def lower_bound(kind, low, p):
         return 0.0
     if kind == _capi.SCG_RAND_CHOICE:
         return min(p[:int(low)])
+    if kind in (_capi.SCG_RAND_GAMMA, _capi.SCG_RAND_BETA):
+        return 0.0
+    if kind == _capi.SCG_RAND_CHOICE_P:
+        return min(p)                                                    # (value slots without a probability repeat a real value)
     return float('-inf')

@@ -94,6 +94,21 @@ static void check_create_validation() {
         scg_config d = c; d.init_rand_kind[2] = SCG_RAND_CHOICE; d.init_rand_low[2] = cnt;
         scg_handle* ok = nullptr; EXPECT(scg_create(&d, &ok) == SCG_OK); EXPECT(scg_destroy(ok) == SCG_OK);
     }
+    // parameter ranges of the rejection samplers and the weighted choice
+    { scg_config d = c; d.init_rand_kind[0] = SCG_RAND_GAMMA; d.init_rand_p[0][0] = 0.0; d.init_rand_p[0][1] = 1.0; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = c; d.init_rand_kind[0] = SCG_RAND_GAMMA; d.init_rand_p[0][0] = 2.0; d.init_rand_p[0][1] = -1.0; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = c; d.init_rand_kind[1] = SCG_RAND_BETA; d.init_rand_p[1][0] = 2.0; d.init_rand_p[1][1] = 0.0; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = c; d.init_rand_kind[2] = SCG_RAND_CHOICE_P; d.init_rand_low[2] = 0.6; d.init_rand_high[2] = 0.5; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = c; d.init_rand_kind[2] = SCG_RAND_CHOICE_P; d.init_rand_low[2] = 0.6; d.init_rand_high[2] = 1.5; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID); }
+    { scg_config d = c; d.init_rand_kind[0] = SCG_RAND_GAMMA; d.init_rand_p[0][0] = 0.5; d.init_rand_p[0][1] = 0.1;
+      d.init_rand_kind[1] = SCG_RAND_BETA; d.init_rand_p[1][0] = 2.0; d.init_rand_p[1][1] = 3.0;
+      d.init_rand_kind[2] = SCG_RAND_CHOICE_P; d.init_rand_low[2] = 0.25; d.init_rand_high[2] = 0.75;
+      scg_handle* ok = nullptr; EXPECT(scg_create(&d, &ok) == SCG_OK); EXPECT(scg_destroy(ok) == SCG_OK); }
+    // a weighted choice of an inertial property must not reach a non-positive value with a non-zero probability
+    { scg_config d = c; d.randomized_inertial = 1; d.inertial_rand_kind[0] = SCG_RAND_CHOICE_P; d.inertial_rand_low[0] = 0.5; d.inertial_rand_high[0] = 1.0;
+      d.inertial_rand_p[0][0] = 0.0; d.inertial_rand_p[0][1] = -1.0; d.inertial_rand_p[0][2] = -1.0; EXPECT(scg_create(&d, &h) == SCG_ERR_INVALID);
+      d.inertial_rand_high[0] = 0.5; d.inertial_rand_low[0] = 0.5; d.inertial_rand_p[0][2] = 0.001;        // p1 has probability 0 now
+      scg_handle* ok = nullptr; EXPECT(scg_create(&d, &ok) == SCG_OK); EXPECT(scg_destroy(ok) == SCG_OK); }
     EXPECT(g_shim.live_allocations == 0);             // no failed create leaks its tables
     EXPECT(scg_destroy(nullptr) == SCG_OK);
     EXPECT(scg_version() == SCG_ABI_VERSION && scg_sizeof_config() == (int)sizeof(scg_config) && scg_sizeof_step_io() == (int)sizeof(scg_step_io));

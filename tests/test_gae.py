@@ -212,6 +212,7 @@ def test_zero_copy_ppo_buffer_equals_the_pushed_buffer(gpu, normalisers, tier):
     a_buf = PPOBuffer(a_env.observation_space, a_env.action_space, T, N)
     b_buf = PPOBuffer(b_env.observation_space, b_env.action_space, T, N, env=b_env)
     assert b_buf.obs.shape == (T, N, od) and b_buf.rew.shape == (T, N, 1) and b_buf.mask.shape == (T, N, 1) and b_buf.v.shape == (T, N, 1)
+    assert b_buf.act.shape == (T, N, 2) and b_buf.act_planes.shape == (T, 2, b_env.plane_stride)
     with pytest.raises(KeyError, match='written by the step kernel'):
         b_buf.push({'obs': torch.zeros(N, od, device='cuda')})
     ident = lambda x, *a, **k: x
@@ -230,7 +231,9 @@ def test_zero_copy_ppo_buffer_equals_the_pushed_buffer(gpu, normalisers, tier):
             act_a, act_b = actor(a_obs), actor(b_obs)
             assert torch.equal(act_a, act_b)
             v_a, v_b = critic(a_obs), critic(b_obs)
-            # reference scheme: everything pushed
+            # reference scheme: everything pushed (the lean tier hands out VIEWS that the next step overwrites: keep a copy of this
+            # step's observation, as a caller of that tier must)
+            a_obs = a_obs.clone()
             nobs, rew, done, info = a_env.step(act_a)
             nobs_n, rew_n = a_on(nobs), a_rn(rew, done)
             tv_a = torch.where(info['TimeLimit.truncated'][:, None], critic(info['terminal_observation']), zeros) if full else zeros
@@ -253,7 +256,7 @@ def test_zero_copy_ppo_buffer_equals_the_pushed_buffer(gpu, normalisers, tier):
             assert torch.equal(getattr(a_buf, k), getattr(b_buf, k)), k
         assert float(b_buf.mask.sum()) < N * T               # episodes ended inside the rollout
         last_a, last_b = critic(a_obs), critic(b_buf.obs_at(T))
-        ret_a, adv_a = compute_returns_and_advantages(a_buf.rew.clone(), a_buf.v, a_buf.mask, a_buf.terminal_v, last_a, gamma=gamma,
+        ret_a, adv_a = compute_returns_and_advantages(a_buf.rew, a_buf.v, a_buf.mask, a_buf.terminal_v, last_a, gamma=gamma,
                                                       use_gae=True, gae_lambda=lam, normalize_advantages=True)
         ret_b, adv_b = compute_returns_and_advantages(b_buf.rew, b_buf.v, None, b_buf.terminal_v, last_b, gamma=gamma, use_gae=True,
                                                       gae_lambda=lam, normalize_advantages=True, dones=b_buf.done)

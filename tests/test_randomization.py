@@ -32,8 +32,18 @@ SPECS = {
     'choice_3': ({'distrib': 'choice', 'args': [[-0.1, 0.0, 0.25]]}, (philox.CHOICE, (-0.1, 0.0, 0.25))),
     'choice_2_kw': ({'distrib': 'choice', 'a': [0.5, 1.5]}, (philox.CHOICE, (0.5, 1.5, 0.0))),
     'choice_int': ({'distrib': 'choice', 'args': [3]}, (philox.RANDINT, (0.0, 3.0, 0.0))),
+    # round 4: the rejection samplers and the weighted choice
+    'gamma': ({'distrib': 'gamma', 'shape': 2.5, 'scale': 0.1}, (philox.GAMMA, (2.5, 0.1, 0.0))),
+    'gamma_shape_below_one': ({'distrib': 'gamma', 'args': [0.6]}, (philox.GAMMA, (0.6, 1.0, 0.0))),
+    'standard_gamma': ({'distrib': 'standard_gamma', 'shape': 7.0}, (philox.GAMMA, (7.0, 1.0, 0.0))),
+    'chisquare': ({'distrib': 'chisquare', 'df': 3.0}, (philox.GAMMA, (1.5, 2.0, 0.0))),
+    'beta': ({'distrib': 'beta', 'a': 2.0, 'b': 5.0}, (philox.BETA, (2.0, 5.0, 0.0))),
+    'beta_u_shaped': ({'distrib': 'beta', 'args': [0.5, 0.5]}, (philox.BETA, (0.5, 0.5, 0.0))),
+    'choice_p_3': ({'distrib': 'choice', 'a': [-0.1, 0.0, 0.25], 'p': [0.2, 0.5, 0.3]}, (philox.CHOICE_P, (-0.1, 0.0, 0.25))),
+    'choice_p_2': ({'distrib': 'choice', 'args': [[0.5, 1.5]], 'p': [0.9, 0.1]}, (philox.CHOICE_P, (0.5, 1.5, 1.5))),
+    'choice_p_int': ({'distrib': 'choice', 'args': [3], 'p': [0.1, 0.1, 0.8]}, (philox.CHOICE_P, (0.0, 1.0, 2.0))),
 }
-DISCRETE = {'randint', 'randint_one_arg', 'choice_3', 'choice_2_kw', 'choice_int'}
+DISCRETE = {'randint', 'randint_one_arg', 'choice_3', 'choice_2_kw', 'choice_int', 'choice_p_3', 'choice_p_2', 'choice_p_int'}
 
 
 @pytest.mark.parametrize('name', sorted(SPECS))
@@ -50,14 +60,25 @@ def test_parser_binds_arguments_like_randomstate(name):
 def test_parser_rejects_what_the_device_cannot_draw():
     with pytest.raises(NotImplementedError, match='at most 3'):
         rz.parse_distribution({'distrib': 'choice', 'args': [[1, 2, 3, 4]]})
-    with pytest.raises(NotImplementedError, match='probabilities'):
-        rz.parse_distribution({'distrib': 'choice', 'a': [1, 2], 'p': [0.3, 0.7]})
+    assert rz.parse_distribution({'distrib': 'choice', 'a': [1, 2], 'p': [0.3, 0.7]})[:3] == (philox.CHOICE_P, 0.3, 1.0)
+    assert rz.parse_distribution({'distrib': 'choice', 'a': [1, 2, 4], 'p': [0.25, 0.5, 0.25]})[:3] == (philox.CHOICE_P, 0.25, 0.75)
+    with pytest.raises(ValueError, match='sum to 1'):
+        rz.parse_distribution({'distrib': 'choice', 'a': [1, 2], 'p': [0.3, 0.3]})
+    with pytest.raises(ValueError, match='same size'):
+        rz.parse_distribution({'distrib': 'choice', 'a': [1, 2], 'p': [1.0]})
+    with pytest.raises(NotImplementedError, match='at most 3'):
+        rz.parse_distribution({'distrib': 'choice', 'a': 4, 'p': [0.25] * 4})
     with pytest.raises(ValueError, match='a <= 0'):
         rz.parse_distribution({'distrib': 'weibull', 'a': 0.0})
     assert rz.parse_distribution({'distrib': 'random_sample'})[:3] == (philox.UNIFORM, 0.0, 1.0)
     assert rz.parse_distribution({'distrib': 'standard_cauchy'})[0] == philox.CAUCHY
-    with pytest.raises(NotImplementedError, match='gamma'):
-        rz.parse_distribution({'distrib': 'gamma', 'shape': 2.0})
+    with pytest.raises(NotImplementedError, match='vonmises'):
+        rz.parse_distribution({'distrib': 'vonmises', 'mu': 0.0, 'kappa': 1.0})
+    with pytest.raises(ValueError, match='shape > 0'):
+        rz.parse_distribution({'distrib': 'gamma', 'shape': 0.0})
+    with pytest.raises(ValueError, match='a > 0 and b > 0'):
+        rz.parse_distribution({'distrib': 'beta', 'a': 1.0, 'b': -1.0})
+    assert rz.lower_bound(*[rz.parse_distribution({'distrib': 'gamma', 'shape': 2.0})[q] for q in (0, 1, 3)]) == 0.0
     with pytest.raises(TypeError, match='unexpected'):
         rz.parse_distribution({'distrib': 'normal', 'mean': 0.0})
     with pytest.raises(TypeError, match='multiple values'):
@@ -76,8 +97,12 @@ def test_oracle_transform_has_the_distribution_numpy_draws(name):
     m = 1 << 18
     u = (np.arange(m) + 0.5) / m
     u2 = ((np.arange(m) * 0.6180339887498949) % 1.0)                    # an independent low-discrepancy sequence
-    low = rz.parse_distribution(info, name)[1]                          # (choice: the number of values travels in `low`)
-    mine = np.array([philox.draw(kind, a, b, p, low) for a, b in zip(u[::8], u2[::8])])
+    _, low, high, _ = rz.parse_distribution(info, name)                 # (choice: the number of values / the cumulative probabilities)
+    # the rejection samplers draw from Philox blocks of their own: one (env index, word0) per sample
+    # (their draws are a Monte-Carlo sample, not a quadrature over the uniforms: twice as many of them and a wider quantile tolerance)
+    mc = kind in (philox.GAMMA, philox.BETA)
+    step = 4 if mc else 8
+    mine = np.array([philox.draw(kind, a, b, p, low, high, (99, i, 3, philox.REJECT_WORD_INIT + 32)) for i, (a, b) in enumerate(zip(u[::step], u2[::step]))])
     d = dict(info)
     fn = getattr(np.random.RandomState(12345), d.pop('distrib'))
     theirs = np.asarray(fn(*d.pop('args', []), size=400000, **d), dtype=np.float64)
@@ -87,9 +112,11 @@ def test_oracle_transform_has_the_distribution_numpy_draws(name):
     for q in (0.05, 0.25, 0.5, 0.75, 0.95):
         if name in DISCRETE:
             continue
-        assert abs(np.quantile(mine, q) - np.quantile(theirs, q)) < 0.03 * scale, q
+        assert abs(np.quantile(mine, q) - np.quantile(theirs, q)) < (0.05 if mc else 0.03) * scale, q
     if name in DISCRETE:
         assert set(np.unique(mine)) == set(np.unique(theirs))
+        for v in np.unique(theirs):                                      # value frequencies (the weighted choice)
+            assert abs(np.mean(mine == v) - np.mean(theirs == v)) < 0.01
     if kind in (philox.TRIANGULAR, philox.EXPONENTIAL):
         assert mine.min() >= theirs.min() - 1e-3 * scale and mine.max() <= max(theirs.max(), p[2] if kind == philox.TRIANGULAR else np.inf)
 
@@ -112,19 +139,29 @@ RAND_3D_MORE = {'init_x': {'distrib': 'rayleigh', 'scale': 0.2}, 'init_x_dot': {
                 'init_q': {'distrib': 'random_sample'}}
 
 
+# the kinds added in round 4: bounded-iteration rejection samplers on Philox blocks of their own, and the weighted choice
+RAND_3D_R4 = {'init_x': {'distrib': 'gamma', 'shape': 2.5, 'scale': 0.1}, 'init_x_dot': {'distrib': 'beta', 'a': 2.0, 'b': 5.0},
+              'init_y': {'distrib': 'gamma', 'args': [0.6], 'scale': 0.2}, 'init_y_dot': {'distrib': 'chisquare', 'df': 3.0},
+              'init_z': {'distrib': 'beta', 'args': [0.5, 0.5]}, 'init_z_dot': {'distrib': 'standard_gamma', 'shape': 7.0},
+              'init_phi': {'distrib': 'choice', 'a': [-0.1, 0.0, 0.25], 'p': [0.2, 0.5, 0.3]},
+              'init_theta': {'distrib': 'choice', 'args': [[0.05, -0.05]], 'p': [0.9, 0.1]},
+              'init_psi': {'distrib': 'choice', 'args': [3], 'p': [0.1, 0.1, 0.8]}, 'init_p': {'distrib': 'normal', 'scale': 0.01}}
+RAND_SETS = {'round2_kinds': RAND_3D, 'round3_kinds': RAND_3D_MORE, 'round4_kinds': RAND_3D_R4}
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize('which', ['round2_kinds', 'round3_kinds'])
+@pytest.mark.parametrize('which', ['round2_kinds', 'round3_kinds', 'round4_kinds'])
 def test_device_draws_equal_the_oracle_for_every_distribution(gpu, which):
     """Same Philox counters, same transforms: the kernel's reset states (scg_reset and the fused auto-reset) equal the
     oracle's per env, for all kinds mixed in one env; then teacher-forced step parity through several auto-resets."""
     n = 200
     kw = dict(task='traj_tracking', cost='quadratic', ctrl_freq=60, pyb_freq=240, episode_len_sec=0.2,
-              init_state_randomization_info=RAND_3D if which == 'round2_kinds' else RAND_3D_MORE, done_on_out_of_bound=which == 'round2_kinds')
+              init_state_randomization_info=RAND_SETS[which], done_on_out_of_bound=which == 'round2_kinds')
     env, ref, sampler = make_pair(3, n, randomized_init=True, **kw)
     obs_e, obs_r = sync_reset(env, ref, sampler)
     assert rel_err(obs_e.cpu().numpy(), obs_r) <= (2e-6 if which == 'round2_kinds' else 5e-6)     # (powf / expf are ~2 ulp)
     assert np.abs(obs_r[:, 8] - np.round(obs_r[:, 8])).max() == 0.0          # randint dims hold integers
-    if which == 'round3_kinds':
+    if which != 'round2_kinds':
         assert set(np.unique(np.round(obs_r[:, 6], 6))) <= {-0.1, 0.0, 0.25} and set(np.unique(np.round(obs_r[:, 7], 6))) == {-0.05, 0.05}
     rng = np.random.default_rng(5)
     lo, hi = env.action_space.low, env.action_space.high
@@ -191,4 +228,39 @@ def test_device_draw_statistics_and_inertial_distributions(gpu):
     with pytest.raises(ValueError, match='negative'):
         scg.make('quadrotor', quad_type=3, num_envs=8, device='cuda', randomized_inertial_prop=True, task='traj_tracking',
                  inertial_prop_randomization_info={'M': {'distrib': 'triangular', 'left': -0.05, 'mode': 0.0, 'right': 0.01}}).reset()
+    env.close()
+
+
+@pytest.mark.gpu
+def test_device_rejection_samplers_and_weighted_choice_statistics(gpu):
+    """2^17 envs: gamma / beta / chisquare moments and the weighted choice's frequencies on the device; a randomised inertial
+    property drawn from a gamma distribution equals the oracle's draw per env."""
+    import safe_control_gym_amd as scg
+    n = 1 << 17
+    env = scg.make('quadrotor', quad_type=3, num_envs=n, device='cuda', seed=21, task='traj_tracking', randomized_init=True,
+                   init_state_randomization_info=RAND_3D_R4, done_on_out_of_bound=False)
+    x = env.reset().double().cpu().numpy()
+    assert abs(x[:, 0].mean() - 0.25) < 2e-3 and abs(x[:, 0].var() - 2.5 * 0.01) < 1e-3 and x[:, 0].min() > 0.0      # gamma(2.5, 0.1)
+    assert abs(x[:, 1].mean() - 2.0 / 7.0) < 2e-3 and abs(x[:, 1].var() - 10.0 / (49.0 * 8.0)) < 5e-4                 # beta(2, 5)
+    assert abs(x[:, 2].mean() - 0.12) < 3e-3 and abs(x[:, 2].var() - 0.6 * 0.04) < 2e-3                              # gamma(0.6, 0.2): the boost
+    assert abs(x[:, 3].mean() - 3.0) < 0.03 and abs(x[:, 3].var() - 6.0) < 0.25                                      # chisquare(3)
+    assert abs(x[:, 4].mean() - 0.5) < 4e-3 and abs(x[:, 4].var() - 0.125) < 3e-3 and 0.0 <= x[:, 4].min() and x[:, 4].max() <= 1.0   # beta(1/2, 1/2)
+    assert abs(x[:, 5].mean() - 7.0) < 0.03 and abs(x[:, 5].var() - 7.0) < 0.2                                       # standard_gamma(7)
+    for vals, probs, col in (((-0.1, 0.0, 0.25), (0.2, 0.5, 0.3), 6), ((0.05, -0.05), (0.9, 0.1), 7), ((0.0, 1.0, 2.0), (0.1, 0.1, 0.8), 8)):
+        for v, pr in zip(vals, probs):
+            assert abs(np.mean(np.abs(x[:, col] - v) < 1e-6) - pr) < 0.01, (col, v)
+    assert abs(np.corrcoef(x[:, 0], x[:, 2])[0, 1]) < 0.01 and abs(np.corrcoef(x[:, 1], x[:, 4])[0, 1]) < 0.01       # streams of their own
+    env.close()
+    # a gamma-distributed mass offset (bounded below by 0: accepted by the positivity check) against the oracle's draws
+    info = {'M': {'distrib': 'gamma', 'shape': 2.0, 'scale': 0.002}, 'Ixx': {'distrib': 'beta', 'a': 2.0, 'b': 2.0}}
+    env = scg.make('quadrotor', quad_type=3, num_envs=512, device='cuda', seed=5, task='traj_tracking', randomized_inertial_prop=True,
+                   inertial_prop_randomization_info={'M': info['M'], 'Ixx': {'distrib': 'choice', 'a': [0.0, 1e-6], 'p': [0.75, 0.25]}})
+    env.reset()
+    got = env.inertial_properties.double().cpu().numpy()
+    kinds = np.array([philox.GAMMA, philox.CHOICE_P, philox.UNIFORM, philox.UNIFORM])
+    params = np.array([[2.0, 0.002, 0.0], [0.0, 1e-6, 1e-6], [0, 0, 0], [0, 0, 0]], dtype=np.float64)
+    low, high = np.array([0.0, 0.75, 0.0, 0.0]), np.array([0.0, 1.0, 0.0, 0.0])
+    nominal = np.array([0.03454, 1.4e-5, 1.4e-5, 2.17e-5])
+    want = np.stack([nominal + philox.inertial_offsets(5, i, 0, low, high, kinds, params) for i in range(512)])
+    assert np.abs(got - want).max() / nominal.max() < 1e-5 and np.abs(got[:, 1] - want[:, 1]).max() < 1e-9
     env.close()

@@ -25,7 +25,7 @@ first)
   echo "== driver's command"; timeout -k 10 600 python bench.py --gpus 1 --steps 20 --warmup 5 > "$out/bench_driver_cmd.json" 2> "$out/bench_driver_cmd.err"; tail -c 600 "$out/bench_driver_cmd.json"
   ;;
 second)
-  echo "== new GPU tests"; timeout -k 10 900 python -m pytest tests/test_pipelines_gpu.py tests/test_gae.py -m gpu -q -x > "$out/gpu_tests_new.log" 2>&1; tail -15 "$out/gpu_tests_new.log"
+  echo "== new GPU tests"; timeout -k 10 900 python -m pytest tests/test_pipelines_gpu.py tests/test_gae.py tests/test_randomization.py -m gpu -q -x > "$out/gpu_tests_new.log" 2>&1; tail -15 "$out/gpu_tests_new.log"
   echo "== driver's command"; timeout -k 10 900 python bench.py --gpus 1 --steps 20 --warmup 5 > "$out/bench_driver_cmd.json" 2> "$out/bench_driver_cmd.err"; tail -5 "$out/bench_driver_cmd.err"
   python - "$out/bench_driver_cmd.json" <<'PY'
 import json, sys
