@@ -43,6 +43,10 @@ PY
     tail -3 "$out/bench_$t.txt"; rm -rf "$d"
   done
   ;;
+suite)
+  echo "== GPU suite"; timeout -k 10 1500 python -m pytest tests -m gpu -q > "$out/gpu_tests.log" 2>&1; grep -E "^(FAILED|ERROR)|passed|failed" "$out/gpu_tests.log" | tail -15
+  echo "== smoke"; timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+  ;;
 probe)
   timeout -k 10 900 python tools/step_api_probe.py "$@" 2>&1 | tee "$out/step_api_probe.txt"
   ;;
