@@ -179,7 +179,8 @@ def test_competition_cost_is_refused(gpu):
 @pytest.mark.parametrize('seed', range(int(os.environ.get('SCG_FUZZ_SEEDS', '96')) // 2))
 def test_random_configuration_rollout_equals_step_loop(gpu, seed):
     """For the same random configurations: K step() calls == scg_rollout (two launch queues forced at this size) ==
-    scg_rollout_fused (where the configuration admits it; others fall back to scg_rollout), bit for bit."""
+    scg_rollout_fused (where the configuration admits it; others fall back to scg_rollout), bit for bit; and (round 4) == the rows
+    of a trajectory sink filled by either form == three pipelined shards stepped through step_async / step_wait."""
     import torch
     import safe_control_gym_amd as scg
     rng = np.random.default_rng(9000 + seed)
@@ -195,12 +196,50 @@ def test_random_configuration_rollout_equals_step_loop(gpu, seed):
     lo = torch.as_tensor(a.action_space.low, device='cuda')[None, :, None]
     hi = torch.as_tensor(a.action_space.high, device='cuda')[None, :, None]
     acts = torch.rand((5, a.action_dim, ld), generator=g, device='cuda') * (hi - lo) * 1.1 + lo - 0.05 * (hi - lo)
+    # round 4: the same K steps through a trajectory sink (per-step launches on two queues; the fused form where admitted) and
+    # through three pipelined shards (make_vec_envs(num_pipelines=3): step_async / step_wait per shard, ragged shard sizes)
+    from functools import partial
+    from safe_control_gym_amd.envs.env_wrappers.vectorized_env import make_vec_envs
+    d, e = mk(), mk()
+    d.reset(), e.reset()
+    name = 'cartpole' if system == 'cartpole' else 'quadrotor'
+    skw = dict(kw, **engine) if system == 'cartpole' else dict(kw, quad_type=system, **engine)
+    venv = make_vec_envs(partial(scg.make, name, device='cuda', randomized_init=True, **skw), batch_size=n, seed=5, num_pipelines=3)
+    venv.reset()
+    want_info = a.INFO_LEVEL == 'full'
+    td, te = d.trajectory_buffer(K, info=want_info), e.trajectory_buffer(K, info=want_info)
+    per_step = []
+    label = 'system %s n %d %s %s' % (system, n, kw, engine)
+
+    def same(x, y, what):
+        assert torch.equal(x.nan_to_num(), y.nan_to_num()) and torch.equal(torch.isnan(x), torch.isnan(y)), '%s | %s' % (what, label)
     for k in range(K):
-        a.step(acts[k % 5])
+        o, r, dn, info = a.step(acts[k % 5])
+        per_step.append((o.clone(), r.clone(), dn.clone(), {q: info[q].clone() for q in ('mse', 'TimeLimit.truncated', 'constraint_values',
+                                                                                       'constraint_violation') if q in info}))
+        vo, vr, vd, _ = venv.step(acts[k % 5][:, :n].T.contiguous())
+        same(vo, o, 'pipelined shards: obs at step %d' % k); same(vr, r, 'pipelined shards: reward at step %d' % k)
+        assert torch.equal(vd, dn), 'pipelined shards: done at step %d | %s' % (k, label)
     b.rollout(acts, steps=K)
     c.rollout(acts, steps=K, fused=True)
+    d.rollout(acts, steps=K, out=td)
+    e.rollout(acts, steps=K, fused=True, out=te)
     torch.cuda.synchronize()
-    label = 'system %s n %d %s %s' % (system, n, kw, engine)
+    for traj, form in ((td, 'sink'), (te, 'fused sink')):
+        for k, (o, r, dn, info) in enumerate(per_step):
+            same(traj.obs[k], o, '%s: obs at step %d' % (form, k)); same(traj.reward[k], r, '%s: reward at step %d' % (form, k))
+            assert torch.equal(traj.done[k], dn), '%s: done at step %d | %s' % (form, k, label)
+            if 'constraint_values' in info:
+                same(traj.constraint_values[k], info['constraint_values'], '%s: constraint values at step %d' % (form, k))
+                assert torch.equal(traj.constraint_violation[k], info['constraint_violation'].bool()), '%s: violation at step %d | %s' % (form, k, label)
+            if want_info:
+                same(traj.mse[k], info['mse'], '%s: mse at step %d' % (form, k))
+                assert torch.equal(traj.truncated[k], info['TimeLimit.truncated']), '%s: truncated at step %d | %s' % (form, k, label)
+    for other, oname in ((d, 'sink'), (e, 'fused sink')):
+        for key in ('state', 'state_lo', 'step_count', 'ep_return', 'inertial', 'episode_id'):
+            if key in a._bufs:
+                same(a._bufs[key][..., :n].float(), other._bufs[key][..., :n].float(), '%s: %s' % (oname, key))
+    venv.close(), d.close(), e.close()
     for other, name in ((b, 'rollout'), (c, 'fused')):
         for key in ('state', 'state_lo', 'step_count', 'ep_return', 'inertial', 'episode_id'):
             if key in a._bufs:

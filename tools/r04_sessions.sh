@@ -43,6 +43,12 @@ PY
     tail -3 "$out/bench_$t.txt"; rm -rf "$d"
   done
   ;;
+fuzz)
+  echo "== configuration fuzz (rollout / sink / pipelines == step loop)"; timeout -k 10 1100 python -m pytest tests/test_config_fuzz_gpu.py tests/test_examples_gpu.py -m gpu -q -x -k "rollout_equals or example" > "$out/gpu_fuzz.log" 2>&1; tail -12 "$out/gpu_fuzz.log"
+  for args in "16384 128 pushed" "16384 128 planes" "262144 128 pushed" "262144 128 planes" "1048576 64 pushed" "1048576 64 planes"; do
+    timeout -k 10 300 python examples/ppo_rollout.py $args 2>&1 | grep "env-steps/s" | tee -a "$out/ppo_rollout_example.txt"
+  done
+  ;;
 suite)
   echo "== GPU suite"; timeout -k 10 1500 python -m pytest tests -m gpu -q > "$out/gpu_tests.log" 2>&1; grep -E "^(FAILED|ERROR)|passed|failed" "$out/gpu_tests.log" | tail -15
   echo "== smoke"; timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
