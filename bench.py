@@ -75,6 +75,9 @@ def parse_args(argv=None):
     ap.add_argument('--queues', type=int, default=0, help='scg_config.rollout_queues: 0 library default (2), 1, 2')
     ap.add_argument('--python-loop', action='store_true', help='also time env.step() called from Python per step')
     ap.add_argument('--fused', action='store_true', help='also time the one-launch multi-step rollout (own byte count)')
+    ap.add_argument('--trajectory-sink', type=int, default=0, metavar='ROWS',
+                    help='the timed rollouts write every step\'s observation / reward / done into a trajectory buffer of ROWS steps '
+                         '(scg_rollout_trajectory, per-step launches; chunks of ROWS steps): for traffic counters of that form')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-sub-records', '--no-bare', dest='no_sub', action='store_true',
                     help='skip the secondary measurements (bare C4 step, precise mode, C3, C2)')
@@ -684,15 +687,19 @@ def run_rank(args):
     actions = make_actions(env, rank, args.action_period, dev)
     env.reset()
 
+    traj = env.trajectory_buffer(args.trajectory_sink) if args.trajectory_sink > 0 else None
+
     def run(steps):
         done_steps = 0
         while done_steps < steps:
             chunk = min(GATHER_EVERY, steps - done_steps) if multi else steps - done_steps
+            if traj is not None:
+                chunk = min(chunk, args.trajectory_sink)
             # the exchange of the path: the returns as of this chunk's start travel over xGMI on RCCL's stream
             # while the chunk's step kernels run; the region ends only after the gather has landed (wait + the closing fence)
             pending = parallel.begin_all_gather_episode_returns(env.episode_return, total_envs=n * world,
                                                                 force_collective=forced) if multi else None
-            env.rollout(actions, steps=chunk)
+            env.rollout(actions, steps=chunk, out=traj)
             done_steps += chunk
             if pending is not None:
                 pending.wait()
@@ -774,6 +781,7 @@ def run_rank(args):
                                   'pass over the whole batch') if two_queues else
                                  'one fused scg_step kernel per step (scg_rollout issues the launches)',
                        'launches_per_step': 2 if two_queues else 1,
+                       'trajectory_sink_rows': args.trajectory_sink,
                        'sharding': 'envs block-sharded by global index; all-gather of episode returns (RCCL, asynchronous, overlapping the step '
                                    'kernels) at least every %d steps and once per timed region' % GATHER_EVERY if world > 1 else 'single GPU'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -332,13 +332,20 @@ class BenchmarkEnv:
     def state_dict(self):
         """Everything a resumed run needs to continue bit for bit: the device planes that persist across steps, the
         position of the Philox streams (seed, step serial) and the per-env nominal reset states.  ``torch.save``-able."""
+        self._refuse_while_pending('state_dict()')
         self._ensure_engine()
         return {'num_envs': self.num_envs, 'plane_stride': self._ld, 'seed': self._seed, 'serial': self._serial,
                 'initial_reset': self.initial_reset,
                 'planes': {k: self._bufs[k].clone() for k in self._CHECKPOINT_PLANES if k in self._bufs},
                 'reset_state': None if self._reset_state_buf is None else self._reset_state_buf.clone()}
 
+    def _refuse_while_pending(self, what):
+        """A step issued by step_async() runs on the env's own queue until step_wait() joins it: nothing else may touch the planes."""
+        if self._async_outs is not None:
+            raise RuntimeError('[ERROR] %s while a step_async() is pending: call step_wait() first.' % what)
+
     def load_state_dict(self, sd):
+        self._refuse_while_pending('load_state_dict()')
         if sd['num_envs'] != self.num_envs:
             raise ValueError('[ERROR] checkpoint holds %d envs, this env has %d.' % (sd['num_envs'], self.num_envs))
         if sd['seed'] != self._seed:
@@ -886,8 +893,7 @@ class BenchmarkEnv:
         with ``fused=True`` the envs stay in registers and only the outputs stream out).  The sunk outputs are not written to
         the env's own per-step buffers."""
         self._check_initial_reset()
-        if self._async_outs is not None:
-            raise RuntimeError('[ERROR] rollout() while a step_async() is pending: call step_wait() first.')
+        self._refuse_while_pending('rollout()')
         if self.adversary_disturbance is not None:
             raise RuntimeError('[ERROR] rollout() cannot take per-step adversary actions; use step().')
         if not (isinstance(actions, torch.Tensor) and actions.dtype == torch.float32 and actions.is_contiguous()
@@ -995,6 +1001,7 @@ class BenchmarkEnv:
         ``reseed_on_reset=True`` (benchmark_env.py:356-362, ``before_reset``: ``self.seed(self.RND_SEED)`` ahead of every reset) makes
         every reset draw the SAME initial states, inertial properties and disturbance streams: the Philox stream is rewound,
         the handle (same key) is kept."""
+        self._refuse_while_pending('reset()')
         if self.RESEED_ON_RESET:
             self.seed(self.RND_SEED)
         self._ensure_engine()
@@ -1090,8 +1097,7 @@ class BenchmarkEnv:
         tensors, the state buffer IS the observation handed out and the next step's input, and nothing writes it again
         (``_own_state``; writing ``env.state[...]`` yourself writes into the last observation).  Only an observation
         disturbance needs an obs buffer of its own.  The tensors inside ``info`` are always views of per-step buffers."""
-        if self._async_outs is not None:
-            raise RuntimeError('[ERROR] step() while a step_async() is pending: call step_wait() first.')
+        self._refuse_while_pending('step()')
         return self._step_outputs(self._step_launch(action, False, out))
 
     def step_async(self, action, out=None):
@@ -1103,8 +1109,7 @@ class BenchmarkEnv:
         num_pipelines=2)``) thereby overlaps its kernel's ramp-up / drain, and its policy, with the other shard's kernel.
         Call both from the same current stream; ``pipeline_stream`` is the queue itself, for callers that run a shard's policy
         on it (then neither call adds an event)."""
-        if self._async_outs is not None:
-            raise RuntimeError('[ERROR] step_async() while another step_async() is pending: call step_wait() first.')
+        self._refuse_while_pending('step_async()')
         self._async_outs = self._step_launch(action, True, out)
 
     def step_wait(self):
@@ -1243,7 +1248,9 @@ class BenchmarkEnv:
         if outs is not None:
             src = new_state if new_state is not None else outs[0]
             obs = (src if src is not None else (b['obs'] if 'obs' in b else b['state']))[:, :self.num_envs].T
-            rew, done = outs[1][:self.num_envs], outs[2][:self.num_envs]
+            rew, done = outs[1], outs[2]
+            if rew.shape[0] != self.num_envs or done.shape[0] != self.num_envs:     # a caller's wider rows (step(out=...))
+                rew, done = rew[:self.num_envs], done[:self.num_envs]
         else:
             if self._out_views is None:
                 self._out_views = ((b['obs'] if 'obs' in b else b['state'])[:, :self.num_envs].T, b['reward'][:self.num_envs],

@@ -133,6 +133,9 @@ def test_step_async_protocol_errors(gpu):
         env.step_async(a)
     with pytest.raises(RuntimeError, match='pending'):
         env.rollout(torch.zeros((1, 2, env.plane_stride), device='cuda'))
+    for call in (env.reset, env.state_dict, lambda: env.load_state_dict({})):
+        with pytest.raises(RuntimeError, match='pending'):
+            call()
     o, r, d, info = env.step_wait()
     twin = scg.make('quadrotor', quad_type=2, num_envs=256, **_common({}))
     twin.reset()
@@ -282,3 +285,63 @@ def test_calls_on_the_handles_device_pass_the_device_guard(gpu):
     q = eng.queue_stream()
     assert q.cuda_stream != 0 and eng.queue_stream() is q
     env.close()
+
+
+def test_pipelined_loop_is_capturable_in_a_hip_graph(gpu):
+    """The event fork / join of step_async / step_wait and the launches on the shards' queues are capturable: K steps of the
+    pipelined loop (policy kernels included) recorded once with torch.cuda.graph and replayed equal K eager steps of the plain env.
+    (The step serials are baked into the nodes: a SECOND replay would repeat the first one's reset draws -- scg_rollout's own
+    graph replay passes the serial through a device word for that reason.)"""
+    kw = _common(dict(quad_type=3, task='traj_tracking', cost='quadratic', info_level='minimal'))
+    n, warm, K = 2048, 3, 70                         # 60-step episodes: auto-resets inside the captured stretch
+    plain = scg.make('quadrotor', num_envs=n, **kw)
+    venv = make_vec_envs(partial(scg.make, 'quadrotor', **kw), batch_size=n, num_pipelines=2)
+    envs = venv.envs
+    lo = torch.as_tensor(plain.action_space.low, device='cuda').reshape(-1, 1)
+    hi = torch.as_tensor(plain.action_space.high, device='cuda').reshape(-1, 1)
+    bias, gain = 0.5 * (lo + hi), 0.1 * (hi - lo)
+    acts = [torch.zeros((4, e.plane_stride), device='cuda') for e in envs]          # the policy's output planes, one buffer per shard
+    act_plain = torch.zeros((4, plain.plane_stride), device='cuda')
+
+    def policy(obs, out, m):                                                        # capture-safe: no allocation, no host sync
+        torch.addcmul(bias, obs.T[:4], gain, out=out[:, :m])
+        return out
+    obs = plain.reset()
+    pobs = [e.reset() for e in envs]
+
+    def pipelined(steps, on_queue):
+        cur = torch.cuda.current_stream()
+        qs = [e.pipeline_stream if on_queue else cur for e in envs]
+        for q in qs:
+            q.wait_stream(cur)
+        for _ in range(steps):
+            for p, e in enumerate(envs):
+                with torch.cuda.stream(qs[p]):
+                    e.step_async(policy(pobs[p], acts[p], e.num_envs))
+            for p, e in enumerate(envs):
+                with torch.cuda.stream(qs[p]):
+                    pobs[p] = e.step_wait()[0]
+        for q in qs:
+            cur.wait_stream(q)
+    for on_queue in (False, True):
+        for _ in range(warm):
+            obs = plain.step(policy(obs, act_plain, n))[0]
+        pipelined(warm, on_queue)                                                   # eager: queues and events exist before the capture
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                pipelined(K, on_queue)
+        torch.cuda.current_stream().wait_stream(side)
+        graph.replay()
+        for _ in range(K):
+            obs = plain.step(policy(obs, act_plain, n))[0]
+        torch.cuda.synchronize()
+        _same(torch.cat([e.state for e in envs]), plain.state, 'state after the replay (on_queue=%s)' % on_queue)
+        _same(torch.cat([e.ctrl_step_counter for e in envs]), plain.ctrl_step_counter, 'step counters after the replay')
+        _same(torch.cat([e.episode_return for e in envs]), plain.episode_return, 'episode returns after the replay')
+        assert int(plain.ctrl_step_counter.max()) < K                                # every env was auto-reset inside the captured stretch
+        del graph
+    venv.close(); plain.close()

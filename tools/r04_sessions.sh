@@ -49,6 +49,14 @@ fuzz)
     timeout -k 10 300 python examples/ppo_rollout.py $args 2>&1 | grep "env-steps/s" | tee -a "$out/ppo_rollout_example.txt"
   done
   ;;
+close)
+  # the closing session: whole GPU suite, the canonical evidence of the round (tools/round_measure.sh), traffic counters of the
+  # trajectory-sink rollout, smoke()
+  echo "== GPU suite"; timeout -k 10 1500 python -m pytest tests -m gpu -q > "$out/gpu_tests.log" 2>&1; grep -E "^(FAILED|ERROR)|passed|failed" "$out/gpu_tests.log" | tail -15
+  timeout -k 10 1500 bash tools/round_measure.sh "r04/$tag" 2>&1 | cut -c1-600
+  echo "== pmc, trajectory-sink rollout, bare C4 step (traffic counters)"; PMC_TRAFFIC_ONLY=1 profiles/pmc.sh "$out/pmc_sink" --no-episode-stats --trajectory-sink 60 > "$out/pmc_summary_bare_trajectory_sink.txt" 2>&1; cat "$out/pmc_summary_bare_trajectory_sink.txt"; rm -rf "$out"/pmc_sink/pass*
+  echo "== smoke"; timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+  ;;
 suite)
   echo "== GPU suite"; timeout -k 10 1500 python -m pytest tests -m gpu -q > "$out/gpu_tests.log" 2>&1; grep -E "^(FAILED|ERROR)|passed|failed" "$out/gpu_tests.log" | tail -15
   echo "== smoke"; timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
