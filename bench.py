@@ -423,6 +423,28 @@ def step_api_record(args, n, steps):
         venv.close()
         return us
 
+    def captured(kw, m, block=50):
+        """The plain loop recorded once (capture_loop: policy kernel + step kernel x `block`, the step serial through a device word) and
+        replayed: no host in the loop."""
+        from safe_control_gym_amd.envs.graph_loop import capture_loop
+        env = scg.make('quadrotor', num_envs=m, **kw)
+        pol = _AffinePolicy(env)
+        obs = env.reset()
+        loop = capture_loop(env, lambda k: env.step(pol(obs)), block, warmup=2)
+
+        def run(k):
+            for _ in range(max(1, k // block)):
+                loop.replay()
+        run(block)
+        torch.cuda.synchronize()
+        reps = max(1, steps // block)
+        t0 = time.perf_counter()
+        run(reps * block)
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) / (reps * block) * 1e6
+        env.close()
+        return us
+
     rec = {'workload': 'C4 (Quadrotor-3D tracking, 2^20 envs) stepped from Python with a device-side affine policy between the steps',
            'envs': n, 'steps': steps, 'unit': 'us per step of the whole batch, host clock',
            'policy': 'act = mid + gain * obs[:nu]: one elementwise kernel, 32 B per env-step of its own'}
@@ -433,11 +455,31 @@ def step_api_record(args, n, steps):
         t['pipelined_env_steps_per_s'] = n / (best * 1e-6)
         rec[tier] = t
         torch.cuda.empty_cache()
+    lean = dict(base, info_level='minimal')
+    rec['lean']['plain_replayed_from_a_hip_graph'] = captured(lean, n)
+    small = {}
+    for e in (12, 16):
+        m = 1 << e
+        env = scg.make('quadrotor', num_envs=m, **lean)
+        pol = _AffinePolicy(env)
+        box = [env.reset()]
+
+        def loop(k, env=env, pol=pol, box=box):
+            obs = box[0]
+            for _ in range(k):
+                obs = env.step(pol(obs))[0]
+            box[0] = obs
+        eager = timed(loop)
+        env.close()
+        small['2^%d' % e] = {'plain': eager, 'plain_replayed_from_a_hip_graph': captured(lean, m)}
+    rec['lean_small_batches'] = small
     rec['note'] = ('step_only = env.step() with a fixed action tensor (no policy kernel); plain = policy(obs) -> env.step(act), one dependent '
                    'chain; pipelined_P = make_vec_envs(num_pipelines=P): P shards, per shard step_wait -> policy -> step_async on the shard\'s own '
                    'queue.  Each shard is still a dependent chain policy -> step -> policy with ~3 us between dependent kernels, so two shards '
                    'overlap one chain\'s gaps and policy with the other\'s step kernel but do not reach the two-queue rollout\'s rate, where a '
-                   'queue carries step kernels only (profiles/r04/step_api_timeline.txt)')
+                   'queue carries step kernels only (profiles/r04/step_api_timeline.txt); plain_replayed_from_a_hip_graph = the plain loop recorded once by '
+                   'capture_loop() (50 steps per replay, results bit-identical to eager stepping): it takes the host out of the loop, which is what '
+                   'bounds the small batches (lean_small_batches), not 2^20 envs')
     return rec
 
 

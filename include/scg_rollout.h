@@ -261,6 +261,14 @@ typedef struct scg_step_io {
                                         with the residuals as int16 planes ((int16_t*)state_lo, [6][ld], 2-byte aligned): state =
                                         hi + lo 2^(e - 40) where hi = f 2^e, f in [1/2, 1), i.e. lo counts 2^-16 ulp(hi) -- 40
                                         significant bits, 24 B per env-step less again */
+    const uint32_t* serial_word;     /* nullable DEVICE word added to reset_serial by the kernel.  For callers that record their own
+                                        step loop in a HIP graph (policy kernels + scg_step launches, torch.cuda.graph): the launch
+                                        parameters are baked into the graph's nodes, so a replay would repeat the serials -- and with
+                                        them the reset draws and disturbance noise -- of the recording.  With serial_word the nodes
+                                        carry only the OFFSET of each step (reset_serial = 0, 1, ... K - 1) and the caller writes the
+                                        loop's current base serial into the word before every replay: results equal eager stepping
+                                        bit for bit.  (scg_rollout's own small-batch graph replay does this internally and is not
+                                        taken when the caller passes a word of its own.) */
 } scg_step_io;
 
 /* One entry of a DisturbanceList (envs/disturbances.py:46-84), evaluated inside the step kernel.

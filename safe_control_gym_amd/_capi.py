@@ -93,6 +93,7 @@ class ScgStepIO(C.Structure):
         ('constraint_violation', _fp), ('truncated', _fp), ('goal_reached', _fp), ('mse', _fp),
         ('terminal_record', _fp), ('terminal_stride', C.c_int64), ('stats', _fp),
         ('reset_serial', C.c_uint32), ('state_lo_kind', C.c_uint32),
+        ('serial_word', _fp),
     ]
 
 

@@ -735,6 +735,7 @@ int scg_step(scg_handle* h, const scg_step_io* io, int64_t n, void* stream) {
     if (int rc = join_async(h, (hipStream_t)stream, "scg_step")) return rc;
     KParams kp = h->kp;
     if (h->cfg.lone_launch_forms >= 0) kp.flags |= F_LONE;      // a single dependent launch: the forms that are faster alone
+    if (io->serial_word) { kp.serial_base = io->serial_word; kp.flags |= F_SERIAL_WORD; }
     HIP_TRY(launch_step(h->system, kp, *io, h->d_tb, h->d_con, h->d_ref, n, h->num_cus, (hipStream_t)stream));
     return SCG_OK;
 }
@@ -751,6 +752,7 @@ int scg_step_async(scg_handle* h, const scg_step_io* io, int64_t n, void* stream
     }
     KParams kp = h->kp;
     if (h->cfg.lone_launch_forms >= 0) kp.flags |= F_LONE;
+    if (io->serial_word) { kp.serial_base = io->serial_word; kp.flags |= F_SERIAL_WORD; }
     HIP_TRY(launch_step(h->system, kp, *io, h->d_tb, h->d_con, h->d_ref, n, h->num_cus, q));
     h->async_pending = true;
     return SCG_OK;
@@ -931,7 +933,9 @@ static int rollout_launches(scg_handle* h, const scg_step_io* io, const scg_traj
         hipStream_t s0 = (hipStream_t)stream, s1 = h->aux_stream;
         HIP_TRY(hipEventRecord(h->ev_fork, s0));                            // nothing runs on s1 yet: plain returns are safe
         HIP_TRY(hipStreamWaitEvent(s1, h->ev_fork, 0));
-        KParams kb = h->kp;
+        KParams ka = h->kp;
+        if (io->serial_word) { ka.serial_base = io->serial_word; ka.flags |= F_SERIAL_WORD; }
+        KParams kb = ka;
         kb.env_base += half;                                               // Philox streams follow the global env index
         // From here on s1 may hold work on the caller's buffers: whatever fails, s1 is joined back into s0 before this
         // call returns, so the caller never sees an un-joined queue running against its tensors.
@@ -942,7 +946,7 @@ static int rollout_launches(scg_handle* h, const scg_step_io* io, const scg_traj
             a.action = io->action + (int64_t)(k % action_period) * action_stride;
             a.reset_serial = io->reset_serial + (uint32_t)k;
             const scg_step_io b = shifted_io(a, half);
-            err = launch_step(h->system, h->kp, a, h->d_tb, h->d_con, h->d_ref, half, h->num_cus, s0);
+            err = launch_step(h->system, ka, a, h->d_tb, h->d_con, h->d_ref, half, h->num_cus, s0);
             what = "launch_step (first half)";
             if (err != hipSuccess) break;
             err = launch_step(h->system, kb, b, h->d_tb, h->d_con, h->d_ref, n - half, h->num_cus, s1);
@@ -962,12 +966,13 @@ static int rollout_launches(scg_handle* h, const scg_step_io* io, const scg_traj
     // (buffers, n, steps, action layout) seen twice in a row is captured into a hipGraph once and replayed from then on
     // (measured at the BASELINE sizes: CartPole 2^16 4.96 -> 4.30, Quadrotor-2D 2^18 8.48 -> 7.85 us per step).  Not with a
     // sink: its launch-free form is the fused one.
-    if (!sink && n > 0 && steps >= kGraphMinSteps && h->cfg.rollout_graph >= 0 && !h->graph_broken) {
+    if (!sink && !io->serial_word && n > 0 && steps >= kGraphMinSteps && h->cfg.rollout_graph >= 0 && !h->graph_broken) {
         const int rc = rollout_by_graph(h, io, n, steps, action_stride, action_period, (hipStream_t)stream);
         if (rc != kGraphNotTaken) return rc;
     }
     KParams kp1 = h->kp;
     if (h->cfg.lone_launch_forms > 0) kp1.flags |= F_LONE;               // single-queue launches are dependent: each runs alone
+    if (io->serial_word) { kp1.serial_base = io->serial_word; kp1.flags |= F_SERIAL_WORD; }
     for (int32_t k = 0; k < steps; ++k) {
         scg_step_io local = sunk_io(*io, sink, k);
         local.action = io->action + (int64_t)(k % action_period) * action_stride;
@@ -1030,7 +1035,9 @@ int scg_rollout_trajectory(scg_handle* h, const scg_step_io* io, const scg_traje
         RolloutArgs ro{steps, action_period, action_stride, sink->obs, sink->obs_step_stride, sink->reward, sink->reward_step_stride,
                        sink->done, sink->done_step_stride, sink->constraint_values, sink->constraint_values_step_stride,
                        sink->constraint_violation, sink->constraint_violation_step_stride};
-        HIP_TRY(launch_rollout_fused(h->system, h->kp, *io, h->d_tb, h->d_con, h->d_ref, n, ro, h->num_cus, (hipStream_t)stream));
+        KParams kp = h->kp;
+        if (io->serial_word) { kp.serial_base = io->serial_word; kp.flags |= F_SERIAL_WORD; }
+        HIP_TRY(launch_rollout_fused(h->system, kp, *io, h->d_tb, h->d_con, h->d_ref, n, ro, h->num_cus, (hipStream_t)stream));
         return SCG_OK;
     }
     if (int rc = rollout_launches(h, io, sink, n, steps, action_stride, action_period, stream, who)) return rc;
@@ -1052,7 +1059,9 @@ int scg_rollout_fused(scg_handle* h, const scg_step_io* io, int64_t n, int32_t s
     RolloutArgs ro;
     std::memset(&ro, 0, sizeof(ro));
     ro.steps = steps; ro.period = action_period; ro.stride = action_stride;
-    HIP_TRY(launch_rollout_fused(h->system, h->kp, *io, h->d_tb, h->d_con, h->d_ref, n, ro, h->num_cus, (hipStream_t)stream));
+    KParams kp = h->kp;
+    if (io->serial_word) { kp.serial_base = io->serial_word; kp.flags |= F_SERIAL_WORD; }
+    HIP_TRY(launch_rollout_fused(h->system, kp, *io, h->d_tb, h->d_con, h->d_ref, n, ro, h->num_cus, (hipStream_t)stream));
     return SCG_OK;
 }
 

@@ -298,6 +298,7 @@ class BenchmarkEnv:
         self._raw_action, self._raw_action_rows = None, False
         self._async_outs, self._inflight = None, None            # step_async() / step_wait()
         self._state_external, self._bound_dirty = False, False   # step(out=...) in views mode
+        self._capture_base, self._serial_word = None, None       # capture_loop(): the steps being recorded carry serial OFFSETS
         # output_ring=K >= 3 (fresh-output mode): step() cycles through K pre-allocated output sets instead of allocating one per
         # step -- a tensor handed out is then OVERWRITTEN K steps later (opt-in: it changes the ownership contract of step())
         self._output_ring = int(kwargs.get('output_ring', 0) or 0)
@@ -338,6 +339,37 @@ class BenchmarkEnv:
                 'initial_reset': self.initial_reset,
                 'planes': {k: self._bufs[k].clone() for k in self._CHECKPOINT_PLANES if k in self._bufs},
                 'reset_state': None if self._reset_state_buf is None else self._reset_state_buf.clone()}
+
+    # -- recording the caller's step loop in a HIP graph (envs/graph_loop.py::capture_loop) ---------------------------------------
+    def _begin_capture(self):
+        self._ensure_engine()
+        self._check_initial_reset()
+        self._refuse_while_pending('capture_loop()')
+        if self._fresh_outputs or (self.COPY_OUTPUTS and self.COMPENSATED_STATE):
+            raise ValueError('[ERROR] capture_loop() needs an env that steps in place (copy_outputs=False): a replayed graph writes the '
+                             'same buffers every time, fresh per-step output tensors cannot exist in it.')
+        if self.adversary_disturbance is not None:
+            raise ValueError('[ERROR] capture_loop(): per-step adversary planes are allocated on the host; not capturable.')
+        if self._serial_word is None:
+            self._serial_word = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._engine.set_serial_word(self._serial_word)
+        self._capture_base = self._serial
+
+    def _end_capture(self):
+        """-> the number of step serials the recorded stretch consumes per replay.  Nothing ran: the serial goes back."""
+        used = self._serial - self._capture_base
+        self._serial, self._capture_base = self._capture_base, None
+        self._engine.set_serial_word(None)
+        return used
+
+    def _before_replay(self):
+        v = self._serial & 0xffffffff
+        self._serial_word.fill_(v - (1 << 32) if v >= (1 << 31) else v)
+
+    def _launch_serial(self):
+        """The serial a launch carries: the env's running serial, or -- while a loop is being recorded -- its offset from the
+        serial the recording started at (the kernel adds the serial word, written before every replay)."""
+        return self._serial if self._capture_base is None else self._serial - self._capture_base
 
     def _refuse_while_pending(self, what):
         """A step issued by step_async() runs on the env's own queue until step_wait() joins it: nothing else may touch the planes."""
@@ -909,7 +941,7 @@ class BenchmarkEnv:
         self._own_state()
         io = dict(self._bufs)
         io['reset_state'] = self._reset_state_buf
-        self._engine.rollout(io, self.num_envs, self._ld, self._serial, steps, actions, fused=fused, sink=sink)
+        self._engine.rollout(io, self.num_envs, self._ld, self._launch_serial(), steps, actions, fused=fused, sink=sink)
         self._bound = False
         self._serial += steps
         k = (steps - 1) % actions.shape[0]
@@ -1002,6 +1034,8 @@ class BenchmarkEnv:
         every reset draw the SAME initial states, inertial properties and disturbance streams: the Philox stream is rewound,
         the handle (same key) is kept."""
         self._refuse_while_pending('reset()')
+        if self._capture_base is not None:
+            raise RuntimeError('[ERROR] reset() inside capture_loop(): record steps only (the envs auto-reset inside the step kernel).')
         if self.RESEED_ON_RESET:
             self.seed(self.RND_SEED)
         self._ensure_engine()
@@ -1222,7 +1256,7 @@ class BenchmarkEnv:
                 if 'obs' in b:
                     io['obs'] = new_state
             self._adversary_planes(io)
-            self._engine.step(io, self.num_envs, self._ld, self._serial, action_rows=rows, asynchronous=asynchronous)
+            self._engine.step(io, self.num_envs, self._ld, self._launch_serial(), action_rows=rows, asynchronous=asynchronous)
             self._bound = False
         else:
             if not self._bound:
@@ -1230,7 +1264,7 @@ class BenchmarkEnv:
                 io['reset_state'] = self._reset_state_buf
                 self._engine.bind_static(io, self._ld)
                 self._bound = True
-            self._engine.step_bound(act, self.num_envs, self._serial, action_rows=rows, outs=outs, state_out=new_state,
+            self._engine.step_bound(act, self.num_envs, self._launch_serial(), action_rows=rows, outs=outs, state_out=new_state,
                                     asynchronous=asynchronous)
         self._serial += 1
         self._handed_out = True

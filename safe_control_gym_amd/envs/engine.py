@@ -46,6 +46,12 @@ class Engine:
         self._io.struct_size = C.sizeof(_capi.ScgStepIO)
         self._io_ref = C.byref(self._io)
 
+    def set_serial_word(self, word):
+        """``scg_step_io.serial_word`` of every later step / rollout of this engine: a one-element int32 device tensor whose value
+        the kernels add to the step's serial (a caller's own HIP graph of the step loop), or None."""
+        self._serial_word = word
+        self._io.serial_word = None if word is None else word.data_ptr()
+
     def close(self):
         if getattr(self, 'handle', None):
             self.lib.scg_destroy(self.handle)

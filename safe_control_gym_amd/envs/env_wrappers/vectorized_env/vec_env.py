@@ -81,6 +81,12 @@ class DeviceVecEnv(VecEnv):
         out, self._pending = self._pending, None
         return out
 
+    def capture_loop(self, body, steps, warmup=2):
+        """``steps`` iterations of ``body(k)`` (policy kernels + this venv's step calls) recorded in one HIP graph: see
+        ``safe_control_gym_amd.envs.graph_loop.capture_loop``."""
+        from safe_control_gym_amd.envs.graph_loop import capture_loop
+        return capture_loop([self.env], body, steps, warmup)
+
     def close_extras(self):
         self.env.close()
 
@@ -189,6 +195,12 @@ class PipelinedDeviceVecEnv(VecEnv):
     def pipeline_stream(self, pipeline):
         """Shard ``pipeline``'s own launch queue as a torch stream (run its policy there and no event is needed)."""
         return self.envs[pipeline].pipeline_stream
+
+    def capture_loop(self, body, steps, warmup=2):
+        """``steps`` iterations of ``body(k)`` (policy kernels + this venv's step calls) recorded in one HIP graph: see
+        ``safe_control_gym_amd.envs.graph_loop.capture_loop``."""
+        from safe_control_gym_amd.envs.graph_loop import capture_loop
+        return capture_loop(self.envs, body, steps, warmup)
 
     def close_extras(self):
         for e in self.envs:

@@ -252,6 +252,19 @@ static void check_step_and_rollout() {
         r.io.state_lo = reinterpret_cast<float*>(reinterpret_cast<char*>(r.f.data()) + 1);
         EXPECT(scg_step(h, &r.io, 8, nullptr) == SCG_ERR_INVALID);
     }
+    // a caller's serial word (its own HIP graph of the step loop): forwarded to the kernel parameters; scg_rollout's internal graph
+    // replay stands back
+    {
+        Buffers w(4096);
+        uint32_t word = 0;
+        w.io.serial_word = &word;
+        shim_reset();
+        EXPECT(scg_step(h, &w.io, 4096, nullptr) == SCG_OK && g_shim.last_serial_base == &word);
+        EXPECT(scg_rollout(h, &w.io, 4096, 16, 16, 2, nullptr) == SCG_OK && scg_rollout(h, &w.io, 4096, 16, 16, 2, nullptr) == SCG_OK);
+        EXPECT(g_shim.graph_launches == 0 && g_shim.captured_nodes == 0 && g_shim.last_serial_base == &word);
+        w.io.serial_word = nullptr;
+        EXPECT(scg_step(h, &w.io, 4096, nullptr) == SCG_OK && g_shim.last_serial_base == nullptr);
+    }
     shim_reset();
     EXPECT(scg_rollout_fused(h, &b.io, 1000, 4, 16, 2, nullptr) == SCG_OK && g_shim.launches == 1);
     EXPECT(scg_destroy(h) == SCG_OK);

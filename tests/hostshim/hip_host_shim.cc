@@ -98,7 +98,7 @@ LaunchGeom step_geometry(const KParams& p, int, int64_t n, int num_cus) {
     g.grid = (int32_t)(b < 1 ? 1 : b); g.lds_bytes = 0; return g;
 }
 hipError_t launch_step(int, const KParams& p, const scg_step_io& io, const KTables*, const ConTable*, const float*, int64_t n, int, hipStream_t s) {
-    g_shim.last_io = io;
+    g_shim.last_io = io; g_shim.last_serial_base = (p.flags & scg::F_SERIAL_WORD) ? p.serial_base : nullptr;
     if (g_shim.fail_launch_after >= 0 && g_shim.step_launches_main + g_shim.step_launches_aux + g_shim.captured_nodes >= g_shim.fail_launch_after) return hipErrorLaunchFailure;
     if (s && s->capturing) { ++s->captured_nodes; ++g_shim.captured_nodes; g_shim.last_n = n; return hipSuccess; }   // recorded, not executed
     ++g_shim.launches; g_shim.last_n = n; g_shim.last_env_base = p.env_base;

@@ -26,6 +26,7 @@ struct ShimState {
     int fail_event_sync;            // != 0: hipEventSynchronize fails (an exec must then be leaked, not destroyed)
     int64_t fused_launches;
     const float* last_fused_sink_obs;
+    const uint32_t* last_serial_base;   // KParams.serial_base of the last launch_step when F_SERIAL_WORD is set, else null
     scg_step_io last_io;            // the scg_step_io of the last launch_step
     void* last_exec;                // the last hipGraphExec_t instantiated (so that a test can free one the layer leaked on purpose)
 };

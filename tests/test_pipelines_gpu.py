@@ -345,3 +345,95 @@ def test_pipelined_loop_is_capturable_in_a_hip_graph(gpu):
         assert int(plain.ctrl_step_counter.max()) < K                                # every env was auto-reset inside the captured stretch
         del graph
     venv.close(); plain.close()
+
+
+@pytest.mark.parametrize('tier', ['lean', 'action_noise', 'goal_horizon_views'])
+def test_captured_loop_replays_equal_eager_stepping(gpu, tier):
+    """capture_loop(): K iterations of policy -> step recorded in one HIP graph, the step serials as offsets from a device word
+    (scg_step_io.serial_word) rewritten before every replay.  Three replays equal 3 K eager steps of a twin env bit for bit -- through
+    auto-resets (their Philox draws are counted by the serial) and, in the noise tier, through in-kernel action noise that is drawn
+    from the serial every step: a graph with baked serials would repeat the first replay's numbers."""
+    from safe_control_gym_amd.envs.graph_loop import capture_loop
+    kw = {'lean': dict(quad_type=3, task='traj_tracking', cost='quadratic', info_level='minimal'),
+          'action_noise': dict(quad_type=2, task='stabilization', cost='rl_reward', info_level='minimal',
+                               disturbances={'action': [{'disturbance_func': 'white_noise', 'std': 0.002}]}),
+          'goal_horizon_views': dict(quad_type=2, task='traj_tracking', cost='rl_reward', obs_goal_horizon=1, copy_outputs=False)}[tier]
+    kw = _common(kw)
+    n, K, warm = 3000, 40, 2
+    eager = scg.make('quadrotor', num_envs=n, **kw)
+    single = scg.make('quadrotor', num_envs=n, **kw)
+    venv = make_vec_envs(partial(scg.make, 'quadrotor', **kw), batch_size=n, num_pipelines=2)
+    nu = eager.action_dim
+    lo = torch.as_tensor(eager.action_space.low, device='cuda').reshape(-1, 1)
+    hi = torch.as_tensor(eager.action_space.high, device='cuda').reshape(-1, 1)
+    bias, gain = 0.5 * (lo + hi), 0.1 * (hi - lo)
+
+    def policy_into(env):
+        out = torch.zeros((nu, env.plane_stride), device='cuda')
+
+        def policy(obs):                                            # capture-safe: writes a preallocated plane buffer
+            torch.addcmul(bias, obs.T[:nu], gain, out=out[:, :env.num_envs])
+            return out
+        return policy
+    pe, ps, pv = policy_into(eager), policy_into(single), [policy_into(e) for e in venv.envs]
+    obs_e, obs_s = eager.reset(), single.reset()
+    obs_v = [e.reset() for e in venv.envs]
+
+    def body_single(k):
+        single.step(ps(obs_s))                                      # views: obs_s is the same tensor in every step
+
+    def body_venv(k):
+        for p, e in enumerate(venv.envs):
+            with torch.cuda.stream(e.pipeline_stream):
+                e.step_async(pv[p](obs_v[p]))
+        for p, e in enumerate(venv.envs):
+            with torch.cuda.stream(e.pipeline_stream):
+                e.step_wait()
+
+    def fork_join(body):                                            # the shards' queues join the recording through the caller's stream
+        def wrapped(k):
+            cur = torch.cuda.current_stream()
+            for e in venv.envs:
+                e.pipeline_stream.wait_stream(cur)
+            body(k)
+            for e in venv.envs:
+                cur.wait_stream(e.pipeline_stream)
+        return wrapped
+    loop_s = capture_loop(single, body_single, K, warmup=warm)
+    loop_v = venv.capture_loop(fork_join(body_venv), K, warmup=warm)
+    assert loop_s.serials == [K] and loop_v.serials == [K, K]
+    for _ in range(warm):
+        obs_e = eager.step(pe(obs_e))[0]
+    resets = 0
+    for r in range(3):
+        loop_s.replay()
+        loop_v.replay()
+        for _ in range(K):
+            obs_e, _, done, _ = eager.step(pe(obs_e))
+            resets += int(done.sum())
+        torch.cuda.synchronize()
+        for other, what in ((single.state, 'one env'), (torch.cat([e.state for e in venv.envs]), 'two pipelined shards')):
+            _same(other, eager.state, '%s: state after replay %d' % (what, r))
+        _same(single.episode_return, eager.episode_return, 'episode returns after replay %d' % r)
+        _same(torch.cat([e.ctrl_step_counter for e in venv.envs]), eager.ctrl_step_counter, 'step counters after replay %d' % r)
+        _same(single._obs_view(), eager._obs_view(), 'observation after replay %d' % r)
+    assert resets >= n
+    # eager steps and recorded replays mix freely: the env's serial runs on
+    obs_e = eager.step(pe(obs_e))[0]
+    single.step(ps(obs_s))
+    _same(single.state, eager.state, 'an eager step after the replays')
+    loop_s.replay()
+    for _ in range(K):
+        obs_e = eager.step(pe(obs_e))[0]
+    _same(single.state, eager.state, 'a replay after an eager step')
+    # what cannot be recorded says so
+    fresh = scg.make('quadrotor', quad_type=2, num_envs=64, **_common({}))
+    fresh.reset()
+    with pytest.raises(ValueError, match='steps in place'):
+        capture_loop(fresh, lambda k: None, 4, warmup=0)
+    with pytest.raises(RuntimeError, match='inside capture_loop'):
+        capture_loop(single, lambda k: single.reset(), 2, warmup=0)
+    assert single._capture_base is None and single._engine._io.serial_word is None      # a failed recording leaves no trace
+    for e in (eager, single, fresh):
+        e.close()
+    venv.close()
