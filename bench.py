@@ -495,7 +495,9 @@ def rl_pipeline_record(args, n, T):
     from safe_control_gym_amd.controllers.ppo.ppo_utils import PPOBuffer, compute_returns_and_advantages
     from safe_control_gym_amd.math_and_models.normalization import MeanStdNormalizer, RewardStdNormalizer
     env = scg.make('quadrotor', quad_type=3, num_envs=n, device='cuda', seed=1337, randomized_init=True, task='traj_tracking',
-                   cost='rl_reward', normalized_rl_action_space=True, ctrl_freq=60, pyb_freq=240, episode_len_sec=5)
+                   cost='rl_reward', normalized_rl_action_space=True, ctrl_freq=60, pyb_freq=240, episode_len_sec=5, copy_outputs=False)
+    # (copy_outputs=False: the raw observation is consumed by the normaliser at once, so the env may step in place; the info of a
+    # plain make() -- TimeLimit.truncated, terminal_observation -- stays)
     od, nu, gamma = env.obs_dim, env.action_dim, 0.99
     buf = PPOBuffer(env.observation_space, env.action_space, T, n, env=env)
     obs_norm, rew_norm = MeanStdNormalizer(shape=(od,), clip=10.0), RewardStdNormalizer(gamma=gamma, clip=10.0)

@@ -26,7 +26,8 @@ def main():
     T = int(sys.argv[2]) if len(sys.argv) > 2 else 128
     planes = (sys.argv[3] if len(sys.argv) > 3 else 'planes') == 'planes'
     env = scg.make('quadrotor', quad_type=2, num_envs=n, device='cuda', seed=0, task='traj_tracking', cost='rl_reward',
-                   normalized_rl_action_space=True, obs_goal_horizon=1, randomized_init=True)
+                   normalized_rl_action_space=True, obs_goal_horizon=1, randomized_init=True, copy_outputs=not planes)
+    # (planes: the normaliser consumes the raw observation at once and writes into the buffer, so the env may step in place)
     od, nu = env.obs_dim, env.action_dim
     torch.manual_seed(0)
     actor = torch.nn.Sequential(torch.nn.Linear(od, 64), torch.nn.Tanh(), torch.nn.Linear(64, nu), torch.nn.Tanh()).cuda()

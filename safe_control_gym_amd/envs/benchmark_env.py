@@ -1273,7 +1273,10 @@ class BenchmarkEnv:
                 b['obs'] = new_state
             b['state'] = new_state[:self.state_dim]
         if self._bound_dirty:
-            self._bound, self._bound_dirty = False, False      # the next call binds the env's own reward / done planes again
+            # views mode after step(out=...): later plain steps write the env's own reward / done planes again
+            self._bound_dirty = False
+            if self._bound:
+                self._engine.restore_outputs(b['reward'], b['done'])
         return new_state, outs
 
     def _step_outputs(self, launched):

@@ -160,6 +160,11 @@ class Engine:
         if state_out is not None:
             io.state, io.state_out = io.state_out, None
 
+    def restore_outputs(self, reward, done):
+        """After a ``step_bound(outs=...)`` that pointed this step's reward / done at a caller's tensors: bind the env's own planes
+        again (two stores instead of a full re-bind)."""
+        self._io.reward, self._io.done = reward.data_ptr(), done.data_ptr()
+
     def rollout(self, bufs, n, ld, serial, steps, actions, fused=False, sink=None):
         """``steps`` launches (or one fused launch); ``actions`` is a contiguous [period, nu, ld] float32 tensor
         used cyclically.  ``sink``: {name: time-major tensor} -- step k writes that output into slab k of the tensor
