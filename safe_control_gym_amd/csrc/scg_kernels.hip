@@ -896,7 +896,10 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
             else if constexpr (SYS == SCG_QUAD_2D) { fx += dn[0]; fz += dn[1]; }        // x-z plane (:543-545)
             else if constexpr (SYS == SCG_QUAD_1D) { fz += dn[0]; }                     // z only (:540-542)
             else { fx += dn[0]; }                                                       // cart force
-            apply_disturbances<NX>(p, &s_dist, SCG_DIST_OBSERVATION, 0, i, serial, episode, t, obs_noise);
+#ifndef SCG_OBS_NOISE_LATE
+#define SCG_OBS_NOISE_LATE 1   // 1: the observation noise is drawn behind the integration, where it is first used (it is a pure function of
+#endif                         // (env, serial, step counter): drawn up here its NX values stay live across the RK4 stages)
+            if (!SCG_OBS_NOISE_LATE) apply_disturbances<NX>(p, &s_dist, SCG_DIST_OBSERVATION, 0, i, serial, episode, t, obs_noise);
         }
 
         // ---- before_step / _preprocess_control (benchmark_env.py:394-404, quadrotor.py:815-842) and the state
@@ -1120,6 +1123,11 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                 asm volatile("" ::: "memory");                              // a real (wave-uniform) branch: ~14 instructions not worth speculating
                 rew = expf(rew);
             }
+        }
+
+        if (SCG_OBS_NOISE_LATE && DIST && p.dist) {
+            const uint32_t episode = io.episode_id ? ldp(io.episode_id, i4) : 0u;
+            apply_disturbances<NX>(p, &s_dist, SCG_DIST_OBSERVATION, 0, i, serial, episode, t, obs_noise);
         }
 
         // ---- after_step (benchmark_env.py:422-463)
