@@ -11,6 +11,8 @@ for bit (tests/test_pipelines_gpu.py::test_captured_loop_replays_equal_eager_ste
 The reference has nothing to mirror here (its loops are Python over NumPy envs: controllers/ppo/ppo.py:247-293); this is what its
 ``for`` loop over ``rollout_steps`` becomes when the env, the policy and the buffer live on one device.
 """
+import gc
+
 import torch
 
 
@@ -29,12 +31,21 @@ class CapturedLoop:
         self.graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        # Nothing but the recorded work may touch the runtime while the capture is open: a cyclic-garbage collection that happens to
+        # run inside it would finalise whatever env objects are waiting (scg_destroy: hipFree, stream / event synchronisation) and
+        # invalidate the capture.  Collect now, keep the collector off until the capture has ended; other threads are not our business
+        # (capture_error_mode='thread_local').
+        gc.collect()
+        was_enabled = gc.isenabled()
+        gc.disable()
         try:
             with torch.cuda.stream(side):
-                with torch.cuda.graph(self.graph, stream=side):
+                with torch.cuda.graph(self.graph, stream=side, capture_error_mode='thread_local'):
                     for k in range(self.steps):
                         body(k)
         finally:
+            if was_enabled:
+                gc.enable()
             self.serials = [e._end_capture() for e in self.envs]
         torch.cuda.current_stream().wait_stream(side)
 

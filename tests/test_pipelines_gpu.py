@@ -331,9 +331,14 @@ def test_pipelined_loop_is_capturable_in_a_hip_graph(gpu):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(graph, stream=side):
-                pipelined(K, on_queue)
+        import gc
+        gc.collect(); gc.disable()                                                  # no finaliser (scg_destroy of an old env) inside the capture
+        try:
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    pipelined(K, on_queue)
+        finally:
+            gc.enable()
         torch.cuda.current_stream().wait_stream(side)
         graph.replay()
         for _ in range(K):
