@@ -522,32 +522,40 @@ def rl_pipeline_record(args, n, T):
     stages = ('policy', 'env_step', 'obs_normalizer', 'reward_normalizer', 'terminal_value', 'returns_gae')
     box = {'obs': obs_norm(env.reset(), out=buf.obs_planes[0])}
 
+    def step_body(t, mark=lambda: None):
+        obs = buf.obs_at(t)                    # slab t: written by the observation normaliser of step t - 1 (slab 0: buf.start)
+        mark()
+        actor(obs, buf.act_planes[t]); critic(obs, buf.v[t, :, 0])
+        mark()
+        raw, rew, done, info = env.step(buf.act_planes[t], out=buf.step_out(t, obs=False, reward=False))
+        mark()
+        obs_norm(raw, out=buf.obs_planes[t + 1])
+        mark()
+        rew_norm(rew, done, out=buf.rew_planes[t])
+        mark()
+        terminal_value(info, buf.terminal_v[t, :, 0])
+
+    def finish():
+        obs = buf.obs_at(T)
+        ret, adv = compute_returns_and_advantages(buf.rew, buf.v, None, buf.terminal_v, critic(obs).reshape(n, 1), gamma=gamma, use_gae=True,
+                                                  gae_lambda=0.95, normalize_advantages=True, dones=buf.done)
+        box['obs'] = obs
+        return ret, adv
+
     def rollout(marks=None):
         def mark():
             if marks is not None:
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record()
                 marks.append(ev)
-        obs = buf.obs_at(0)
-        if obs.data_ptr() != box['obs'].data_ptr():
-            obs = buf.start(box['obs'])
+        if buf.obs_at(0).data_ptr() != box['obs'].data_ptr():
+            buf.start(box['obs'])
         for t in range(T):
-            mark()
-            actor(obs, buf.act_planes[t]); critic(obs, buf.v[t, :, 0])
-            mark()
-            raw, rew, done, info = env.step(buf.act_planes[t], out=buf.step_out(t, obs=False, reward=False))
-            mark()
-            obs = obs_norm(raw, out=buf.obs_planes[t + 1])
-            mark()
-            rew_norm(rew, done, out=buf.rew_planes[t])
-            mark()
-            terminal_value(info, buf.terminal_v[t, :, 0])
+            step_body(t, mark)
         mark()
-        ret, adv = compute_returns_and_advantages(buf.rew, buf.v, None, buf.terminal_v, critic(obs).reshape(n, 1), gamma=gamma, use_gae=True,
-                                                  gae_lambda=0.95, normalize_advantages=True, dones=buf.done)
+        out = finish()
         mark()
-        box['obs'] = obs
-        return ret, adv
+        return out
 
     rollout()
     torch.cuda.synchronize()
@@ -565,10 +573,30 @@ def rl_pipeline_record(args, n, T):
         for q in range(5):
             per[stages[q]] += marks[5 * t + q].elapsed_time(marks[5 * t + q + 1])
     per['returns_gae'] = marks[5 * T].elapsed_time(marks[5 * T + 1])
+    # the same rollout with its T steps recorded once in a HIP graph (capture_loop: the step serial through a device word; T is even, so the
+    # normalisers' double-buffered records are back where the recording found them) -- one launch per rollout, GAE behind it
+    from safe_control_gym_amd.envs.graph_loop import capture_loop
+    buf.start(box['obs'])
+    loop = capture_loop(env, step_body, T, warmup=2)
+
+    def rollout_replayed():
+        buf.start(box['obs'])
+        loop.replay()
+        return finish()
+    rollout_replayed()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        rollout_replayed()
+    torch.cuda.synchronize()
+    wall_graph = (time.perf_counter() - t0) / reps
     rec = {'workload': 'Quadrotor-3D tracking, rl_reward, normalised actions, default make() info (time-limit bootstrap); %d envs x %d steps per '
                        'rollout: stand-in policy + critic -> env.step -> MeanStdNormalizer -> RewardStdNormalizer -> terminal value -> '
                        'PPOBuffer(env=...) rows -> scg_gae + advantage normalisation' % (n, T),
            'envs': n, 'rollout_steps': T, 'value': n * T / wall, 'unit': 'env-steps/s', 'us_per_step': wall / T * 1e6,
+           'replayed_from_a_hip_graph': {'value': n * T / wall_graph, 'us_per_step': wall_graph / T * 1e6,
+                                         'note': 'the T steps of a rollout (policy, step, normalisers, bootstrap) recorded once by capture_loop() and '
+                                                 'replayed with one launch; GAE behind it'},
            'stage_us_per_step': {k: (v * 1e3 / T) for k, v in per.items()},
            'library_stages_us_per_step': sum(per[k] for k in ('env_step', 'obs_normalizer', 'reward_normalizer', 'returns_gae')) * 1e3 / T,
            'stand_in_stages_us_per_step': sum(per[k] for k in ('policy', 'terminal_value')) * 1e3 / T,
