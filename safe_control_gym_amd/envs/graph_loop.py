@@ -62,7 +62,11 @@ def capture_loop(envs, body, steps, warmup=2):
     data-dependent shapes) -- for the batched env(s) ``envs`` (one env, or the shards of a ``PipelinedDeviceVecEnv``) and return a
     ``CapturedLoop``.  The envs must step in place (``copy_outputs=False`` / ``info_level='minimal'``): their output views are the
     same tensors in every step, which is what lets a policy recorded once read the right observation on every replay.  ``body``
-    runs ``warmup`` times eagerly first (those steps count: the envs advance)."""
+    runs ``warmup`` times eagerly first (those steps count: the envs advance).
+
+    Host-side state that alternates per call must come round per replay: the normalisers double-buffer their statistics record
+    (``RunningMeanStd._records``), so a recorded stretch has to contain an EVEN number of updating normaliser calls (``steps`` even
+    with one call per step) -- the nodes of the next replay start from the record the recording started from."""
     if not isinstance(envs, (list, tuple)):
         envs = getattr(envs, 'envs', [envs])
     return CapturedLoop(envs, body, steps, warmup)
