@@ -57,6 +57,12 @@ close)
   echo "== pmc, trajectory-sink rollout, bare C4 step (traffic counters)"; PMC_TRAFFIC_ONLY=1 profiles/pmc.sh "$out/pmc_sink" --no-episode-stats --trajectory-sink 60 > "$out/pmc_summary_bare_trajectory_sink.txt" 2>&1; cat "$out/pmc_summary_bare_trajectory_sink.txt"; rm -rf "$out"/pmc_sink/pass*
   echo "== smoke"; timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
   ;;
+final)
+  # the last word of the round on the final tree: whole GPU suite, the driver's command, smoke()
+  echo "== GPU suite"; timeout -k 10 1500 python -m pytest tests -m gpu -q > "$out/gpu_tests.log" 2>&1; grep -E "^(FAILED|ERROR)|passed|failed" "$out/gpu_tests.log" | tail -15
+  echo "== driver's command"; timeout -k 10 900 python bench.py --gpus 1 --steps 20 --warmup 5 > "$out/bench_driver_cmd.json" 2> "$out/bench_driver_cmd.err"; cut -c1-300 "$out/bench_driver_cmd.json"
+  echo "== smoke"; timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+  ;;
 suite)
   echo "== GPU suite"; timeout -k 10 1500 python -m pytest tests -m gpu -q > "$out/gpu_tests.log" 2>&1; grep -E "^(FAILED|ERROR)|passed|failed" "$out/gpu_tests.log" | tail -15
   echo "== smoke"; timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
