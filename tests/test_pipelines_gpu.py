@@ -442,3 +442,59 @@ def test_captured_loop_replays_equal_eager_stepping(gpu, tier):
     for e in (eager, single, fresh):
         e.close()
     venv.close()
+
+
+BASELINE_SIZES = {
+    'c4_2p20': ('quadrotor', 1 << 20, dict(quad_type=3, task='traj_tracking', cost='quadratic', info_level='minimal', episode_len_sec=5)),
+    'c3_2p18': ('quadrotor', 1 << 18, dict(quad_type=2, task='stabilization', cost='rl_reward', constraints=C3_CONSTRAINTS,
+                                           info_level='minimal', episode_len_sec=5)),
+    'c2_2p16': ('cartpole', 1 << 16, dict(task='stabilization', cost='quadratic', info_level='minimal', ctrl_freq=50, pyb_freq=50,
+                                          episode_len_sec=5)),
+}
+
+
+@pytest.mark.parametrize('case', list(BASELINE_SIZES))
+def test_round4_forms_at_baseline_sizes(gpu, case):
+    """At BASELINE.json's full sizes (C4 2^20 -- the natural two-queue split --, C3 2^18, C2 2^16): the trajectory sink filled by
+    per-step launches and by the fused launch, and two pipelined shards, reproduce the plain step() loop bit for bit (a
+    size-independent property: equality of every observation / reward / done of every step).  A short stretch with a high
+    termination rate (wide random actions) so that auto-resets occur inside it."""
+    name, n, kw = BASELINE_SIZES[case]
+    kw = _common(kw)
+    steps = 12
+    plain, sunk, fused = (scg.make(name, num_envs=n, **kw) for _ in range(3))
+    venv = make_vec_envs(partial(scg.make, name, **kw), batch_size=n, num_pipelines=2)
+    for e in (plain, sunk, fused):
+        e.reset()
+    pobs = [venv.reset(pipeline=p)[0] for p in range(2)]
+    ld, nu = plain.plane_stride, plain.action_dim
+    g = torch.Generator(device='cuda'); g.manual_seed(17)
+    lo = torch.as_tensor(plain.action_space.low, device='cuda')[None, :, None]
+    hi = torch.as_tensor(plain.action_space.high, device='cuda')[None, :, None]
+    acts = torch.rand((4, nu, ld), generator=g, device='cuda') * (hi - lo) * 1.6 + lo - 0.3 * (hi - lo)
+    ts, tf = sunk.trajectory_buffer(steps), fused.trajectory_buffer(steps)
+    sunk.rollout(acts, steps=steps, out=ts)
+    fused.rollout(acts, steps=steps, fused=True, out=tf)
+    finished = 0
+    for k in range(steps):
+        obs, rew, done, info = plain.step(acts[k % 4])
+        rows = acts[k % 4][:, :n].T.contiguous()
+        for p, (a, b) in enumerate(venv.bounds):
+            venv.step_async(rows[a:b], pipeline=p)
+        outs = [venv.step_wait(pipeline=p) for p in range(2)]
+        for q, what in enumerate(('obs', 'reward', 'done')):
+            _same(torch.cat([o[q] for o in outs]), (obs, rew, done)[q], 'pipelined shards: %s at step %d' % (what, k))
+        for traj, form in ((ts, 'sink'), (tf, 'fused sink')):
+            _same(traj.obs[k], obs, '%s: obs at step %d' % (form, k))
+            _same(traj.reward[k], rew, '%s: reward at step %d' % (form, k))
+            _same(traj.done[k], done, '%s: done at step %d' % (form, k))
+            if plain.constraints is not None:
+                _same(traj.constraint_values[k], info['constraint_values'], '%s: constraint values at step %d' % (form, k))
+        finished += int(done.sum())
+    assert finished > 0
+    for e in (sunk, fused):
+        _same(e.state, plain.state, 'final state')
+        _same(e.ctrl_step_counter, plain.ctrl_step_counter, 'final step counters')
+    for e in (plain, sunk, fused):
+        e.close()
+    venv.close()
