@@ -341,6 +341,12 @@ class BenchmarkEnv:
                 'reset_state': None if self._reset_state_buf is None else self._reset_state_buf.clone()}
 
     # -- recording the caller's step loop in a HIP graph (envs/graph_loop.py::capture_loop) ---------------------------------------
+    def capture_loop(self, body, steps, warmup=2):
+        """``steps`` iterations of ``body(k)`` -- capture-safe torch code around this env's ``step`` -- recorded in one HIP graph;
+        ``.replay()`` runs them with one launch and equals eager stepping bit for bit (``envs/graph_loop.py``)."""
+        from safe_control_gym_amd.envs.graph_loop import capture_loop
+        return capture_loop([self], body, steps, warmup)
+
     def _begin_capture(self):
         self._ensure_engine()
         self._check_initial_reset()
