@@ -7,7 +7,11 @@ normalisers' kernels write the normalised observation / reward into the buffer's
 the policy produces, and GAE reads the done bytes and the planes in place.  The policy is a small random MLP (no learning):
 the point is the data path.
 
-    python examples/ppo_rollout.py [num_envs] [rollout_steps] [pushed|planes]
+    python examples/ppo_rollout.py [num_envs] [rollout_steps] [pushed|planes|graph]
+
+``graph``: the plane-layout rollout with its T steps recorded once in a HIP graph (``env.capture_loop``: MLP kernels, step kernel,
+normalisers; the step serial through a device word, so every replay draws fresh resets) and replayed per rollout -- no host in the
+loop, which is what bounds the small batches.
 """
 import os
 import sys
@@ -24,7 +28,8 @@ from safe_control_gym_amd.math_and_models.normalization import MeanStdNormalizer
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
     T = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-    planes = (sys.argv[3] if len(sys.argv) > 3 else 'planes') == 'planes'
+    mode = sys.argv[3] if len(sys.argv) > 3 else 'planes'
+    planes, graph = mode in ('planes', 'graph'), mode == 'graph'
     env = scg.make('quadrotor', quad_type=2, num_envs=n, device='cuda', seed=0, task='traj_tracking', cost='rl_reward',
                    normalized_rl_action_space=True, obs_goal_horizon=1, randomized_init=True, copy_outputs=not planes)
     # (planes: the normaliser consumes the raw observation at once and writes into the buffer, so the env may step in place)
@@ -36,8 +41,27 @@ def main():
     buf = PPOBuffer(env.observation_space, env.action_space, T, n, env=env if planes else None)
     zeros = torch.zeros(n, 1, device='cuda')
 
+    def step_body(t):                                  # one step of the plane-layout rollout, capture-safe (graph mode records T of them)
+        obs = buf.obs_at(t)
+        act = actor(obs) + 0.1 * torch.randn(n, nu, device='cuda')
+        v = critic(obs)
+        raw, rew, done, info = env.step(act, out=buf.step_out(t, obs=False, reward=False))
+        obs_norm(raw, out=buf.obs_planes[t + 1])
+        rew_norm(rew, done, out=buf.rew_planes[t])
+        terminal_v = torch.where(info['TimeLimit.truncated'][:, None], critic(info['terminal_observation']), zeros)
+        buf.act[t].copy_(act); buf.v[t].copy_(v); buf.terminal_v[t].copy_(terminal_v)      # (push() without its host-side ring index)
+
+    loop = None
+
     def rollout(obs):
         with torch.no_grad():
+            if graph:
+                buf.start(obs)
+                loop.replay()
+                obs = buf.obs_at(T)
+                ret, adv = compute_returns_and_advantages(buf.rew, buf.v, None, buf.terminal_v, critic(obs), gamma=0.99, use_gae=True,
+                                                          gae_lambda=0.95, dones=buf.done)
+                return obs, ret, adv
             if planes:
                 obs = buf.start(obs) if obs.data_ptr() != buf.obs_at(0).data_ptr() else obs
             for t in range(T):
@@ -66,6 +90,11 @@ def main():
         return obs, ret, adv
 
     obs = obs_norm(env.reset())
+    if graph:
+        assert T % 2 == 0, 'graph mode: an even number of steps (the normalisers double-buffer their statistics)'
+        buf.start(obs)
+        with torch.no_grad():
+            loop = env.capture_loop(step_body, T, warmup=2)
     obs, _, _ = rollout(obs)                                                        # warm-up
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -75,7 +104,8 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print('%s buffer: %d envs x %d steps x %d rollouts in %.3f s: %.3e env-steps/s through policy + env + normalisers + buffer + GAE'
-          % ('plane-layout (zero-copy)' if planes else 'pushed', n, T, iters, dt, n * T * iters / dt))
+          % ('plane-layout buffer, rollout replayed from a HIP graph' if graph else 'plane-layout (zero-copy)' if planes else 'pushed',
+             n, T, iters, dt, n * T * iters / dt))
     print('advantage mean %.3e std %.3e; return mean %.3e' % (float(adv.mean()), float(adv.std()), float(ret.mean())))
     env.close()
 

@@ -19,6 +19,9 @@ def _run(script, *args):
 def test_ppo_rollout_example(gpu):
     out = _run('ppo_rollout.py', 4096, 8)
     assert 'env-steps/s through policy + env + normalisers + buffer + GAE' in out and 'advantage mean' in out
+    for mode in ('pushed', 'graph'):                   # the reference's push scheme; the rollout recorded in a HIP graph and replayed
+        out = _run('ppo_rollout.py', 4096, 8, mode)
+        assert 'env-steps/s through policy + env + normalisers + buffer + GAE' in out and 'nan' not in out.lower()
 
 
 def test_linearize_along_trajectory_example(gpu):

@@ -45,7 +45,7 @@ PY
   ;;
 fuzz)
   echo "== configuration fuzz (rollout / sink / pipelines == step loop)"; timeout -k 10 1100 python -m pytest tests/test_config_fuzz_gpu.py tests/test_examples_gpu.py -m gpu -q -x -k "rollout_equals or example" > "$out/gpu_fuzz.log" 2>&1; tail -12 "$out/gpu_fuzz.log"
-  for args in "16384 128 pushed" "16384 128 planes" "262144 128 pushed" "262144 128 planes" "1048576 64 pushed" "1048576 64 planes"; do
+  for args in "4096 128 planes" "4096 128 graph" "16384 128 pushed" "16384 128 planes" "16384 128 graph" "262144 128 pushed" "262144 128 planes" "262144 128 graph" "1048576 64 pushed" "1048576 64 planes" "1048576 64 graph"; do
     timeout -k 10 300 python examples/ppo_rollout.py $args 2>&1 | grep "env-steps/s" | tee -a "$out/ppo_rollout_example.txt"
   done
   ;;
