@@ -474,6 +474,7 @@ int scg_create(const scg_config* cfg, scg_handle** out) {
 
 int scg_destroy(scg_handle* h) {
     if (!h) return SCG_OK;
+    if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);   // a step issued by scg_step_async may still be reading the tables
     if (h->d_con) (void)hipFree(h->d_con);
     if (h->d_tb) (void)hipFree(h->d_tb);
     if (h->d_ref) (void)hipFree(h->d_ref);
@@ -484,7 +485,6 @@ int scg_destroy(scg_handle* h) {
         if (h->graphs[q].replayed) (void)hipEventDestroy(h->graphs[q].replayed);
     }
     if (h->aux_stream) {
-        (void)hipStreamSynchronize(h->aux_stream);          // a step issued by scg_step_async may still be running on it
         (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join);
         (void)hipEventDestroy(h->ev_async_in); (void)hipEventDestroy(h->ev_async_out);
         (void)hipStreamDestroy(h->aux_stream);

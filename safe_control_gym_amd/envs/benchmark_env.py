@@ -1262,6 +1262,8 @@ class BenchmarkEnv:
                 if 'obs' in b:
                     io['obs'] = new_state
             self._adversary_planes(io)
+            if asynchronous:                                   # the adversary's planes are read by the other queue too
+                self._inflight += (io.get('action_disturbance'), io.get('dynamics_force'))
             self._engine.step(io, self.num_envs, self._ld, self._launch_serial(), action_rows=rows, asynchronous=asynchronous)
             self._bound = False
         else:

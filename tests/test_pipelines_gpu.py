@@ -150,6 +150,29 @@ def test_step_async_protocol_errors(gpu):
     env.close(); twin.close()
 
 
+@pytest.mark.parametrize('mode', ['action', 'dynamics'])
+def test_asynchronous_step_with_an_adversary_equals_the_plain_step(gpu, mode):
+    """benchmark_env.py:256-266: the adversary's planes are built per step and read by the env's own queue; between
+    step_async and step_wait the caller allocates freely (the planes must stay alive until the join)."""
+    n, steps = 2048, 40
+    kw = _common(dict(quad_type=2, task='stabilization', cost='rl_reward', adversary_disturbance=mode, adversary_disturbance_scale=0.02))
+    a_env, b_env = scg.make('quadrotor', num_envs=n, **kw), scg.make('quadrotor', num_envs=n, **kw)
+    policy = _policy(a_env)
+    oa, ob = a_env.reset(), b_env.reset()
+    g = torch.Generator(device='cuda').manual_seed(5)
+    adv_dim = a_env.DISTURBANCE_MODES[mode]['dim']
+    for k in range(steps):
+        adv = torch.rand((n, adv_dim), device='cuda', generator=g) * 2 - 1
+        a_env.set_adversary_control(adv); b_env.set_adversary_control(adv)
+        oa, ra, da, _ = a_env.step(policy(oa, k))
+        b_env.step_async(policy(ob, k))
+        churn = [torch.full((3, b_env.plane_stride), float(k), device='cuda') for _ in range(4)]     # reuses freed blocks at once
+        del churn
+        ob, rb, db, _ = b_env.step_wait()
+        _same(ob, oa, 'obs at step %d' % k); _same(rb, ra, 'reward at step %d' % k); _same(db, da, 'done at step %d' % k)
+    a_env.close(); b_env.close()
+
+
 SINK_CASES = {
     'c4_lean': ('quadrotor', dict(quad_type=3, task='traj_tracking', cost='quadratic', info_level='minimal')),
     'c3_constraints': ('quadrotor', dict(quad_type=2, task='stabilization', cost='rl_reward', constraints=C3_CONSTRAINTS,
