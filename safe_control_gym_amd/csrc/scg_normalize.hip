@@ -110,23 +110,69 @@ __global__ __launch_bounds__(256) void scg_moments_kernel(const float* __restric
 // "information leak" reset.  legacy == 0: ret[i] = 0 where done[i] (what the comment at :187 intends).
 // legacy != 0 reproduces the reference statement literally -- `self.ret[dones.astype(np.long)] = 0` indexes with
 // the 0 / 1 VALUES of dones, i.e. clears ret[0] when some env is not done and ret[1] when some env is done --
-// which the normalise pass applies once the done count is known.  partials: [max_partials(1)][3].
+// which the normalise pass applies once the done count is known.  partials: [<= kRewardPartials][3].
+// 13 B per env in one pass: <= 256 workgroups, every thread with four independent 16-byte groups (ret, rew, 4 done bytes)
+// in flight before the first use (round 4: the one-element-per-iteration form spent its time on exposed latencies).
+constexpr int kRewardPartials = 256;
+
+template <bool VEC>
 __global__ __launch_bounds__(256) void scg_reward_moments_kernel(const float* __restrict__ rew,
                                                                  const uint8_t* __restrict__ done,
                                                                  float* __restrict__ ret, uint32_t n, float gamma,
                                                                  const double* __restrict__ state, int legacy,
                                                                  double* __restrict__ partials) {
     __shared__ double lds[12];
-    const double c = state[0];
+    const double cd = state[0];
     double acc[3] = {0.0, 0.0, 0.0};
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const float r = fmaf(ret[i], gamma, rew[i]);
-        const double v = (double)r - c;
-        acc[0] += v;
-        acc[1] = fma(v, v, acc[1]);
-        const bool dn = done[i] != 0;
-        acc[2] += dn ? 1.0 : 0.0;
-        ret[i] = (!legacy && dn) ? 0.f : r;
+    if constexpr (VEC) {
+        const uint32_t n4 = n >> 2, stride = gridDim.x * 256u;
+        for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < n4; q += 4u * stride) {
+            nf4 a4[4], r4[4];
+            uint32_t d4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (q + u * stride < n4) {
+                    a4[u] = reinterpret_cast<const nf4*>(ret)[q + u * stride];
+                    r4[u] = reinterpret_cast<const nf4*>(rew)[q + u * stride];
+                    d4[u] = reinterpret_cast<const uint32_t*>(done)[q + u * stride];
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (q + u * stride < n4) {
+                    nf4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float r = fmaf(a4[u][k], gamma, r4[u][k]);
+                        const bool dn = ((d4[u] >> (8 * k)) & 0xffu) != 0;
+                        const double v = (double)r - cd;
+                        acc[0] += v;
+                        acc[1] = fma(v, v, acc[1]);
+                        acc[2] += dn ? 1.0 : 0.0;
+                        o[k] = (!legacy && dn) ? 0.f : r;
+                    }
+                    reinterpret_cast<nf4*>(ret)[q + u * stride] = o;
+                }
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3u)) {                // ragged tail: at most 3 elements
+            const uint32_t i = (n & ~3u) + threadIdx.x;
+            const float r = fmaf(ret[i], gamma, rew[i]);
+            const bool dn = done[i] != 0;
+            const double v = (double)r - cd;
+            acc[0] += v;
+            acc[1] = fma(v, v, acc[1]);
+            acc[2] += dn ? 1.0 : 0.0;
+            ret[i] = (!legacy && dn) ? 0.f : r;
+        }
+    } else {
+        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+            const float r = fmaf(ret[i], gamma, rew[i]);
+            const double v = (double)r - cd;
+            acc[0] += v;
+            acc[1] = fma(v, v, acc[1]);
+            const bool dn = done[i] != 0;
+            acc[2] += dn ? 1.0 : 0.0;
+            ret[i] = (!legacy && dn) ? 0.f : r;
+        }
     }
     block_sum<3>(acc, lds);
     if (threadIdx.x == 0) {
@@ -227,12 +273,21 @@ __global__ __launch_bounds__(256) void scg_mean_std_apply_kernel(const float* __
 }
 
 // RewardStdNormalizer, second half (:189): out = clip(rew / sqrt(var + eps)) -- scaling only.
+template <bool VEC>
 __global__ __launch_bounds__(256) void scg_reward_apply_kernel(const float* __restrict__ rew, float* __restrict__ out,
                                                                float* __restrict__ ret, uint32_t n,
                                                                const double* __restrict__ state_in,
                                                                double* __restrict__ state_out,
                                                                const double* __restrict__ partials, int n_partials,
                                                                int legacy, float clip, double epsilon) {
+    // this thread's rewards first: their latency covers the partial sums below
+    const uint32_t n4 = n >> 2, stride = gridDim.x * 256u, q0 = blockIdx.x * 256u + threadIdx.x;
+    nf4 r4[4];
+    if constexpr (VEC) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (q0 + u * stride < n4) r4[u] = reinterpret_cast<const nf4*>(rew)[q0 + u * stride];
+    }
     double var = state_in[1];
     if (state_out) {
         double tot[3];
@@ -250,8 +305,30 @@ __global__ __launch_bounds__(256) void scg_reward_apply_kernel(const float* __re
     }
     const double inv = 1.0 / sqrt(var + epsilon);
     const double lo = -(double)clip, hi = (double)clip;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
-        out[i] = (float)fmin(fmax((double)rew[i] * inv, lo), hi);
+    if constexpr (VEC) {
+        for (uint32_t q = q0; q < n4; q += 4u * stride) {
+            if (q != q0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (q + u * stride < n4) r4[u] = reinterpret_cast<const nf4*>(rew)[q + u * stride];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (q + u * stride < n4) {
+                    nf4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = (float)fmin(fmax((double)r4[u][k] * inv, lo), hi);
+                    reinterpret_cast<nf4*>(out)[q + u * stride] = o;
+                }
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3u)) {
+            const uint32_t i = (n & ~3u) + threadIdx.x;
+            out[i] = (float)fmin(fmax((double)rew[i] * inv, lo), hi);
+        }
+    } else {
+        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
+            out[i] = (float)fmin(fmax((double)rew[i] * inv, lo), hi);
+    }
 }
 
 // ---- launchers ------------------------------------------------------------------------------------
@@ -267,7 +344,7 @@ static unsigned apply_blocks(int64_t n, int d) {
     return (unsigned)(b < 1 ? 1 : b);
 }
 
-// scratch: 2 d max_partials(d) doubles (mean / std normaliser), 3 max_partials(1) = 3072 doubles (reward normaliser)
+// scratch: 2 d max_partials(d) doubles (mean / std normaliser), 3 kRewardPartials = 768 doubles (reward normaliser)
 hipError_t launch_mean_std_normalize(const float* x, float* y, int d, int64_t ld_x, int64_t ld_y, int64_t n,
                                      const double* state_in, double* state_out, double* partials, float clip,
                                      double epsilon, hipStream_t s) {
@@ -288,15 +365,29 @@ hipError_t launch_mean_std_normalize(const float* x, float* y, int d, int64_t ld
     return hipGetLastError();
 }
 
+static unsigned reward_blocks(int64_t n) {
+    int64_t b = (n + 4095) / 4096;                              // 16 elements per thread: four 16-byte groups in flight
+    if (b > kRewardPartials) b = kRewardPartials;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
 hipError_t launch_reward_normalize(const float* rew, const uint8_t* done, float* ret, float* out, int64_t n,
                                    const double* state_in, double* state_out, double* partials, float gamma,
                                    float clip, double epsilon, int legacy, hipStream_t s) {
-    const unsigned pb = partial_blocks(n, 1);
-    if (state_out)
-        hipLaunchKernelGGL(scg_reward_moments_kernel, dim3(pb), dim3(256), 0, s, rew, done, ret, (uint32_t)n, gamma,
-                           state_in, legacy, partials);
-    hipLaunchKernelGGL(scg_reward_apply_kernel, dim3(apply_blocks(n, 1)), dim3(256), 0, s, rew, out, ret, (uint32_t)n,
-                       state_in, state_out, partials, (int)pb, legacy, clip, epsilon);
+    const unsigned pb = reward_blocks(n);
+    auto addr = [](const void* p) { return reinterpret_cast<uintptr_t>(p); };
+    if (state_out) {
+        const bool vec = ((addr(rew) | addr(ret)) & 15u) == 0 && (addr(done) & 3u) == 0;
+        if (vec) hipLaunchKernelGGL(scg_reward_moments_kernel<true>, dim3(pb), dim3(256), 0, s, rew, done, ret, (uint32_t)n, gamma,
+                                    state_in, legacy, partials);
+        else hipLaunchKernelGGL(scg_reward_moments_kernel<false>, dim3(pb), dim3(256), 0, s, rew, done, ret, (uint32_t)n, gamma,
+                                state_in, legacy, partials);
+    }
+    const bool vec2 = ((addr(rew) | addr(out)) & 15u) == 0;
+    if (vec2) hipLaunchKernelGGL(scg_reward_apply_kernel<true>, dim3(pb), dim3(256), 0, s, rew, out, ret, (uint32_t)n,
+                                 state_in, state_out, partials, (int)pb, legacy, clip, epsilon);
+    else hipLaunchKernelGGL(scg_reward_apply_kernel<false>, dim3(pb), dim3(256), 0, s, rew, out, ret, (uint32_t)n,
+                            state_in, state_out, partials, (int)pb, legacy, clip, epsilon);
     return hipGetLastError();
 }
 

@@ -38,6 +38,10 @@ class RunningMeanStd:
         self._state[:, 2 * self.d] = epsilon
         self._cur = 0
         self._moments = torch.zeros(max(2 * max(64 * self.d, 1024), 3072), dtype=torch.float64, device=self.device)   # kernel scratch
+        # raw addresses for the per-step calls (the records never move): a tensor index + data_ptr() costs ~3 us of host each
+        self._rec_ptr = (self._state[0].data_ptr(), self._state[1].data_ptr())
+        self._moments_ptr = self._moments.data_ptr()
+        self.device = self._state.device                        # with its index: the launches check the current device against it
 
     # the reference's attributes, as views of the current record
     @property
@@ -61,6 +65,14 @@ class RunningMeanStd:
         self._cur = 1 - self._cur
         return cur, nxt
 
+    def _record_ptrs(self, update):
+        """``_records`` as raw addresses (state_in, state_out or None)."""
+        cur = self._rec_ptr[self._cur]
+        if not update:
+            return cur, None
+        self._cur = 1 - self._cur
+        return cur, self._rec_ptr[self._cur]
+
     def update(self, arr):
         """normalization.py:34-46 on a device batch [N, *shape]: the moments pass of the normalisers alone (``y == NULL``:
         no scratch output, no apply pass).  An [N, d] view of SoA planes (``env.step()``'s obs) is read in place."""
@@ -75,12 +87,9 @@ class RunningMeanStd:
             planes, ld = x, (x.stride(1) if self.d > 1 else n)             # already [d][ld] planes underneath: zero copy
         else:
             planes, ld = x.T.contiguous(), n                                # [d, n] SoA planes
-        state_in, state_out = self._records(True)
-        lib = _capi.load()
-        with torch.cuda.device(self.device):
-            _capi.check(lib.scg_mean_std_normalize(planes.data_ptr(), 0, self.d, ld, 0, n, state_in.data_ptr(),
-                                                   state_out.data_ptr(), self._moments.data_ptr(), 0.0, 0.0,
-                                                   _capi.current_stream(self.device)), 'scg_mean_std_normalize')
+        state_in, state_out = self._record_ptrs(True)
+        _launch(self.device, _capi.load().scg_mean_std_normalize, 'scg_mean_std_normalize', planes.data_ptr(), 0, self.d, ld, 0, n,
+                state_in, state_out, self._moments_ptr, 0.0, 0.0)
 
     def update_from_moments(self, batch_mean, batch_var, batch_count):
         """normalization.py:48-62 (Chan's parallel update), float64 on the device record; device tensors stay on the device."""
@@ -108,8 +117,19 @@ class RunningMeanStd:
             rec[2 * self.d] = float(count)
 
 
-def _stream(device):
-    return _capi.current_stream(device)
+_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
+def _launch(device, fn, name, *args):
+    """``fn(*args, current stream of device)`` with the device current; without the context manager (~5 us) when it already is."""
+    idx = device.index
+    if _RAW_STREAM is not None and idx is not None and torch.cuda.current_device() == idx:
+        status = fn(*args, _RAW_STREAM(idx))
+    else:
+        with torch.cuda.device(device):
+            status = fn(*args, _capi.current_stream(device))
+    if status != 0:
+        _capi.check(status, name)
 
 
 class BaseNormalizer:
@@ -148,6 +168,10 @@ class MeanStdNormalizer(BaseNormalizer):
     def _planes(self, x):
         """(planes pointer tensor, ld, n): zero copy for an [N, d] view of SoA planes, else one transposing copy."""
         d = self.rms.d
+        if type(x) is torch.Tensor and x.dtype == torch.float32 and x.ndim == 2 and x.device == self.device and x.shape[1] == d:
+            n = x.shape[0]                                                  # the per-step case: env.step()'s obs
+            if n > 0 and x.stride(0) == 1 and (d == 1 or x.stride(1) >= n):
+                return x, (x.stride(1) if d > 1 else n), n
         x = torch.as_tensor(x, device=self.device)
         if x.dtype != torch.float32:
             x = x.to(torch.float32)
@@ -180,13 +204,9 @@ class MeanStdNormalizer(BaseNormalizer):
                   and out.shape[0] == d and out.shape[1] >= n and out.device == xv.device):
             raise ValueError('[ERROR] out must be a contiguous float32 (%d, ld >= %d) device tensor' % (d, n))
         ld_y = out.shape[1]
-        state_in, state_out = self.rms._records(not self.read_only)
-        with torch.cuda.device(self.device):
-            _capi.check(self.lib.scg_mean_std_normalize(xv.data_ptr(), out.data_ptr(), d, ld_x, ld_y, n,
-                                                        state_in.data_ptr(), _capi.ptr(state_out),
-                                                        self.rms._moments.data_ptr(), float(self.clip),
-                                                        float(self.epsilon), _stream(self.device)),
-                        'scg_mean_std_normalize')
+        state_in, state_out = self.rms._record_ptrs(not self.read_only)
+        _launch(self.device, self.lib.scg_mean_std_normalize, 'scg_mean_std_normalize', xv.data_ptr(), out.data_ptr(), d, ld_x, ld_y, n,
+                state_in, state_out, self.rms._moments_ptr, float(self.clip), float(self.epsilon))
         return out[:, :n].T
 
     def state_dict(self):
@@ -212,14 +232,18 @@ class RewardStdNormalizer(MeanStdNormalizer):
     def __call__(self, x, dones, out=None):
         """``out`` (optional): a contiguous float32 [>= N] device tensor that receives the normalised rewards (e.g. row t of a
         rollout buffer's reward planes); its [N] head is returned."""
-        x = torch.as_tensor(x, dtype=torch.float32, device=self.device).reshape(-1).contiguous()
+        dev = self.device
+        if not (type(x) is torch.Tensor and x.dtype == torch.float32 and x.ndim == 1 and x.device == dev and x.is_contiguous()):
+            x = torch.as_tensor(x, dtype=torch.float32, device=dev).reshape(-1).contiguous()
         n = x.shape[0]
         if n == 0:
             return x
-        dones = torch.as_tensor(dones, device=self.device).reshape(-1)
-        if dones.dtype not in (torch.bool, torch.uint8):
-            dones = dones != 0
-        dones = dones.contiguous()
+        if not (type(dones) is torch.Tensor and dones.dtype in (torch.bool, torch.uint8) and dones.ndim == 1 and dones.device == dev
+                and dones.is_contiguous()):                    # (the per-step case, env.step()'s rew / done, skips both conversions)
+            dones = torch.as_tensor(dones, device=dev).reshape(-1)
+            if dones.dtype not in (torch.bool, torch.uint8):
+                dones = dones != 0
+            dones = dones.contiguous()
         if not self.read_only and self.ret is None:
             self.ret = torch.zeros(n, dtype=torch.float32, device=self.device)
         if out is None:
@@ -227,14 +251,11 @@ class RewardStdNormalizer(MeanStdNormalizer):
         elif not (isinstance(out, torch.Tensor) and out.dtype == torch.float32 and out.ndim == 1 and out.is_contiguous()
                   and out.shape[0] >= n and out.device == x.device):
             raise ValueError('[ERROR] out must be a contiguous float32 (>= %d,) device tensor' % n)
-        state_in, state_out = self.rms._records(not self.read_only)
-        with torch.cuda.device(self.device):
-            _capi.check(self.lib.scg_reward_normalize(x.data_ptr(), dones.data_ptr(), _capi.ptr(self.ret), out.data_ptr(),
-                                                      n, state_in.data_ptr(), _capi.ptr(state_out),
-                                                      self.rms._moments.data_ptr(), float(self.gamma), float(self.clip),
-                                                      float(self.epsilon), int(self.legacy_index_reset),
-                                                      _stream(self.device)), 'scg_reward_normalize')
-        return out[:n]
+        state_in, state_out = self.rms._record_ptrs(not self.read_only)
+        _launch(dev, self.lib.scg_reward_normalize, 'scg_reward_normalize', x.data_ptr(), dones.data_ptr(),
+                None if self.ret is None else self.ret.data_ptr(), out.data_ptr(), n, state_in, state_out, self.rms._moments_ptr,
+                float(self.gamma), float(self.clip), float(self.epsilon), int(self.legacy_index_reset))
+        return out if out.shape[0] == n else out[:n]
 
 
 class RescaleNormalizer(BaseNormalizer):
