@@ -863,7 +863,11 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         float x[NX], a_raw[NU], xlo[NLO];
 #pragma unroll
         for (int j = 0; j < NX; ++j) x[j] = cur.x[j];
-        if (FUSED && kstep > 0) {
+#ifndef SCG_FUSED_ACTION_AHEAD
+#define SCG_FUSED_ACTION_AHEAD 1   // 1: a fused rollout loads step k + 1's action BEFORE step k's sink stores are issued.  The vector
+#endif                             // memory counter retires in order: a load issued behind the 14 stores of a step with a sink is
+                                   // waited for with vmcnt(0), i.e. together with the write acknowledgements of all of them
+        if (FUSED && !SCG_FUSED_ACTION_AHEAD && kstep > 0) {
             const float* act = io.action + (int64_t)(kstep % ro.period) * ro.stride;
 #pragma unroll
             for (int j = 0; j < NU; ++j) a_raw[j] = ldp(PL(act, j), i4);
@@ -1133,6 +1137,12 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         // ---- after_step (benchmark_env.py:422-463)
         const int t1 = t + 1;
         bool violated = false;
+        float a_next[NU];
+        if (FUSED && SCG_FUSED_ACTION_AHEAD && !last) {
+            const float* act = io.action + (int64_t)((kstep + 1) % ro.period) * ro.stride;
+#pragma unroll
+            for (int j = 0; j < NU; ++j) a_next[j] = ldp(PL(act, j), i4);
+        }
         if (has_con) {
             float v[NV];
 #pragma unroll
@@ -1298,6 +1308,10 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
 #pragma unroll
             for (int j = 0; j < NX; ++j) cur.x[j] = x[j];
             cur.t = t_out; cur.epr = epr; cur.epl = epl;
+            if (FUSED && SCG_FUSED_ACTION_AHEAD) {
+#pragma unroll
+                for (int j = 0; j < NU; ++j) cur.a_raw[j] = a_next[j];
+            }
         }
 
         // ---- _get_observation + extend_obs (quadrotor.py:878-884, benchmark_env.py:406-420)
