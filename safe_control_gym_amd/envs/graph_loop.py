@@ -26,8 +26,17 @@ class CapturedLoop:
         for k in range(warmup):                      # eager: lazy initialisation (queues, events, torch's kernels and workspaces)
             body(k)
         torch.cuda.synchronize()
-        for e in self.envs:
-            e._begin_capture()
+        from safe_control_gym_amd.math_and_models.normalization import live_trackers
+        trackers = [(r, r._cur) for r in live_trackers()]
+        begun = []
+        try:
+            for e in self.envs:
+                e._begin_capture()
+                begun.append(e)
+        except Exception:
+            for e in begun:                          # an env that refused (fresh outputs, an adversary): the others leave recording mode
+                e._end_capture()
+            raise
         self.graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -48,6 +57,16 @@ class CapturedLoop:
                 gc.enable()
             self.serials = [e._end_capture() for e in self.envs]
         torch.cuda.current_stream().wait_stream(side)
+        # host-side state that alternates per call must have come round: a replay runs no Python, so the nodes of the NEXT replay start
+        # from the statistics record the recording started from
+        odd = [r for r, cur in trackers if r._cur != cur]
+        if odd:
+            for r in odd:
+                r._cur = 1 - r._cur                  # nothing ran: back to the record the recording started from
+            self.graph = None
+            raise ValueError('[ERROR] capture_loop(): %d running-statistics tracker(s) were updated an odd number of times in the recorded '
+                             'stretch; their records are double-buffered, so a replayable stretch holds an even number of updating normaliser '
+                             'calls (an even number of steps with one call per step).' % len(odd))
 
     def replay(self):
         for e in self.envs:

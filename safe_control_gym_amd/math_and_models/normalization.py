@@ -13,6 +13,7 @@ Observations are taken zero-copy when they are the engine's own ``[N, d]`` view 
 (``env.step()``'s obs: stride (1, ld)); any other tensor is transposed into planes first.
 """
 import math
+import weakref
 
 import numpy as np
 import torch
@@ -23,6 +24,15 @@ from safe_control_gym_amd import _capi
 def normalize_angle(x):
     """Wraps input angle to [-pi, pi] (normalization.py:10-14)."""
     return ((x + math.pi) % (2 * math.pi)) - math.pi
+
+
+_LIVE_TRACKERS = weakref.WeakSet()
+
+
+def live_trackers():
+    """Every RunningMeanStd alive in this process (envs/graph_loop.py checks that a recorded stretch leaves each one's double-buffered
+    record where it found it)."""
+    return list(_LIVE_TRACKERS)
 
 
 class RunningMeanStd:
@@ -42,6 +52,7 @@ class RunningMeanStd:
         self._rec_ptr = (self._state[0].data_ptr(), self._state[1].data_ptr())
         self._moments_ptr = self._moments.data_ptr()
         self.device = self._state.device                        # with its index: the launches check the current device against it
+        _LIVE_TRACKERS.add(self)
 
     # the reference's attributes, as views of the current record
     @property

@@ -467,6 +467,39 @@ def test_captured_loop_replays_equal_eager_stepping(gpu, tier):
     venv.close()
 
 
+def test_capture_loop_refusals_leave_the_envs_usable(gpu):
+    """A recorded stretch that cannot be replayed is refused when it is recorded, and the env steps eagerly afterwards as if nothing
+    had happened: (a) an odd number of updating normaliser calls (the statistics records are double-buffered on the host);
+    (b) a shard with fresh per-step outputs next to one that steps in place."""
+    from safe_control_gym_amd.envs.graph_loop import capture_loop
+    from safe_control_gym_amd.math_and_models.normalization import MeanStdNormalizer
+    kw = _common(dict(quad_type=2, task='stabilization', cost='rl_reward', info_level='minimal'))
+    env, twin = scg.make('quadrotor', num_envs=512, **kw), scg.make('quadrotor', num_envs=512, **kw)
+    env.reset(); twin.reset()
+    act = torch.as_tensor(env.action_space.sample(512), device='cuda', dtype=torch.float32)
+    norm = MeanStdNormalizer(shape=(env.obs_dim,))
+    planes = torch.empty((env.obs_dim, env.plane_stride), device='cuda')
+
+    def body(k):
+        obs, _, _, _ = env.step(act)
+        norm(obs, out=planes)
+    with pytest.raises(ValueError, match='odd number'):
+        capture_loop(env, body, 3, warmup=0)
+    cur = norm.rms._cur
+    loop = capture_loop(env, body, 4, warmup=0)                 # an even stretch is fine, and starts from the same record
+    assert norm.rms._cur == cur
+    loop.replay()
+    for _ in range(4):
+        o2 = twin.step(act)[0]
+    _same(env.step(act)[0], twin.step(act)[0], 'the step after a refused and a replayed recording')
+    fresh = scg.make('quadrotor', num_envs=512, **_common(dict(quad_type=2, task='stabilization', cost='rl_reward')))
+    fresh.reset()
+    with pytest.raises(ValueError, match='steps in place'):
+        capture_loop([env, fresh], lambda k: (env.step(act), fresh.step(act)), 2, warmup=0)
+    _same(env.step(act)[0], twin.step(act)[0], 'the step after a refused two-env recording')   # env left recording mode again
+    env.close(); twin.close(); fresh.close()
+
+
 BASELINE_SIZES = {
     'c4_2p20': ('quadrotor', 1 << 20, dict(quad_type=3, task='traj_tracking', cost='quadratic', info_level='minimal', episode_len_sec=5)),
     'c3_2p18': ('quadrotor', 1 << 18, dict(quad_type=2, task='stabilization', cost='rl_reward', constraints=C3_CONSTRAINTS,
