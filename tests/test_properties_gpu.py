@@ -101,6 +101,48 @@ def test_c5_total_size_eight_shards_reproduce_the_8m_batch(gpu):
     assert torch.equal(torch.cat(gathered), ret_full)               # what the all-gather of the 8 ranks assembles
 
 
+def test_lane_offsets_up_to_the_documented_limit(gpu):
+    """The kernels address a plane with a wave-uniform base and ONE 32-bit byte offset per lane; the C ABI therefore admits n <= 2^30 envs
+    per device (byte offsets up to 2^32 - 4).  CartPole at n = 2^30 - 192 (ragged: not a multiple of the workgroup), ~40 GB of planes:
+    env.step() is ONE launch over the whole batch (offsets beyond 2^31 bytes in the upper half), rollout() the two half-batch queues.
+    Small shards built with env_index_base reproduce their slices -- the start, the 2^31-byte boundary (env 2^29), the ragged end -- bit
+    for bit, so every lane up there read and wrote its own env."""
+    n = (1 << 30) - 192
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * (1 << 30):
+        pytest.skip('needs ~60 GB of free device memory')
+    kw = dict(device='cuda', seed=5, ctrl_freq=50, pyb_freq=50, randomized_init=True, task='stabilization', cost='quadratic', info_level='minimal',
+              episode_len_sec=0.1)                     # 5-step episodes: auto-resets (Philox keyed by the global env index) inside the run
+    big = scg.make('cartpole', num_envs=n, **kw)
+    big.reset()
+    ld = big.plane_stride
+    acts = torch.empty((2, 1, ld), device='cuda')
+    lane = torch.arange(ld, device='cuda', dtype=torch.float32)
+    acts[0, 0] = torch.sin(lane * 1e-3) * 5.0
+    acts[1, 0] = torch.cos(lane * 7e-4) * 5.0
+    del lane
+    for k in range(4):
+        big.step(acts[k % 2])                          # lone launches over the whole batch
+    big.rollout(acts, steps=4)                         # two queues, serials 4 .. 7
+    windows = [(0, 4096), ((1 << 29) - 2048, (1 << 29) + 2048), (n - 4096, n)]
+    got = [(big.state_soa[:, lo:hi].clone(), big.ctrl_step_counter[lo:hi].clone()) for lo, hi in windows]
+    assert int((big.ctrl_step_counter[:1 << 20] < 8).sum()) > 0            # auto-resets happened
+    big.close()
+    del big
+    torch.cuda.empty_cache()
+    for (lo, hi), (state, t) in zip(windows, got):
+        small = scg.make('cartpole', num_envs=hi - lo, env_index_base=lo, **kw)
+        small.reset()
+        a = torch.zeros((2, 1, small.plane_stride), device='cuda')
+        a[:, :, :hi - lo] = acts[:, :, lo:hi]
+        for k in range(4):
+            small.step(a[k % 2])
+        small.rollout(a, steps=4)
+        assert torch.equal(small.state_soa, state), (lo, hi)
+        assert torch.equal(small.ctrl_step_counter, t), (lo, hi)
+        small.close()
+
+
 def test_determinism_and_shard_invariance(gpu):
     """Same seed -> bit-identical rollouts; a shard built with env_index_base reproduces the matching slice of
     the big batch bit for bit (per-env Philox streams are keyed by the GLOBAL env index)."""
