@@ -24,6 +24,11 @@ Groups written (inputs and the reference's outputs, float64):
                                                                                  envs/env_wrappers/record_episode_statistics.py:92-169
   discretize     discretize_linear_system (exact and Euler; scipy.linalg.expm is importable)   controllers/mpc/mpc_utils.py:24-54
   normalization  RunningMeanStd, MeanStdNormalizer, RewardStdNormalizer                   math_and_models/normalization.py:17-190
+  vehicle        BaseAviary._parse_urdf_parameters on the reference's own assets/cf2x.urdf (xml.etree: stdlib), the "Compute constants"
+                 statements of BaseAviary.__init__, and the NumPy statements of the explicit rigid-body model BaseAviary._dynamics
+                 (forces, mixer torques, gyroscopic term, J_INV, world-frame acceleration), of _physics (forces, yaw torque), of
+                 _ground_effect and of _drag, each cut before / after its PyBullet calls
+                                                            envs/gym_pybullet_drones/base_aviary.py:100-147,412-423,437-496,522-558
 
 Run in the build container only (the reference never travels to the GPU box):
     python tests/golden/make_golden_reference_numpy.py
@@ -227,6 +232,45 @@ def GENERAL_CONSTRAINTS():
             'bounded_constraint': NS['BoundedConstraint'], 'default_constraint': NS['DefaultConstraint'],
             'symmetric_state': NS['SymmetricStateConstraint']}
 
+
+# -- the vehicle model as base_aviary.py states it in NumPy (everything between its PyBullet calls) ----------------------------------
+import xml.etree.ElementTree as etxml                      # base_aviary.py:10 imports it under this name
+NS['etxml'] = etxml
+SOURCES += top_level('envs/gym_pybullet_drones/base_aviary.py', ['DroneModel'], NS)
+SOURCES += methods('envs/gym_pybullet_drones/base_aviary.py', 'BaseAviary', ['_parse_urdf_parameters'], NS)
+
+
+def _lines(lo, hi):
+    return lambda stmt: lo <= stmt.lineno and stmt.end_lineno <= hi
+
+
+def _self_attr_assign(names):
+    return lambda stmt: any(_assigns_self(stmt, a) for a in names)
+
+
+SOURCES += method_statements('envs/gym_pybullet_drones/base_aviary.py', 'BaseAviary', '__init__',
+                             _self_attr_assign(('GRAVITY', 'HOVER_RPM', 'MAX_RPM', 'MAX_THRUST', 'MAX_XY_TORQUE', 'MAX_Z_TORQUE',
+                                                'GND_EFF_H_CLIP')), 'vehicle_constants', NS)
+
+
+def _assigns_local(names):
+    return lambda stmt: isinstance(stmt, ast.Assign) and any(isinstance(t, ast.Name) and t.id in names for t in stmt.targets)
+
+
+# _dynamics: from `forces = ...` to `no_pybullet_dyn_accs = ...` (the state reads above use self.*, `rotation` comes from PyBullet; the
+# statements below update the state and hand it to PyBullet).  `rpm`, `rotation`, `rpy_rates` are read as globals of the namespace.
+SOURCES += method_statements('envs/gym_pybullet_drones/base_aviary.py', 'BaseAviary', '_dynamics',
+                             lambda st: (isinstance(st, ast.If) and 'DRONE_MODEL' in ast.unparse(st.test)) or
+                             _assigns_local(('forces', 'thrust', 'thrust_world_frame', 'force_world_frame', 'z_torques', 'z_torque',
+                                             'torques', 'rpy_rates_deriv', 'no_pybullet_dyn_accs'))(st),
+                             'explicit_dynamics', NS, returns=('no_pybullet_dyn_accs', 'rpy_rates_deriv'))
+# _physics (the path Physics.PYB runs every sub-step): per-propeller forces and the yaw torque handed to PyBullet
+SOURCES += method_statements('envs/gym_pybullet_drones/base_aviary.py', 'BaseAviary', '_physics', _assigns_local(('forces', 'torques', 'z_torque')),
+                             'pyb_forces_and_yaw_torque', NS, returns=('forces', 'z_torque'))
+SOURCES += method_statements('envs/gym_pybullet_drones/base_aviary.py', 'BaseAviary', '_ground_effect',
+                             _assigns_local(('prop_heights', 'gnd_effects')), 'ground_effect_forces', NS, returns='gnd_effects')
+SOURCES += method_statements('envs/gym_pybullet_drones/base_aviary.py', 'BaseAviary', '_drag', _assigns_local(('drag_factors', 'drag')),
+                             'drag_force', NS, returns='drag')
 
 # constants of the reference's vehicle (assets/cf2x.urdf:5,12-13; base_aviary.py:90,100-147)
 CF = dict(MASS=0.03454, GRAVITY_ACC=9.8, KF=3.16e-10, KM=7.94e-12, PWM2RPM_SCALE=0.2685, PWM2RPM_CONST=4070.3, MIN_PWM=20000,
@@ -797,6 +841,76 @@ def gen_normalization(rng):
                                                     'RewardStdNormalizer(gamma=0.95, clip=5.0), 6 calls (legacy index reset semantics)')
 
 
+def gen_vehicle():
+    """The vehicle's constants and its explicit NumPy rigid-body statements, executed."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(20261005)
+    h = Holder(GRAVITY_ACC=9.8, DRONE_MODEL=NS['DroneModel'].CF2X)                       # base_aviary.py:90, :64
+    bind(h, NS, ['_parse_urdf_parameters'])
+    names = ('MASS', 'L', 'THRUST2WEIGHT_RATIO', 'J', 'J_INV', 'KF', 'KM', 'COLLISION_H', 'COLLISION_R', 'COLLISION_Z_OFFSET',
+             'MAX_SPEED_KMH', 'GND_EFF_COEFF', 'PROP_RADIUS', 'DRAG_COEFF', 'DW_COEFF_1', 'DW_COEFF_2', 'DW_COEFF_3', 'PWM2RPM_SCALE',
+             'PWM2RPM_CONST', 'MIN_PWM', 'MAX_PWM')                                        # the order of base_aviary.py:100-120
+    values = h._parse_urdf_parameters(os.path.join(REF, 'envs/gym_pybullet_drones/assets/cf2x.urdf'))
+    for k, v in zip(names, values):
+        setattr(h, k, v)
+        put('vehicle/urdf/' + k, v)
+    types.MethodType(NS['vehicle_constants'], h)()
+    for k in ('GRAVITY', 'HOVER_RPM', 'MAX_RPM', 'MAX_THRUST', 'MAX_XY_TORQUE', 'MAX_Z_TORQUE', 'GND_EFF_H_CLIP'):
+        put('vehicle/const/' + k, getattr(h, k))
+    # explicit dynamics: random motor speeds around hover, attitudes up to +-1.2 rad, body rates up to +-8 rad/s
+    n = 64
+    rpm = h.HOVER_RPM * rng.uniform(0.5, 1.45, size=(n, 4))
+    rpy = rng.uniform(-1.2, 1.2, size=(n, 3))
+    rates = rng.uniform(-8.0, 8.0, size=(n, 3))
+    rot = Rotation.from_euler('xyz', rpy).as_matrix()          # extrinsic x-y-z = Rz(yaw) Ry(pitch) Rx(roll): what PyBullet's
+    acc, rdot = [], []                                          # getMatrixFromQuaternion(getQuaternionFromEuler(rpy)) returns
+    fn = types.MethodType(NS['explicit_dynamics'], h)
+    for i in range(n):
+        NS['rpm'], NS['rotation'], NS['rpy_rates'] = rpm[i], rot[i], rates[i]
+        a, r = fn()
+        acc.append(a); rdot.append(r)
+    put('vehicle/dynamics/rpm', rpm); put('vehicle/dynamics/rpy', rpy); put('vehicle/dynamics/rates', rates)
+    put('vehicle/dynamics/rotation', rot); put('vehicle/dynamics/acc', acc); put('vehicle/dynamics/rates_deriv', rdot)
+    fn = types.MethodType(NS['pyb_forces_and_yaw_torque'], h)
+    forces, ztq = [], []
+    for i in range(n):
+        NS['rpm'] = rpm[i]
+        f, z = fn()
+        forces.append(f); ztq.append(z)
+    put('vehicle/physics/forces', forces); put('vehicle/physics/z_torque', ztq)
+    # ground effect: per-propeller forces for propeller heights from below the clip to 1 m
+    heights = np.concatenate([rng.uniform(0.0, 0.05, size=(16, 4)), rng.uniform(0.05, 1.0, size=(16, 4))])
+    gnd = []
+    fn = types.MethodType(NS['ground_effect_forces'], h)
+    for i in range(heights.shape[0]):
+        links = np.empty((5, 1), dtype=object)                 # getLinkStates(...)[i][0] = world position of link i (4 propellers + CoM)
+        for q in range(4):
+            links[q, 0] = (0.0, 0.0, float(heights[i, q]))
+        links[4, 0] = (0.0, 0.0, float(heights[i].mean()))
+        NS['rpm'], NS['link_states'] = rpm[i], links
+        gnd.append(fn())
+    put('vehicle/gnd/rpm', rpm[:heights.shape[0]]); put('vehicle/gnd/prop_heights', heights); put('vehicle/gnd/forces', gnd)
+    # drag: link-frame force for random velocities
+    vel = rng.uniform(-3.0, 3.0, size=(n, 3))
+    drag = []
+    fn = types.MethodType(NS['drag_force'], h)
+    NS['nth_drone'] = 0
+    for i in range(n):
+        NS['rpm'], NS['base_rot'] = rpm[i], rot[i]
+        h.vel = vel[i][None, :]
+        drag.append(fn())
+    put('vehicle/drag/vel', vel); put('vehicle/drag/link_frame_force', drag)
+    for k in ('rpm', 'rotation', 'rpy_rates', 'link_states', 'base_rot', 'nth_drone'):
+        NS.pop(k, None)
+    MANIFEST['groups']['vehicle'] = dict(note='urdf/*: _parse_urdf_parameters(assets/cf2x.urdf) in the order of base_aviary.py:100-120; const/*: '
+                                              'the "Compute constants" statements (:138-147); dynamics/*: statements :540-558 of _dynamics for 64 '
+                                              'samples -- `rotation` (PyBullet\'s getMatrixFromQuaternion in the reference) is an INPUT, computed '
+                                              'by scipy.spatial.transform.Rotation.from_euler("xyz", rpy); acc = no_pybullet_dyn_accs, rates_deriv = '
+                                              'rpy_rates_deriv; physics/*: the forces / z_torque statements of _physics (:420-423) for the same rpm; gnd/*: the prop_heights / clip / gnd_effects statements of _ground_effect (:455-461) for given '
+                                              'propeller positions (`link_states`, PyBullet\'s getLinkStates in the reference, is an INPUT); drag/*: the two NumPy statements of _drag (:489-491), the force PyBullet then '
+                                              'applies in the LINK frame')
+
+
 def main():
     rng = np.random.default_rng(20241004)
     gen_motor_map(rng)
@@ -813,6 +927,7 @@ def main():
     gen_spaces(rng)            # (appended; draws nothing)
     gen_randomization(rng)     # (appended; its own RandomState)
     gen_ppo_buffer(np.random.default_rng(77))     # (appended; its own generator)
+    gen_vehicle()              # (appended; its own generator)
     OUT['manifest'] = np.array(json.dumps(MANIFEST))
     np.savez_compressed(os.path.join(HERE, 'reference_numpy.npz'), **OUT)
     print('wrote %d arrays, %d reference symbols executed' % (len(OUT) - 1, len(SOURCES)))

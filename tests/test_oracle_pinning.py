@@ -29,6 +29,28 @@ def zeros_sampler(i, e):
     return np.zeros(12)
 
 
+# ---- (0) the three models are one rigid body: the 1-D and 2-D restatements (quadrotor.py:594-621) equal the 3-D one (:624-674, whose
+#      rigid-body terms are pinned to the reference's executed BaseAviary._dynamics: tests/test_reference_pins.py) on their subspaces
+def test_planar_and_vertical_models_are_restrictions_of_the_3d_model():
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        # 1-D: level attitude, the thrust T spread over the four motors
+        z, zd, T = rng.uniform(0, 2), rng.uniform(-2, 2), rng.uniform(0.1, 0.6)
+        x3 = [0.0] * 12
+        x3[4], x3[5] = z, zd
+        full = rm.f_quad3d(x3, [T / 4] * 4, P)
+        assert np.allclose(rm.f_quad1d([z, zd], [T], P), [full[4], full[5]], rtol=1e-14, atol=1e-14)
+        assert np.allclose([full[k] for k in (0, 1, 2, 3, 6, 7, 8, 9, 10, 11)], 0.0, atol=1e-12)          # nothing leaves the z axis
+        # 2-D: pitch only; T1 = f1 + f4, T2 = f2 + f3 (the pairs whose difference is the pitch moment of quadrotor.py:668)
+        x2 = rng.uniform(-1, 1, size=6)
+        T1, T2 = rng.uniform(0.05, 0.3, size=2)
+        x3 = [0.0] * 12
+        x3[0], x3[1], x3[4], x3[5], x3[7], x3[10] = x2
+        full = rm.f_quad3d(x3, [T1 / 2, T2 / 2, T2 / 2, T1 / 2], P)
+        assert np.allclose(rm.f_quad2d(list(x2), [T1, T2], P), [full[0], full[1], full[4], full[5], full[7], full[10]], rtol=1e-13, atol=1e-13)
+        assert np.allclose([full[k] for k in (2, 3, 6, 8, 9, 11)], 0.0, atol=1e-12)                           # and nothing leaves the x-z plane
+
+
 # ---- (1) hover fixed point: level attitude, u = m g / nu each -> x_dot = 0 (quadrotor.py:262,328-329)
 @pytest.mark.parametrize('system', [1, 2, 3])
 def test_kat_hover_fixed_point(system):

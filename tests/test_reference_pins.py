@@ -35,7 +35,12 @@ def test_manifest_lists_the_executed_reference_symbols():
                  ('safe_control_gym/envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor._set_observation_space statements'),
                  ('safe_control_gym/envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor._set_action_space statements'),
                  ('safe_control_gym/envs/benchmark_env.py', 'BenchmarkEnv._randomize_values_by_info'),
-                 ('safe_control_gym/controllers/ppo/ppo_utils.py', 'PPOBuffer')):
+                 ('safe_control_gym/controllers/ppo/ppo_utils.py', 'PPOBuffer'),
+                 ('safe_control_gym/envs/gym_pybullet_drones/base_aviary.py', 'BaseAviary._parse_urdf_parameters'),
+                 ('safe_control_gym/envs/gym_pybullet_drones/base_aviary.py', 'BaseAviary._dynamics statements'),
+                 ('safe_control_gym/envs/gym_pybullet_drones/base_aviary.py', 'BaseAviary._physics statements'),
+                 ('safe_control_gym/envs/gym_pybullet_drones/base_aviary.py', 'BaseAviary._ground_effect statements'),
+                 ('safe_control_gym/envs/gym_pybullet_drones/base_aviary.py', 'BaseAviary._drag statements')):
         assert want in syms
     assert all(s['lines'][0] <= s['lines'][1] for s in MANIFEST['sources'])
 
@@ -43,6 +48,93 @@ def test_manifest_lists_the_executed_reference_symbols():
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU: the oracle (and the package's host-side tables) against the reference's output
 # ---------------------------------------------------------------------------------------------------------------------
+def test_vehicle_constants_match_the_reference_urdf_parser():
+    """The constants the oracle and the package carry as literals == what BaseAviary._parse_urdf_parameters (base_aviary.py:612-651,
+    executed) reads from the reference's assets/cf2x.urdf, and the derived constants of base_aviary.py:138-147."""
+    from oracle import ref_model
+    from safe_control_gym_amd.envs import quadrotor as product
+    urdf = {k.split('/')[-1]: G[k] for k in G.files if k.startswith('vehicle/urdf/')}
+    for table in (ref_model.CF2X, product.CF2X):
+        mass_key = 'M' if 'M' in table else 'MASS'
+        assert table[mass_key] == float(urdf['MASS'])
+        for k in ('L', 'KF', 'KM', 'PWM2RPM_SCALE', 'PWM2RPM_CONST', 'MIN_PWM', 'MAX_PWM', 'THRUST2WEIGHT_RATIO', 'GND_EFF_COEFF', 'PROP_RADIUS'):
+            assert table[k] == float(urdf[k]), k
+        assert [table['IXX'], table['IYY'], table['IZZ']] == np.diag(urdf['J']).tolist()
+        assert [table['DRAG_COEFF_XY'], table['DRAG_COEFF_XY'], table['DRAG_COEFF_Z']] == urdf['DRAG_COEFF'].tolist()
+    assert rel_err(ref_model.GRAVITY_ACC * ref_model.CF2X['M'], float(G['vehicle/const/GRAVITY'])) < TIGHT
+    assert rel_err(ref_model.gnd_eff_h_clip(), float(G['vehicle/const/GND_EFF_H_CLIP'])) < TIGHT
+    p = ref_model.QuadParams()
+    assert rel_err(np.diag([1 / p.ixx, 1 / p.iyy, 1 / p.izz]), G['vehicle/urdf/J_INV']) < TIGHT
+    # the hover thrust per motor (quadrotor.py:262 U_GOAL) is KF HOVER_RPM^2
+    assert rel_err(p.m * p.g / 4, p.kf * float(G['vehicle/const/HOVER_RPM']) ** 2) < TIGHT
+
+
+def _scaled_err(a, b):
+    """max |a - b| / max |b|: for forces of 1e-2 .. 1e-4 N, where helpers.rel_err (absolute below 1) would pass anything."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+def _vehicle_samples():
+    kf = float(G['vehicle/urdf/KF'])
+    rpm, rpy, rates = G['vehicle/dynamics/rpm'], G['vehicle/dynamics/rpy'], G['vehicle/dynamics/rates']
+    x = np.zeros((rpm.shape[0], 12))
+    x[:, 6:9], x[:, 9:12] = rpy, rates
+    return x, kf * rpm ** 2
+
+
+def test_oracle_rigid_body_terms_match_the_reference_explicit_dynamics():
+    """oracle.ref_model.f_quad3d (the restatement of the CasADi model, quadrotor.py:624-674) against the reference's OWN NumPy statement
+    of the same rigid body, BaseAviary._dynamics (base_aviary.py:540-558, executed): per-motor forces KF rpm^2, the X-configuration
+    mixer with its signs, the yaw couple KM rpm^2 = (KM / KF) f, torques - w x (J w), J_INV, and the world-frame acceleration
+    R [0, 0, sum f] / m - g.  The rotation matrix (PyBullet's in the reference) is SciPy's for extrinsic x-y-z Euler angles; the oracle's
+    csRotXYZ restatement equals it.  Not covered by this pin: the Euler-rate kinematics, the 1-D / 2-D models, the integrator."""
+    from oracle import ref_model
+    x, u = _vehicle_samples()
+    p = ref_model.QuadParams()
+    worst = 0.0
+    for i in range(x.shape[0]):
+        R = np.array(ref_model.rot_xyz(*x[i, 6:9]))
+        assert np.abs(R - G['vehicle/dynamics/rotation'][i]).max() < 1e-15
+        xdot = np.array(ref_model.f_quad3d(list(x[i]), list(u[i]), p))
+        worst = max(worst, rel_err(xdot[[1, 3, 5]], G['vehicle/dynamics/acc'][i]), rel_err(xdot[9:12], G['vehicle/dynamics/rates_deriv'][i]))
+    assert worst < TIGHT, worst
+    # BaseAviary._physics (:420-423, the PyBullet path): the inputs of the symbolic model ARE its per-propeller forces, and the yaw
+    # moment gamma (f1 - f2 + f3 - f4) of quadrotor.py:669 is its z_torque (at zero body rates the yaw acceleration is z_torque / Izz)
+    assert _scaled_err(u, G['vehicle/physics/forces']) < TIGHT
+    still = np.zeros(12)
+    yaw_acc = np.array([ref_model.f_quad3d(list(still), list(u[i]), p)[11] for i in range(u.shape[0])])
+    assert _scaled_err(yaw_acc * p.izz, G['vehicle/physics/z_torque']) < TIGHT
+
+
+def test_oracle_aero_terms_match_the_reference_statements():
+    """Ground effect and drag as the oracle restates them for the analytic model against the NumPy statements of
+    BaseAviary._ground_effect (:455-461) and BaseAviary._drag (:488-490), executed.  The reference hands these forces to PyBullet (per
+    propeller in the link frame; the drag in the link frame of the base); how Bullet integrates them stays unpinned."""
+    from oracle import ref_model
+    p = ref_model.QuadParams()
+    kf = float(G['vehicle/urdf/KF'])
+    # ground effect: extra thrust of propeller q at height h_q, level attitude (then every propeller sits at the height of the CoM)
+    rpm, heights, forces = G['vehicle/gnd/rpm'], G['vehicle/gnd/prop_heights'], G['vehicle/gnd/forces']
+    extra = np.zeros_like(forces)
+    for i in range(rpm.shape[0]):
+        u = list(kf * rpm[i] ** 2)
+        for q in range(4):
+            x = [0.0] * 12
+            x[4] = heights[i, q]
+            extra[i, q] = ref_model.ground_effect_thrusts(3, x, u, p)[q] - u[q]
+    assert np.abs(extra / forces - 1.0).max() < 1e-9               # (the difference of two thrusts: a few digits go to the subtraction)
+    assert forces.min() > 0 and forces.max() / forces.min() > 100   # from far above the ground to below the height clip
+    # drag: the reference's `drag` is applied with flags=LINK_FRAME, i.e. the world force is R drag
+    x, u = _vehicle_samples()
+    x[:, [1, 3, 5]] = G['vehicle/drag/vel']
+    worst = 0.0
+    for i in range(x.shape[0]):
+        world = G['vehicle/dynamics/rotation'][i] @ G['vehicle/drag/link_frame_force'][i]
+        worst = max(worst, _scaled_err(ref_model.drag_force(3, list(x[i]), list(u[i]), p), world))
+    assert worst < TIGHT, worst
+
+
 def test_ppo_buffer_matches_reference_class():
     """PPOBuffer (ppo_utils.py:282-407), executed: ring index, partial pushes, mask initialised to ones, the time-major flattening of
     get() / sample(), and the mini-batch structure of sampler() (a permutation cut into batches, the remainder kept or dropped)."""
@@ -340,6 +432,22 @@ def test_oracle_normalisers_match_reference_classes():
 # ---------------------------------------------------------------------------------------------------------------------
 # GPU: the HIP path against the reference's output
 # ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_device_model_matches_the_reference_explicit_dynamics(gpu):
+    """scg_model_eval (the device's f(x, u), csrc/scg_dynamics.h) against BaseAviary._dynamics' executed statements: translational and
+    angular accelerations of 64 random (motor speeds, attitude, body rates) samples."""
+    import torch
+    import safe_control_gym_amd as scg
+    x, u = _vehicle_samples()
+    env = scg.make('quadrotor', quad_type=3, num_envs=x.shape[0], device='cuda', seed=0)
+    env.reset()
+    xdot = env.model_dynamics(torch.as_tensor(x, dtype=torch.float32, device='cuda'),
+                              torch.as_tensor(u, dtype=torch.float32, device='cuda')).double().cpu().numpy()
+    assert rel_err(xdot[:, [1, 3, 5]], G['vehicle/dynamics/acc']) < RTOL
+    assert rel_err(xdot[:, 9:12], G['vehicle/dynamics/rates_deriv']) < RTOL
+    env.close()
+
+
 @pytest.mark.gpu
 def test_device_motor_map_matches_reference(gpu):
     """cmd2pwm -> pwm2rpm -> KF rpm^2 inside the step kernel: a 1-D quadrotor at rest accelerates with T_eff / m - g, and RK4
