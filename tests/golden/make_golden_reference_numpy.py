@@ -240,8 +240,25 @@ SOURCES += top_level('envs/gym_pybullet_drones/base_aviary.py', ['DroneModel'], 
 SOURCES += methods('envs/gym_pybullet_drones/base_aviary.py', 'BaseAviary', ['_parse_urdf_parameters'], NS)
 
 
-def _lines(lo, hi):
-    return lambda stmt: lo <= stmt.lineno and stmt.end_lineno <= hi
+def class_assignments(rel, cls, names, ns, prefix):
+    """The class-level assignments `names` of class `cls` (its default tables), executed unchanged; the values land in `ns` under
+    ``prefix + name``."""
+    tree, path = _tree(rel)
+    c = _find(tree.body, cls)
+    out = []
+    for n in names:
+        node = next(st for st in c.body if isinstance(st, ast.Assign) and any(isinstance(t, ast.Name) and t.id == n for t in st.targets))
+        scratch = dict(ns)
+        _exec_nodes([node], path, scratch)
+        ns[prefix + n] = scratch[n]
+        out.append((rel, '%s.%s (class attribute)' % (cls, n), node.lineno, node.end_lineno))
+    return out
+
+
+SOURCES += class_assignments('envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor',
+                             ['DISTURBANCE_MODES', 'INERTIAL_PROP_RAND_INFO', 'INIT_STATE_RAND_INFO', 'TASK_INFO'], NS, 'Quadrotor_')
+SOURCES += method_statements('envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor', '__init__', lambda st: _assigns_self(st, 'INIT_STATE_LABELS'),
+                             'init_state_labels', NS)
 
 
 def _self_attr_assign(names):
@@ -841,6 +858,18 @@ def gen_normalization(rng):
                                                     'RewardStdNormalizer(gamma=0.95, clip=5.0), 6 calls (legacy index reset semantics)')
 
 
+def gen_defaults():
+    """The default tables of the reference's Quadrotor class (class attributes and one __init__ statement), executed; stored as JSON."""
+    h = Holder()
+    types.MethodType(NS['init_state_labels'], h)()
+    MANIFEST['groups']['defaults'] = dict(
+        INIT_STATE_LABELS={str(int(k)): v for k, v in h.INIT_STATE_LABELS.items()},
+        INIT_STATE_RAND_INFO=NS['Quadrotor_INIT_STATE_RAND_INFO'], INERTIAL_PROP_RAND_INFO=NS['Quadrotor_INERTIAL_PROP_RAND_INFO'],
+        TASK_INFO=NS['Quadrotor_TASK_INFO'], DISTURBANCE_MODES=NS['Quadrotor_DISTURBANCE_MODES'],
+        note='Quadrotor.INIT_STATE_RAND_INFO / INERTIAL_PROP_RAND_INFO / TASK_INFO / DISTURBANCE_MODES (class attributes, quadrotor.py:31-146) and '
+             'self.INIT_STATE_LABELS (quadrotor.py:207-212), as the executed statements define them')
+
+
 def gen_vehicle():
     """The vehicle's constants and its explicit NumPy rigid-body statements, executed."""
     from scipy.spatial.transform import Rotation
@@ -928,6 +957,7 @@ def main():
     gen_randomization(rng)     # (appended; its own RandomState)
     gen_ppo_buffer(np.random.default_rng(77))     # (appended; its own generator)
     gen_vehicle()              # (appended; its own generator)
+    gen_defaults()             # (appended; draws nothing)
     OUT['manifest'] = np.array(json.dumps(MANIFEST))
     np.savez_compressed(os.path.join(HERE, 'reference_numpy.npz'), **OUT)
     print('wrote %d arrays, %d reference symbols executed' % (len(OUT) - 1, len(SOURCES)))

@@ -39,6 +39,7 @@ def test_manifest_lists_the_executed_reference_symbols():
                  ('safe_control_gym/envs/gym_pybullet_drones/base_aviary.py', 'BaseAviary._parse_urdf_parameters'),
                  ('safe_control_gym/envs/gym_pybullet_drones/base_aviary.py', 'BaseAviary._dynamics statements'),
                  ('safe_control_gym/envs/gym_pybullet_drones/base_aviary.py', 'BaseAviary._physics statements'),
+                 ('safe_control_gym/envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor.INIT_STATE_RAND_INFO (class attribute)'),
                  ('safe_control_gym/envs/gym_pybullet_drones/base_aviary.py', 'BaseAviary._ground_effect statements'),
                  ('safe_control_gym/envs/gym_pybullet_drones/base_aviary.py', 'BaseAviary._drag statements')):
         assert want in syms
@@ -67,6 +68,20 @@ def test_vehicle_constants_match_the_reference_urdf_parser():
     assert rel_err(np.diag([1 / p.ixx, 1 / p.iyy, 1 / p.izz]), G['vehicle/urdf/J_INV']) < TIGHT
     # the hover thrust per motor (quadrotor.py:262 U_GOAL) is KF HOVER_RPM^2
     assert rel_err(p.m * p.g / 4, p.kf * float(G['vehicle/const/HOVER_RPM']) ** 2) < TIGHT
+
+
+def test_default_tables_match_the_reference_class_attributes():
+    """The default randomisation ranges, task description, disturbance modes and init-state labels of the package's Quadrotor and of
+    the oracle == the reference's class attributes and its INIT_STATE_LABELS statement (quadrotor.py:31-146,207-212, executed)."""
+    from oracle import ref_env, ref_trajectory
+    from safe_control_gym_amd.envs.quadrotor import Quadrotor
+    d = GROUPS['defaults']
+    assert Quadrotor.INIT_STATE_RAND_INFO == d['INIT_STATE_RAND_INFO'] == ref_env.QUAD_INIT_STATE_RAND_INFO
+    assert Quadrotor.INERTIAL_PROP_RAND_INFO == d['INERTIAL_PROP_RAND_INFO']
+    assert Quadrotor.TASK_INFO == d['TASK_INFO'] == ref_trajectory.DEFAULT_TASK_INFO
+    assert {str(int(k)): v for k, v in Quadrotor._LABELS.items()} == d['INIT_STATE_LABELS']
+    assert {str(k): v for k, v in ref_env.INIT_STATE_LABELS.items() if k != 'cartpole'} == d['INIT_STATE_LABELS']
+    assert set(d['DISTURBANCE_MODES']) == {'observation', 'action', 'dynamics'}     # dims are set at run time (quadrotor.py:808-813)
 
 
 def _scaled_err(a, b):
