@@ -454,7 +454,7 @@ def test_device_model_matches_the_reference_explicit_dynamics(gpu):
     import torch
     import safe_control_gym_amd as scg
     x, u = _vehicle_samples()
-    env = scg.make('quadrotor', quad_type=3, num_envs=x.shape[0], device='cuda', seed=0)
+    env = scg.make('quadrotor', quad_type=3, num_envs=x.shape[0], device='cuda', seed=0, task='traj_tracking')
     env.reset()
     xdot = env.model_dynamics(torch.as_tensor(x, dtype=torch.float32, device='cuda'),
                               torch.as_tensor(u, dtype=torch.float32, device='cuda')).double().cpu().numpy()
