@@ -58,7 +58,9 @@ constexpr int kBlock = SCG_BLOCK;
 #ifndef SCG_DIST_WAVES
 #define SCG_DIST_WAVES 5       // ... in the float disturbance-tier instantiations (FT_DIST): 89-93 VGPRs without a spill (left alone: 112, 4 waves; 6: spills)
 #endif
-#define SCG_BOUNDS __launch_bounds__(kBlock, (COMP == 2 ? SCG_ATT_WAVES : (COMP == 1 ? SCG_COMP_WAVES : (SCG_MIN_WAVES > 0 ? SCG_MIN_WAVES : ((FT & 16u) ? SCG_DIST_WAVES : 1))))) SCG_SGPR_CAP
+// The occupancy demands hold for the one-env-per-lane form; the grid-stride form (MODE 1: only behind the grid_cap_per_cu / ref_in_lds
+// tuning knobs) carries the next iteration's addressing on top and would spill under them (64-95 VGPRs to scratch): no demand there.
+#define SCG_BOUNDS __launch_bounds__(kBlock, (MODE == 1 ? 1 : (COMP == 2 ? SCG_ATT_WAVES : (COMP == 1 ? SCG_COMP_WAVES : (SCG_MIN_WAVES > 0 ? SCG_MIN_WAVES : ((FT & 16u) ? SCG_DIST_WAVES : 1)))))) SCG_SGPR_CAP
 
 // Philox4x32-10 (Salmon et al., SC'11).  Counter layout shared with oracle/philox.py.
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
