@@ -412,3 +412,42 @@ def test_make_vec_envs_cuts_the_batch_into_pipelines():
     assert built[0].calls[-1] == 'close' and built[1].calls[-1] == 'close'
     with pytest.raises(ValueError, match='env_configs differ'):
         make_vec_envs(StubEnv, env_configs=[{'a': 1}, {'a': 2}], batch_size=8, num_pipelines=2)
+
+
+def test_no_kernel_of_the_library_spills_registers():
+    """Build-quality gate on the gfx950 code objects of the in-tree build (csrc/build.sh leaves one object per translation unit in
+    lib/obj): the metadata note of every kernel says vgpr_spill_count = 0 and no private (scratch) segment (SGPRs parked in VGPR lanes are
+    register moves, not memory, and are allowed).  A kernel
+    that spills still passes every numerics test and silently loses a third of its rate (DESIGN.md / TUNING.md: every forced occupancy
+    that spilled was slower)."""
+    import glob
+    import re
+    import subprocess
+    import tempfile
+    llvm = '/opt/rocm/lib/llvm/bin'
+    objs = sorted(glob.glob(os.path.join(ROOT, 'safe_control_gym_amd', 'lib', 'obj', '*.o')))
+    if not objs or not all(os.path.exists(os.path.join(llvm, t)) for t in ('clang-offload-bundler', 'llvm-objcopy', 'llvm-readelf')):
+        pytest.skip('needs the object files of an in-tree build and the ROCm LLVM tools')
+    kernels = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        for obj in objs:
+            fat = os.path.join(tmp, os.path.basename(obj) + '.fatbin')             # the device code travels in the .hip_fatbin section
+            subprocess.run([llvm + '/llvm-objcopy', '-O', 'binary', '--only-section=.hip_fatbin', obj, fat], check=True, capture_output=True)
+            if not os.path.exists(fat) or os.path.getsize(fat) == 0:
+                continue                                     # host-only unit
+            listed = subprocess.run([llvm + '/clang-offload-bundler', '--list', '--type=o', '--input=' + fat], capture_output=True, text=True).stdout
+            targets = [t for t in listed.split() if 'gfx950' in t]
+            if not targets:
+                continue
+            co = os.path.join(tmp, os.path.basename(obj) + '.co')
+            subprocess.run([llvm + '/clang-offload-bundler', '--unbundle', '--type=o', '--input=' + fat, '--targets=' + targets[0], '--output=' + co],
+                           check=True, capture_output=True)
+            notes = subprocess.run([llvm + '/llvm-readelf', '--notes', co], capture_output=True, text=True, check=True).stdout
+            for block in notes.split('.agpr_count')[1:]:
+                name = re.search(r'\.name:\s+(\S+)', block)
+                fields = {k: int(v) for k, v in re.findall(r'\.(vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\d+)', block)}
+                if name is None or len(fields) < 3:
+                    continue
+                kernels += 1
+                assert fields['vgpr_spill_count'] == 0 and fields['private_segment_fixed_size'] == 0, (os.path.basename(obj), name.group(1), fields)
+    assert kernels > 100                                     # the step kernel's instantiations alone are ~170
