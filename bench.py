@@ -520,18 +520,18 @@ def rl_pipeline_record(args, n, T):
         torch.where(info['TimeLimit.truncated'], tv, zeros, out=out)
 
     stages = ('policy', 'env_step', 'obs_normalizer', 'reward_normalizer', 'terminal_value', 'returns_gae')
-    box = {'obs': obs_norm(env.reset(), out=buf.obs_planes[0])}
+    box = {'obs': obs_norm(env.reset(), out=buf.obs_row(0))}
 
     def step_body(t, mark=lambda: None):
         obs = buf.obs_at(t)                    # slab t: written by the observation normaliser of step t - 1 (slab 0: buf.start)
         mark()
-        actor(obs, buf.act_planes[t]); critic(obs, buf.v[t, :, 0])
+        actor(obs, buf.act_row(t)); critic(obs, buf.v[t, :, 0])
         mark()
-        raw, rew, done, info = env.step(buf.act_planes[t], out=buf.step_out(t, obs=False, reward=False))
+        raw, rew, done, info = env.step(buf.act_row(t), out=buf.step_out(t, obs=False, reward=False))
         mark()
-        obs_norm(raw, out=buf.obs_planes[t + 1])
+        obs_norm(raw, out=buf.obs_row(t + 1))
         mark()
-        rew_norm(rew, done, out=buf.rew_planes[t])
+        rew_norm(rew, done, out=buf.rew_row(t))
         mark()
         terminal_value(info, buf.terminal_v[t, :, 0])
 

@@ -46,8 +46,8 @@ def main():
         act = actor(obs) + 0.1 * torch.randn(n, nu, device='cuda')
         v = critic(obs)
         raw, rew, done, info = env.step(act, out=buf.step_out(t, obs=False, reward=False))
-        obs_norm(raw, out=buf.obs_planes[t + 1])
-        rew_norm(rew, done, out=buf.rew_planes[t])
+        obs_norm(raw, out=buf.obs_row(t + 1))
+        rew_norm(rew, done, out=buf.rew_row(t))
         terminal_v = torch.where(info['TimeLimit.truncated'][:, None], critic(info['terminal_observation']), zeros)
         buf.act[t].copy_(act); buf.v[t].copy_(v); buf.terminal_v[t].copy_(terminal_v)      # (push() without its host-side ring index)
 
@@ -69,8 +69,8 @@ def main():
                 v = critic(obs)
                 if planes:
                     raw, rew, done, info = env.step(act, out=buf.step_out(t, obs=False, reward=False))   # done -> row t of the buffer
-                    next_obs = obs_norm(raw, out=buf.obs_planes[t + 1])                                  # normalised obs -> slab t + 1
-                    rew_norm(rew, done, out=buf.rew_planes[t])                                           # normalised reward -> row t
+                    next_obs = obs_norm(raw, out=buf.obs_row(t + 1))                                  # normalised obs -> slab t + 1
+                    rew_norm(rew, done, out=buf.rew_row(t))                                           # normalised reward -> row t
                 else:
                     raw, rew, done, info = env.step(act)
                     next_obs = obs_norm(raw)            # a fresh tensor per call: `obs` of this step stays intact

@@ -70,6 +70,12 @@ class PPOBuffer:
             # (env.step(buf.act_planes[t])); push({'act': rows}) transposes into them
             self.act_planes = torch.zeros((T, self.scheme['act']['vshape'][2], ld), dtype=torch.float32, device=self.device)
             self.__dict__['act'] = self.act_planes[:, :, :N].permute(0, 2, 1)                  # (T, N, act_dim), zero copy
+            # the per-step rows as ready-made views: indexing a tensor costs 2-3 us of host time, a rollout step needs eight of them,
+            # and below ~2^17 envs the host is what bounds an eager rollout
+            self._obs_rows, self._rew_rows = self.obs_planes.unbind(0), self.rew_planes.unbind(0)
+            self._done_rows, self._act_rows = self.done_planes.unbind(0), self.act_planes.unbind(0)
+            self._obs_views = [row[:, :N].T for row in self._obs_rows]
+            self._step_outs = {}
         self.t = 0
 
     # ---- the engine-written rows (env=...) ---------------------------------------------------------------------------
@@ -97,7 +103,22 @@ class PPOBuffer:
 
     def obs_at(self, t):
         """[N, obs_dim] view of observation slab t (t = max_length: the observation after the last step, for the bootstrap value)."""
-        return self.obs_planes[t, :, :self.batch_size].T
+        return self._obs_views[t]
+
+    def obs_row(self, t):
+        """Observation slab t as planes [obs_dim, plane_stride] (``obs_normalizer(raw, out=buf.obs_row(t + 1))``)."""
+        return self._obs_rows[t]
+
+    def rew_row(self, t):
+        """Reward row t [plane_stride] (``reward_normalizer(rew, done, out=buf.rew_row(t))``)."""
+        return self._rew_rows[t]
+
+    def done_row(self, t):
+        return self._done_rows[t]
+
+    def act_row(self, t):
+        """Action planes of step t [act_dim, plane_stride]: a policy that writes them hands the env its action in place."""
+        return self._act_rows[t]
 
     def step_out(self, t=None, obs=True, reward=True):
         """The ``out=`` argument of ``env.step`` for step t (default: the current row): the next observation into slab t + 1, reward
@@ -105,11 +126,15 @@ class PPOBuffer:
         buffer then writes the row itself: ``obs_normalizer(next_obs, out=buf.obs_planes[t + 1])``,
         ``reward_normalizer(rew, done, out=buf.rew_planes[t])``)."""
         t = self.t if t is None else t
-        out = {'done': self.done_planes[t]}
-        if obs:
-            out['obs'] = self.obs_planes[t + 1]
-        if reward:
-            out['reward'] = self.rew_planes[t]
+        key = (t, obs, reward)
+        out = self._step_outs.get(key)
+        if out is None:                                      # (built once per row: env.step only reads it)
+            out = {'done': self._done_rows[t]}
+            if obs:
+                out['obs'] = self._obs_rows[t + 1]
+            if reward:
+                out['reward'] = self._rew_rows[t]
+            self._step_outs[key] = out
         return out
 
     def push(self, batch):

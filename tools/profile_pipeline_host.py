@@ -22,7 +22,7 @@ od, nu = env.obs_dim, env.action_dim
 obs_norm, rew_norm = MeanStdNormalizer(shape=(od,), clip=10.0), RewardStdNormalizer(gamma=0.99, clip=10.0)
 buf = PPOBuffer(env.observation_space, env.action_space, T, n, env=env)
 act = torch.zeros((nu, env.plane_stride), device='cuda')
-obs_norm(env.reset(), out=buf.obs_planes[0])
+obs_norm(env.reset(), out=buf.obs_row(0))
 
 
 def rollout(parts):
@@ -30,9 +30,9 @@ def rollout(parts):
         if 'step' in parts:
             raw, rew, done, info = env.step(act, out=buf.step_out(t, obs=False, reward=False))
         if 'obs_norm' in parts:
-            obs_norm(raw, out=buf.obs_planes[t + 1])
+            obs_norm(raw, out=buf.obs_row(t + 1))
         if 'rew_norm' in parts:
-            rew_norm(rew, done, out=buf.rew_planes[t])
+            rew_norm(rew, done, out=buf.rew_row(t))
 
 
 for parts in (('step',), ('step', 'obs_norm'), ('step', 'obs_norm', 'rew_norm')):
