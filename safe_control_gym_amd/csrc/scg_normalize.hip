@@ -20,6 +20,10 @@
 #include "scg_device.h"
 #include "scg_math.h"
 
+#ifndef SCG_NORMALIZE_SMALL_BATCH
+#define SCG_NORMALIZE_SMALL_BATCH 16384   // envs up to which a normaliser call is ONE launch (one workgroup per feature, the plane in registers); 0: never
+#endif
+
 namespace scg {
 
 __device__ __forceinline__ double wsum(double v) {
@@ -331,6 +335,163 @@ __global__ __launch_bounds__(256) void scg_reward_apply_kernel(const float* __re
     }
 }
 
+// ---- small batches: ONE launch -------------------------------------------------------------------------
+// A feature's normalisation depends on that feature's moments only, so ONE workgroup per feature can do the whole call: read its
+// plane, block reduction, update_from_moments, normalise -- no second launch and no partials.  Up to kSmallBatch envs the second
+// launch (~3 us on the host, ~3 us of dependent-launch gap on the device) costs more than one workgroup's pass over its plane;
+// above, one workgroup per feature is too little parallelism and the two-launch form takes over.
+constexpr int kSmallBlock = 1024;
+constexpr int64_t kSmallBatch = SCG_NORMALIZE_SMALL_BATCH < 16 * kSmallBlock ? SCG_NORMALIZE_SMALL_BATCH : 16 * kSmallBlock;
+
+template <int K>
+__device__ __forceinline__ void block_sum_all(double (&v)[K], double* lds) {          // every thread gets the sums; kSmallBlock threads
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = wsum(v[k]);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) lds[wave * K + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kSmallBlock / 64; ++w) t += lds[w * K + k];               // fixed order: bit-reproducible
+        v[k] = t;
+    }
+}
+
+// Up to 4 x 16 bytes per thread and plane: kSmallBatch = 4 * 4 * kSmallBlock envs, read ONCE -- the values wait in registers for the
+// statistics (16-byte aligned planes; anything else takes the two-launch form).
+__global__ __launch_bounds__(kSmallBlock) void scg_mean_std_small_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                          int64_t ld_x, int64_t ld_y, uint32_t n, int d,
+                                                                          const double* __restrict__ state_in,
+                                                                          double* __restrict__ state_out, float clip, double epsilon) {
+    __shared__ double lds[2 * (kSmallBlock / 64)];
+    const int j = blockIdx.x;
+    const float* src = uptr(x + (int64_t)j * ld_x);
+    const uint32_t n4 = n >> 2, tail = (n & ~3u) + threadIdx.x;
+    const bool has_tail = threadIdx.x < (n & 3u);
+    nf4 v4[4];
+    float vt = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (threadIdx.x + u * kSmallBlock < n4) v4[u] = reinterpret_cast<const nf4*>(src)[threadIdx.x + u * kSmallBlock];
+    if (has_tail) vt = src[tail];
+    double mean = state_in[j], var = state_in[d + j];
+    if (state_out) {
+        const double c = mean;
+        double acc[2] = {0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (threadIdx.x + u * kSmallBlock < n4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double v = (double)v4[u][k] - c;
+                    acc[0] += v;
+                    acc[1] = fma(v, v, acc[1]);
+                }
+            }
+        if (has_tail) {
+            const double v = (double)vt - c;
+            acc[0] += v;
+            acc[1] = fma(v, v, acc[1]);
+        }
+        block_sum_all<2>(acc, lds);
+        const Updated u = update_from_moments(mean, var, state_in[2 * d], c, acc[0], acc[1], (double)n);
+        mean = u.mean; var = u.var;
+        if (threadIdx.x == 0) {
+            state_out[j] = u.mean;
+            state_out[d + j] = u.var;
+            if (j == 0) state_out[2 * d] = u.count;
+        }
+    }
+    const double inv = 1.0 / sqrt(var + epsilon);
+    const double lo = -(double)clip, hi = (double)clip;
+    float* dst = uptr(y + (int64_t)j * ld_y);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (threadIdx.x + u * kSmallBlock < n4) {
+            nf4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (float)fmin(fmax(((double)v4[u][k] - mean) * inv, lo), hi);
+            reinterpret_cast<nf4*>(dst)[threadIdx.x + u * kSmallBlock] = o;
+        }
+    if (has_tail) dst[tail] = (float)fmin(fmax(((double)vt - mean) * inv, lo), hi);
+}
+
+__global__ __launch_bounds__(kSmallBlock) void scg_reward_small_kernel(const float* __restrict__ rew, const uint8_t* __restrict__ done,
+                                                                        float* __restrict__ ret, float* __restrict__ out, uint32_t n,
+                                                                        float gamma, const double* __restrict__ state_in,
+                                                                        double* __restrict__ state_out, int legacy, float clip,
+                                                                        double epsilon) {
+    __shared__ double lds[3 * (kSmallBlock / 64)];
+    const uint32_t n4 = n >> 2, tail = (n & ~3u) + threadIdx.x;
+    const bool has_tail = threadIdx.x < (n & 3u);
+    nf4 r4[4], a4[4];
+    uint32_t d4[4];
+    float rt = 0.f, at = 0.f;
+    bool dt = false;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (threadIdx.x + u * kSmallBlock < n4) {
+            const uint32_t q = threadIdx.x + u * kSmallBlock;
+            r4[u] = reinterpret_cast<const nf4*>(rew)[q];
+            a4[u] = reinterpret_cast<const nf4*>(ret)[q];
+            d4[u] = reinterpret_cast<const uint32_t*>(done)[q];
+        }
+    if (has_tail) { rt = rew[tail]; at = ret[tail]; dt = done[tail] != 0; }
+    const double c = state_in[0];
+    double var = state_in[1];
+    double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (threadIdx.x + u * kSmallBlock < n4) {
+            nf4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float r = fmaf(a4[u][k], gamma, r4[u][k]);
+                const bool dn = ((d4[u] >> (8 * k)) & 0xffu) != 0;
+                const double v = (double)r - c;
+                acc[0] += v;
+                acc[1] = fma(v, v, acc[1]);
+                acc[2] += dn ? 1.0 : 0.0;
+                o[k] = (!legacy && dn) ? 0.f : r;
+            }
+            reinterpret_cast<nf4*>(ret)[threadIdx.x + u * kSmallBlock] = o;
+        }
+    if (has_tail) {
+        const float r = fmaf(at, gamma, rt);
+        const double v = (double)r - c;
+        acc[0] += v;
+        acc[1] = fma(v, v, acc[1]);
+        acc[2] += dt ? 1.0 : 0.0;
+        ret[tail] = (!legacy && dt) ? 0.f : r;
+    }
+    block_sum_all<3>(acc, lds);                                    // (its barrier orders every ret store above before the two below)
+    const Updated u = update_from_moments(c, var, state_in[2], c, acc[0], acc[1], (double)n);
+    var = u.var;
+    if (threadIdx.x == 0) {
+        state_out[0] = u.mean; state_out[1] = u.var; state_out[2] = u.count;
+        if (legacy) {
+            if (acc[2] < (double)n) ret[0] = 0.f;                   // some dones == 0 -> index 0
+            if (acc[2] > 0.0 && n > 1) ret[1] = 0.f;                // some dones == 1 -> index 1
+        }
+    }
+    const double inv = 1.0 / sqrt(var + epsilon);
+    const double lo = -(double)clip, hi = (double)clip;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (threadIdx.x + u * kSmallBlock < n4) {
+            nf4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (float)fmin(fmax((double)r4[u][k] * inv, lo), hi);
+            reinterpret_cast<nf4*>(out)[threadIdx.x + u * kSmallBlock] = o;
+        }
+    if (has_tail) out[tail] = (float)fmin(fmax((double)rt * inv, lo), hi);
+}
+
 // ---- launchers ------------------------------------------------------------------------------------
 static unsigned partial_blocks(int64_t n, int d) {
     int64_t b = (n + 1023) / 1024;                              // >= 4 elements per thread
@@ -348,6 +509,12 @@ static unsigned apply_blocks(int64_t n, int d) {
 hipError_t launch_mean_std_normalize(const float* x, float* y, int d, int64_t ld_x, int64_t ld_y, int64_t n,
                                      const double* state_in, double* state_out, double* partials, float clip,
                                      double epsilon, hipStream_t s) {
+    auto addr = [](const void* p) { return reinterpret_cast<uintptr_t>(p); };
+    if (n <= kSmallBatch && state_out && y && ((addr(x) | addr(y) | (uintptr_t)(ld_x * 4) | (uintptr_t)(ld_y * 4)) & 15u) == 0) {
+        hipLaunchKernelGGL(scg_mean_std_small_kernel, dim3((unsigned)d), dim3(kSmallBlock), 0, s, x, y, ld_x, ld_y, (uint32_t)n, d, state_in,
+                           state_out, clip, epsilon);
+        return hipGetLastError();
+    }
     const unsigned pb = partial_blocks(n, d);
     if (state_out) {
         const dim3 grid(pb, (unsigned)d), block(256);
@@ -374,8 +541,13 @@ static unsigned reward_blocks(int64_t n) {
 hipError_t launch_reward_normalize(const float* rew, const uint8_t* done, float* ret, float* out, int64_t n,
                                    const double* state_in, double* state_out, double* partials, float gamma,
                                    float clip, double epsilon, int legacy, hipStream_t s) {
-    const unsigned pb = reward_blocks(n);
     auto addr = [](const void* p) { return reinterpret_cast<uintptr_t>(p); };
+    if (n <= kSmallBatch && state_out && ((addr(rew) | addr(ret) | addr(out)) & 15u) == 0 && (addr(done) & 3u) == 0) {
+        hipLaunchKernelGGL(scg_reward_small_kernel, dim3(1), dim3(kSmallBlock), 0, s, rew, done, ret, out, (uint32_t)n, gamma, state_in,
+                           state_out, legacy, clip, epsilon);
+        return hipGetLastError();
+    }
+    const unsigned pb = reward_blocks(n);
     if (state_out) {
         const bool vec = ((addr(rew) | addr(ret)) & 15u) == 0 && (addr(done) & 3u) == 0;
         if (vec) hipLaunchKernelGGL(scg_reward_moments_kernel<true>, dim3(pb), dim3(256), 0, s, rew, done, ret, (uint32_t)n, gamma,
