@@ -4,7 +4,7 @@
 // RewardStdNormalizer (:150-190), which PPO calls on every rollout step on host copies of the observations
 // and rewards (controllers/ppo/ppo.py:260-261).  Here the batch stays where the step kernel left it.
 //
-// One call = two launches:
+// One call = two launches (batches above 2^14 envs; smaller ones take the one-launch form further down):
 //   1. moments: per feature j, sum (x - c_j) and sum (x - c_j)^2 over the batch in double, c_j = the current
 //      running mean (a shift that removes the cancellation of the one-pass variance).  Each of the <= 64
 //      workgroups of a feature reduces through wave shuffles + LDS and writes ONE partial pair -- no atomics:
