@@ -888,6 +888,11 @@ def run_rank(args):
                  '(tests/test_parity_gpu.py::test_precise_mode_open_loop_1000_step_drift)')
         out['step_api'] = step_api_record(args, n, 300)
         out['rl_pipeline'] = rl_pipeline_record(args, n, 128)
+        if n > 1 << 14:
+            # the same pipeline at a batch the HOST bounds when it is stepped from Python (the reference's own scale is smaller still): what
+            # recording the rollout's steps in one graph and the one-launch normaliser calls (<= 2^14 envs) are for
+            small = rl_pipeline_record(args, 1 << 14, 128)
+            out['rl_pipeline']['at_16384_envs'] = {k: small[k] for k in ('envs', 'rollout_steps', 'value', 'unit', 'us_per_step', 'replayed_from_a_hip_graph')}
         out['c3'] = sub_record(args, timer, 'c3', 1 << 18, max(sub_steps, 1000), fused_too=True)
         out['c2'] = sub_record(args, timer, 'c2', 1 << 16, max(sub_steps, 1000), fused_too=True)
         # the north-star's N in {1k ... 1M}: the bare C4 step at each batch size, same clock (a few ms apiece)
