@@ -936,7 +936,7 @@ class BenchmarkEnv:
         if self.adversary_disturbance is not None:
             raise RuntimeError('[ERROR] rollout() cannot take per-step adversary actions; use step().')
         if not (isinstance(actions, torch.Tensor) and actions.dtype == torch.float32 and actions.is_contiguous()
-                and actions.ndim == 3 and actions.shape[1:] == (self.action_dim, self._ld)):
+                and actions.ndim == 3 and actions.shape[1:] == (self.action_dim, self._ld) and actions.device == self._bufs['state'].device):
             raise ValueError('[ERROR] rollout() needs a contiguous float32 [T, %d, %d] device tensor.'
                              % (self.action_dim, self._ld))
         steps = actions.shape[0] if steps is None else int(steps)

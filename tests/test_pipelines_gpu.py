@@ -244,6 +244,8 @@ def test_trajectory_buffer_argument_checks(gpu):
         env.rollout(acts, steps=4, out=env.trajectory_buffer(3))
     with pytest.raises(ValueError, match='no constraints'):
         env.trajectory_buffer(4, constraints=True)
+    with pytest.raises(ValueError, match='device tensor'):          # a host tensor's address must never reach a kernel
+        env.rollout(acts.cpu(), steps=4)
     env.close(); other.close()
 
 
