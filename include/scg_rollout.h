@@ -512,6 +512,25 @@ int scg_reward_normalize(const float* rew, const uint8_t* done, float* ret, floa
                          const double* state_in, double* state_out, double* scratch, float gamma, float clip,
                          double epsilon, int32_t legacy_index_reset, void* stream);
 
+/* ---- one statistics tracker, the batch spread over several devices ------------------------------------------------
+ * The reference normalises in ONE process over the observations of ALL its envs (controllers/ppo/ppo.py:260-261 behind a
+ * SubprocVecEnv); with one process per GPU every rank holds a shard of the batch.  The two passes of the normalisers apart, with
+ * the one exchange the path has between them: pass 1 leaves this shard's sums -- sums[j] = {sum (x_j - c_j), sum (x_j - c_j)^2},
+ * c_j = the tracker's current mean (identical on every rank as long as every update goes through this path) -- the caller adds the
+ * shards' sums and row counts (one all-reduce of 2 d + 1 doubles: RCCL over xGMI), pass 2 updates the tracker from the added sums
+ * with batch_count = the rows of all shards and normalises this shard's rows.  Every rank ends up with the same record, the one a
+ * single tracker fed with the whole batch would hold.  scratch as for scg_mean_std_normalize; sums: 2 d doubles on the device. */
+int scg_mean_std_moments(const float* x, int32_t d, int64_t ld_x, int64_t n, const double* state_in, double* scratch, double* sums,
+                         void* stream);
+int scg_mean_std_normalize_sums(const float* x, float* y, int32_t d, int64_t ld_x, int64_t ld_y, int64_t n, const double* state_in,
+                                double* state_out, const double* sums, double batch_count, float clip, double epsilon, void* stream);
+/* The same split of RewardStdNormalizer (the returns of finished envs are cleared, i.e. legacy_index_reset = 0): pass 1 advances
+ * ret and leaves sums[3] = {sum (ret - c), sum (ret - c)^2, finished envs}; pass 2 takes the added sums. */
+int scg_reward_moments(const float* rew, const uint8_t* done, float* ret, int64_t n, const double* state_in, double* scratch,
+                       double* sums, float gamma, void* stream);
+int scg_reward_normalize_sums(const float* rew, float* out, int64_t n, const double* state_in, double* state_out, const double* sums,
+                              double batch_count, float clip, double epsilon, void* stream);
+
 /* Introspection of scg_rollout's hipGraph replay (tests, tuning): *cached = rollout signatures currently held as instantiated
  * graphs (-1: a capture failed and the handle stays on plain launches), *replays = graph launches so far.  Either may be NULL. */
 int scg_rollout_graph_info(const scg_handle* h, int32_t* cached, int64_t* replays);

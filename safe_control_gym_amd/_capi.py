@@ -125,7 +125,7 @@ class ScgDisturbance(C.Structure):
 EXPORTS = (
     'scg_create', 'scg_destroy', 'scg_set_reference', 'scg_set_constraints', 'scg_set_disturbances', 'scg_reset', 'scg_step', 'scg_rollout', 'scg_rollout_fused',
     'scg_step_async', 'scg_step_wait', 'scg_step_queue', 'scg_rollout_trajectory', 'scg_sizeof_trajectory_sink',
-    'scg_eval_constraints', 'scg_gae', 'scg_normalize_advantages', 'scg_model_eval', 'scg_model_flow', 'scg_linearize', 'scg_fc_linear', 'scg_discretize_exact', 'scg_quadratic_loss', 'scg_mean_std_normalize', 'scg_reward_normalize', 'scg_num_constraints', 'scg_obs_dim', 'scg_kernel_info', 'scg_rollout_graph_info', 'scg_last_error',
+    'scg_eval_constraints', 'scg_gae', 'scg_normalize_advantages', 'scg_model_eval', 'scg_model_flow', 'scg_linearize', 'scg_fc_linear', 'scg_discretize_exact', 'scg_quadratic_loss', 'scg_mean_std_normalize', 'scg_reward_normalize', 'scg_mean_std_moments', 'scg_mean_std_normalize_sums', 'scg_reward_moments', 'scg_reward_normalize_sums', 'scg_num_constraints', 'scg_obs_dim', 'scg_kernel_info', 'scg_rollout_graph_info', 'scg_last_error',
     'scg_version', 'scg_sizeof_config', 'scg_sizeof_step_io', 'scg_sizeof_constraint_row', 'scg_sizeof_disturbance',
 )
 
@@ -193,6 +193,10 @@ def load():
                                            C.c_void_p]
     lib.scg_reward_normalize.argtypes = [_fp, _fp, _fp, _fp, C.c_int64, _fp, _fp, _fp, C.c_float, C.c_float, _dbl, _i32,
                                          C.c_void_p]
+    lib.scg_mean_std_moments.argtypes = [_fp, _i32, C.c_int64, C.c_int64, _fp, _fp, _fp, C.c_void_p]
+    lib.scg_mean_std_normalize_sums.argtypes = [_fp, _fp, _i32, C.c_int64, C.c_int64, C.c_int64, _fp, _fp, _fp, _dbl, C.c_float, _dbl, C.c_void_p]
+    lib.scg_reward_moments.argtypes = [_fp, _fp, _fp, C.c_int64, _fp, _fp, _fp, C.c_float, C.c_void_p]
+    lib.scg_reward_normalize_sums.argtypes = [_fp, _fp, C.c_int64, _fp, _fp, _fp, _dbl, C.c_float, _dbl, C.c_void_p]
     lib.scg_num_constraints.argtypes = [C.c_void_p]
     lib.scg_obs_dim.argtypes = [C.c_void_p]
     lib.scg_kernel_info.argtypes = [C.c_void_p, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.c_int64]

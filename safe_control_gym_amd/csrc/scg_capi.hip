@@ -1220,6 +1220,49 @@ int scg_reward_normalize(const float* rew, const uint8_t* done, float* ret, floa
     return SCG_OK;
 }
 
+int scg_mean_std_moments(const float* x, int32_t d, int64_t ld_x, int64_t n, const double* state_in, double* scratch, double* sums,
+                         void* stream) {
+    if (!x || !state_in || !scratch || !sums) return fail(SCG_ERR_INVALID, "scg_mean_std_moments: null argument");
+    if (d < 1 || d > 65535) return fail(SCG_ERR_INVALID, "scg_mean_std_moments: need 1 <= d <= 65535");
+    if (n < 1 || ld_x < n || n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_mean_std_moments: need 1 <= n <= ld_x, n <= 2^30");
+    HIP_TRY(launch_mean_std_moments(x, d, ld_x, n, state_in, scratch, sums, (hipStream_t)stream));
+    return SCG_OK;
+}
+
+int scg_mean_std_normalize_sums(const float* x, float* y, int32_t d, int64_t ld_x, int64_t ld_y, int64_t n, const double* state_in,
+                                double* state_out, const double* sums, double batch_count, float clip, double epsilon, void* stream) {
+    if (!x || !state_in || !state_out || !sums) return fail(SCG_ERR_INVALID, "scg_mean_std_normalize_sums: null argument");
+    if (state_out == state_in) return fail(SCG_ERR_INVALID, "scg_mean_std_normalize_sums: state_out must not alias state_in");
+    if (d < 1 || d > 65535) return fail(SCG_ERR_INVALID, "scg_mean_std_normalize_sums: need 1 <= d <= 65535");
+    if (n < 0 || ld_x < n || (y && ld_y < n) || n > (int64_t)1 << 30)
+        return fail(SCG_ERR_INVALID, "scg_mean_std_normalize_sums: need 0 <= n <= ld_x, ld_y and n <= 2^30");
+    if (!(batch_count >= 1.0) || batch_count < (double)n)
+        return fail(SCG_ERR_INVALID, "scg_mean_std_normalize_sums: batch_count (the rows of all shards) must be >= max(n, 1)");
+    if (!(clip >= 0.f) || !(epsilon >= 0.0)) return fail(SCG_ERR_INVALID, "scg_mean_std_normalize_sums: clip and epsilon must be >= 0");
+    HIP_TRY(launch_mean_std_apply_sums(x, n > 0 ? y : nullptr, d, ld_x, ld_y, n, state_in, state_out, sums, batch_count, clip, epsilon,
+                                       (hipStream_t)stream));
+    return SCG_OK;
+}
+
+int scg_reward_moments(const float* rew, const uint8_t* done, float* ret, int64_t n, const double* state_in, double* scratch,
+                       double* sums, float gamma, void* stream) {
+    if (!rew || !done || !ret || !state_in || !scratch || !sums) return fail(SCG_ERR_INVALID, "scg_reward_moments: null argument");
+    if (n < 1 || n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_reward_moments: need 1 <= n <= 2^30");
+    HIP_TRY(launch_reward_moments(rew, done, ret, n, state_in, scratch, sums, gamma, (hipStream_t)stream));
+    return SCG_OK;
+}
+
+int scg_reward_normalize_sums(const float* rew, float* out, int64_t n, const double* state_in, double* state_out, const double* sums,
+                              double batch_count, float clip, double epsilon, void* stream) {
+    if (!rew || !out || !state_in || !state_out || !sums) return fail(SCG_ERR_INVALID, "scg_reward_normalize_sums: null argument");
+    if (state_out == state_in) return fail(SCG_ERR_INVALID, "scg_reward_normalize_sums: state_out must not alias state_in");
+    if (n < 1 || n > (int64_t)1 << 30) return fail(SCG_ERR_INVALID, "scg_reward_normalize_sums: need 1 <= n <= 2^30");
+    if (!(batch_count >= (double)n)) return fail(SCG_ERR_INVALID, "scg_reward_normalize_sums: batch_count (the envs of all shards) must be >= n");
+    if (!(clip >= 0.f) || !(epsilon >= 0.0)) return fail(SCG_ERR_INVALID, "scg_reward_normalize_sums: clip and epsilon must be >= 0");
+    HIP_TRY(launch_reward_apply_sums(rew, out, n, state_in, state_out, sums, batch_count, clip, epsilon, (hipStream_t)stream));
+    return SCG_OK;
+}
+
 int scg_num_constraints(const scg_handle* h) { return h ? h->n_con_rows : 0; }
 
 int scg_obs_dim(const scg_handle* h) { return h ? h->obs_dim : 0; }

@@ -214,6 +214,14 @@ hipError_t launch_mean_std_normalize(const float* x, float* y, int d, int64_t ld
 hipError_t launch_reward_normalize(const float* rew, const uint8_t* done, float* ret, float* out, int64_t n,
                                    const double* state_in, double* state_out, double* moments, float gamma,
                                    float clip, double epsilon, int legacy, hipStream_t s);
+hipError_t launch_mean_std_moments(const float* x, int d, int64_t ld_x, int64_t n, const double* state_in, double* partials,
+                                   double* sums, hipStream_t s);
+hipError_t launch_mean_std_apply_sums(const float* x, float* y, int d, int64_t ld_x, int64_t ld_y, int64_t n, const double* state_in,
+                                      double* state_out, const double* sums, double batch_n, float clip, double epsilon, hipStream_t s);
+hipError_t launch_reward_moments(const float* rew, const uint8_t* done, float* ret, int64_t n, const double* state_in, double* partials,
+                                 double* sums, float gamma, hipStream_t s);
+hipError_t launch_reward_apply_sums(const float* rew, float* out, int64_t n, const double* state_in, double* state_out,
+                                    const double* sums, double batch_n, float clip, double epsilon, hipStream_t s);
 hipError_t launch_eval_constraints(int system, const ConTable* ct, const float* state, const float* action,
                                    float* c_val, uint8_t* violation, int64_t ld, int64_t n, hipStream_t s);
 }  // namespace scg

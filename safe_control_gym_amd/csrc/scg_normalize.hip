@@ -226,13 +226,14 @@ __global__ __launch_bounds__(256) void scg_mean_std_apply_kernel(const float* __
                                                                  const double* __restrict__ state_in,
                                                                  double* __restrict__ state_out,
                                                                  const double* __restrict__ partials, int n_partials,
-                                                                 float clip, double epsilon) {
+                                                                 int partials_stride, double batch_n, float clip, double epsilon) {
+    // batch_n: rows behind the sums -- n, or the rows of ALL shards when the sums were added up across devices (partials_stride 1)
     const int j = blockIdx.y;
     double mean = state_in[j], var = state_in[d + j];
     if (state_out) {
         double tot[2];
-        sum_partials<2>(partials + (int64_t)j * max_partials(d) * 2, n_partials, tot);
-        const Updated u = update_from_moments(mean, var, state_in[2 * d], mean, tot[0], tot[1], (double)n);
+        sum_partials<2>(partials + (int64_t)j * partials_stride * 2, n_partials, tot);
+        const Updated u = update_from_moments(mean, var, state_in[2 * d], mean, tot[0], tot[1], batch_n);
         mean = u.mean; var = u.var;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             state_out[j] = u.mean;
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(256) void scg_reward_apply_kernel(const float* __re
                                                                const double* __restrict__ state_in,
                                                                double* __restrict__ state_out,
                                                                const double* __restrict__ partials, int n_partials,
-                                                               int legacy, float clip, double epsilon) {
+                                                               double batch_n, int legacy, float clip, double epsilon) {
     // this thread's rewards first: their latency covers the partial sums below
     const uint32_t n4 = n >> 2, stride = gridDim.x * 256u, q0 = blockIdx.x * 256u + threadIdx.x;
     nf4 r4[4];
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(256) void scg_reward_apply_kernel(const float* __re
     if (state_out) {
         double tot[3];
         sum_partials<3>(partials, n_partials, tot);
-        const Updated u = update_from_moments(state_in[0], var, state_in[2], state_in[0], tot[0], tot[1], (double)n);
+        const Updated u = update_from_moments(state_in[0], var, state_in[2], state_in[0], tot[0], tot[1], batch_n);
         var = u.var;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             state_out[0] = u.mean; state_out[1] = u.var; state_out[2] = u.count;
@@ -332,6 +333,19 @@ __global__ __launch_bounds__(256) void scg_reward_apply_kernel(const float* __re
     } else {
         for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
             out[i] = (float)fmin(fmax((double)rew[i] * inv, lo), hi);
+    }
+}
+
+// ---- statistics shared by several shards (one tracker, the batch spread over devices) -------------------------------------
+// sums[j][k] = the feature's partials added up: what every shard contributes to the all-reduce between the two passes.
+template <int K>
+__global__ __launch_bounds__(64) void scg_sum_partials_kernel(const double* __restrict__ partials, int n_partials, int partials_stride,
+                                                              double* __restrict__ sums) {
+    double tot[K];
+    sum_partials<K>(partials + (int64_t)blockIdx.x * partials_stride * K, n_partials, tot);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) sums[blockIdx.x * K + k] = tot[k];
     }
 }
 
@@ -526,9 +540,35 @@ hipError_t launch_mean_std_normalize(const float* x, float* y, int d, int64_t ld
     const bool vec2 = ((reinterpret_cast<uintptr_t>(x) | (uintptr_t)(ld_x * 4) | reinterpret_cast<uintptr_t>(y) |
                         (uintptr_t)(ld_y * 4)) & 15u) == 0;
     if (vec2) hipLaunchKernelGGL(scg_mean_std_apply_kernel<true>, grid, block, 0, s, x, y, ld_x, ld_y, (uint32_t)n, d,
-                                 state_in, state_out, partials, (int)pb, clip, epsilon);
+                                 state_in, state_out, partials, (int)pb, max_partials(d), (double)n, clip, epsilon);
     else hipLaunchKernelGGL(scg_mean_std_apply_kernel<false>, grid, block, 0, s, x, y, ld_x, ld_y, (uint32_t)n, d,
-                            state_in, state_out, partials, (int)pb, clip, epsilon);
+                            state_in, state_out, partials, (int)pb, max_partials(d), (double)n, clip, epsilon);
+    return hipGetLastError();
+}
+
+// The two passes apart, for a tracker whose batch is spread over several devices: pass 1 leaves sums[d][2] (this shard's
+// sum (x - c), sum (x - c)^2 with c = the tracker's current mean -- the same on every shard), the caller adds the shards' sums
+// (an all-reduce of 2 d doubles), pass 2 takes the added sums and the total row count.
+hipError_t launch_mean_std_moments(const float* x, int d, int64_t ld_x, int64_t n, const double* state_in, double* partials,
+                                   double* sums, hipStream_t s) {
+    const unsigned pb = partial_blocks(n, d);
+    const dim3 grid(pb, (unsigned)d), block(256);
+    const bool vec = ((reinterpret_cast<uintptr_t>(x) | (uintptr_t)(ld_x * 4)) & 15u) == 0;
+    if (vec) hipLaunchKernelGGL(scg_moments_kernel<true>, grid, block, 0, s, x, ld_x, (uint32_t)n, state_in, d, partials);
+    else hipLaunchKernelGGL(scg_moments_kernel<false>, grid, block, 0, s, x, ld_x, (uint32_t)n, state_in, d, partials);
+    hipLaunchKernelGGL(scg_sum_partials_kernel<2>, dim3((unsigned)d), dim3(64), 0, s, partials, (int)pb, max_partials(d), sums);
+    return hipGetLastError();
+}
+
+hipError_t launch_mean_std_apply_sums(const float* x, float* y, int d, int64_t ld_x, int64_t ld_y, int64_t n, const double* state_in,
+                                      double* state_out, const double* sums, double batch_n, float clip, double epsilon, hipStream_t s) {
+    const dim3 grid(y ? apply_blocks(n, d) : 1u, (unsigned)d), block(256);
+    const bool vec2 = ((reinterpret_cast<uintptr_t>(x) | (uintptr_t)(ld_x * 4) | reinterpret_cast<uintptr_t>(y) |
+                        (uintptr_t)(ld_y * 4)) & 15u) == 0;
+    if (vec2) hipLaunchKernelGGL(scg_mean_std_apply_kernel<true>, grid, block, 0, s, x, y, ld_x, ld_y, (uint32_t)n, d,
+                                 state_in, state_out, sums, 1, 1, batch_n, clip, epsilon);
+    else hipLaunchKernelGGL(scg_mean_std_apply_kernel<false>, grid, block, 0, s, x, y, ld_x, ld_y, (uint32_t)n, d,
+                            state_in, state_out, sums, 1, 1, batch_n, clip, epsilon);
     return hipGetLastError();
 }
 
@@ -557,9 +597,36 @@ hipError_t launch_reward_normalize(const float* rew, const uint8_t* done, float*
     }
     const bool vec2 = ((addr(rew) | addr(out)) & 15u) == 0;
     if (vec2) hipLaunchKernelGGL(scg_reward_apply_kernel<true>, dim3(pb), dim3(256), 0, s, rew, out, ret, (uint32_t)n,
-                                 state_in, state_out, partials, (int)pb, legacy, clip, epsilon);
+                                 state_in, state_out, partials, (int)pb, (double)n, legacy, clip, epsilon);
     else hipLaunchKernelGGL(scg_reward_apply_kernel<false>, dim3(pb), dim3(256), 0, s, rew, out, ret, (uint32_t)n,
-                            state_in, state_out, partials, (int)pb, legacy, clip, epsilon);
+                            state_in, state_out, partials, (int)pb, (double)n, legacy, clip, epsilon);
+    return hipGetLastError();
+}
+
+// The reward normaliser's two passes apart (statistics shared by several shards; the finished envs' returns are cleared, i.e. the
+// non-legacy reset): sums[3] = this shard's sum (ret - c), sum (ret - c)^2, number of finished envs.
+hipError_t launch_reward_moments(const float* rew, const uint8_t* done, float* ret, int64_t n, const double* state_in, double* partials,
+                                 double* sums, float gamma, hipStream_t s) {
+    const unsigned pb = reward_blocks(n);
+    auto addr = [](const void* p) { return reinterpret_cast<uintptr_t>(p); };
+    const bool vec = ((addr(rew) | addr(ret)) & 15u) == 0 && (addr(done) & 3u) == 0;
+    if (vec) hipLaunchKernelGGL(scg_reward_moments_kernel<true>, dim3(pb), dim3(256), 0, s, rew, done, ret, (uint32_t)n, gamma,
+                                state_in, 0, partials);
+    else hipLaunchKernelGGL(scg_reward_moments_kernel<false>, dim3(pb), dim3(256), 0, s, rew, done, ret, (uint32_t)n, gamma,
+                            state_in, 0, partials);
+    hipLaunchKernelGGL(scg_sum_partials_kernel<3>, dim3(1), dim3(64), 0, s, partials, (int)pb, 0, sums);
+    return hipGetLastError();
+}
+
+hipError_t launch_reward_apply_sums(const float* rew, float* out, int64_t n, const double* state_in, double* state_out,
+                                    const double* sums, double batch_n, float clip, double epsilon, hipStream_t s) {
+    const unsigned pb = reward_blocks(n);
+    auto addr = [](const void* p) { return reinterpret_cast<uintptr_t>(p); };
+    const bool vec2 = ((addr(rew) | addr(out)) & 15u) == 0;
+    if (vec2) hipLaunchKernelGGL(scg_reward_apply_kernel<true>, dim3(pb), dim3(256), 0, s, rew, out, (float*)nullptr, (uint32_t)n,
+                                 state_in, state_out, sums, 1, batch_n, 0, clip, epsilon);
+    else hipLaunchKernelGGL(scg_reward_apply_kernel<false>, dim3(pb), dim3(256), 0, s, rew, out, (float*)nullptr, (uint32_t)n,
+                            state_in, state_out, sums, 1, batch_n, 0, clip, epsilon);
     return hipGetLastError();
 }
 

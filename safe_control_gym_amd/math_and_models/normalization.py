@@ -165,15 +165,56 @@ class BaseNormalizer:
         pass
 
 
-class MeanStdNormalizer(BaseNormalizer):
-    """Normalise by the running average (normalization.py:107-147)."""
+class _SharedStatistics:
+    """One tracker, the batch spread over the ranks of a ``torch.distributed`` world (one process per GPU, each with a shard of the
+    envs): the reference normalises in ONE process over the observations of ALL its envs (controllers/ppo/ppo.py:260-261), so the
+    shards' moments are added up between the two passes of the normaliser -- one all-reduce of 2 d (+1) doubles per call, over RCCL
+    / xGMI on the device (through host memory under gloo) -- and every rank ends up with the record a single tracker fed with the
+    whole batch would hold.  Every rank must make the same calls with a fixed shard size (the total row count is exchanged once per
+    shard size, the only blocking exchange)."""
 
-    def __init__(self, shape=(), read_only=False, clip=10.0, epsilon=1e-8, device='cuda'):
+    def __init__(self, sync_statistics, process_group):
+        self.sync_statistics, self.process_group = bool(sync_statistics), process_group
+        self._totals = {}
+
+    def world(self):
+        """torch.distributed when the statistics are shared and there is more than one rank, else None."""
+        if not self.sync_statistics:
+            return None
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
+            return dist
+        return None
+
+    def add_up(self, dist, t):
+        """In-place sum of a small device tensor over the ranks."""
+        if dist.get_backend(self.process_group) == 'gloo' and t.is_cuda:
+            h = t.cpu()
+            dist.all_reduce(h, group=self.process_group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, group=self.process_group)
+
+    def total_rows(self, dist, n, device):
+        if n not in self._totals:
+            t = torch.tensor([float(n)], dtype=torch.float64, device=device)
+            self.add_up(dist, t)
+            self._totals[n] = float(t.item())
+        return self._totals[n]
+
+
+class MeanStdNormalizer(BaseNormalizer):
+    """Normalise by the running average (normalization.py:107-147).  ``sync_statistics=True`` (with an initialised
+    ``torch.distributed`` world of more than one rank): the tracker is updated with the batch of ALL ranks (``_SharedStatistics``)."""
+
+    def __init__(self, shape=(), read_only=False, clip=10.0, epsilon=1e-8, device='cuda', sync_statistics=False, process_group=None):
         super().__init__(read_only)
         self.lib = _capi.load()
         self.rms = RunningMeanStd(shape=shape, device=device)
         self.clip = clip
         self.epsilon = epsilon
+        self.shared = _SharedStatistics(sync_statistics, process_group)
+        self._sums = None
         self.device = self.rms.device
 
     def _planes(self, x):
@@ -215,7 +256,19 @@ class MeanStdNormalizer(BaseNormalizer):
                   and out.shape[0] == d and out.shape[1] >= n and out.device == xv.device):
             raise ValueError('[ERROR] out must be a contiguous float32 (%d, ld >= %d) device tensor' % (d, n))
         ld_y = out.shape[1]
+        dist = None if self.read_only else self.shared.world()
         state_in, state_out = self.rms._record_ptrs(not self.read_only)
+        if dist is not None:
+            # moments of this shard -> sums over the ranks -> update from the added sums + normalise this shard
+            if self._sums is None:
+                self._sums = torch.zeros(2 * d, dtype=torch.float64, device=self.device)
+            total = self.shared.total_rows(dist, n, self.device)
+            _launch(self.device, self.lib.scg_mean_std_moments, 'scg_mean_std_moments', xv.data_ptr(), d, ld_x, n, state_in,
+                    self.rms._moments_ptr, self._sums.data_ptr())
+            self.shared.add_up(dist, self._sums)
+            _launch(self.device, self.lib.scg_mean_std_normalize_sums, 'scg_mean_std_normalize_sums', xv.data_ptr(), out.data_ptr(), d,
+                    ld_x, ld_y, n, state_in, state_out, self._sums.data_ptr(), total, float(self.clip), float(self.epsilon))
+            return out[:, :n].T
         _launch(self.device, self.lib.scg_mean_std_normalize, 'scg_mean_std_normalize', xv.data_ptr(), out.data_ptr(), d, ld_x, ld_y, n,
                 state_in, state_out, self.rms._moments_ptr, float(self.clip), float(self.epsilon))
         return out[:, :n].T
@@ -234,11 +287,15 @@ class RewardStdNormalizer(MeanStdNormalizer):
     clears ret[0] / ret[1] according to the VALUES in dones); the default clears the returns of the finished envs,
     which is what the comment above that line says it is for."""
 
-    def __init__(self, gamma=0.99, read_only=False, clip=10.0, epsilon=1e-8, device='cuda', legacy_index_reset=False):
-        super().__init__((), read_only, clip, epsilon, device=device)
+    def __init__(self, gamma=0.99, read_only=False, clip=10.0, epsilon=1e-8, device='cuda', legacy_index_reset=False,
+                 sync_statistics=False, process_group=None):
+        super().__init__((), read_only, clip, epsilon, device=device, sync_statistics=sync_statistics, process_group=process_group)
         self.gamma = gamma
         self.ret = None
         self.legacy_index_reset = legacy_index_reset
+        if sync_statistics and legacy_index_reset:
+            raise ValueError('[ERROR] sync_statistics: the legacy index reset addresses elements 0 / 1 of ONE array of returns; the shards '
+                             'of a distributed batch clear the returns of their finished envs (legacy_index_reset=False).')
 
     def __call__(self, x, dones, out=None):
         """``out`` (optional): a contiguous float32 [>= N] device tensor that receives the normalised rewards (e.g. row t of a
@@ -262,7 +319,18 @@ class RewardStdNormalizer(MeanStdNormalizer):
         elif not (isinstance(out, torch.Tensor) and out.dtype == torch.float32 and out.ndim == 1 and out.is_contiguous()
                   and out.shape[0] >= n and out.device == x.device):
             raise ValueError('[ERROR] out must be a contiguous float32 (>= %d,) device tensor' % n)
+        dist = None if self.read_only else self.shared.world()
         state_in, state_out = self.rms._record_ptrs(not self.read_only)
+        if dist is not None:
+            if self._sums is None:
+                self._sums = torch.zeros(3, dtype=torch.float64, device=dev)
+            total = self.shared.total_rows(dist, n, dev)
+            _launch(dev, self.lib.scg_reward_moments, 'scg_reward_moments', x.data_ptr(), dones.data_ptr(), self.ret.data_ptr(), n, state_in,
+                    self.rms._moments_ptr, self._sums.data_ptr(), float(self.gamma))
+            self.shared.add_up(dist, self._sums)
+            _launch(dev, self.lib.scg_reward_normalize_sums, 'scg_reward_normalize_sums', x.data_ptr(), out.data_ptr(), n, state_in, state_out,
+                    self._sums.data_ptr(), total, float(self.clip), float(self.epsilon))
+            return out if out.shape[0] == n else out[:n]
         _launch(dev, self.lib.scg_reward_normalize, 'scg_reward_normalize', x.data_ptr(), dones.data_ptr(),
                 None if self.ret is None else self.ret.data_ptr(), out.data_ptr(), n, state_in, state_out, self.rms._moments_ptr,
                 float(self.gamma), float(self.clip), float(self.epsilon), int(self.legacy_index_reset))

@@ -589,6 +589,23 @@ static void check_next_row_entry_points() {
     EXPECT(scg_mean_std_normalize(f.data(), f.data(), 3, 8, 8, 8, d.data(), d.data() + 32, d.data(), 10.f, 1e-8, nullptr) == SCG_OK);
     EXPECT(scg_reward_normalize(f.data(), nullptr, nullptr, f.data(), 8, d.data(), d.data() + 8, d.data(), 0.99f, 10.f, 1e-8, 0, nullptr) == SCG_ERR_INVALID);
     EXPECT(scg_reward_normalize(f.data(), u.data(), f.data(), f.data(), 8, d.data(), d.data() + 8, d.data(), 0.99f, 10.f, 1e-8, 0, nullptr) == SCG_OK);
+    // the two passes apart (statistics shared by several shards): argument checks of the four entry points
+    {
+        double* rec0 = d.data(); double* rec1 = d.data() + 16; double* scratch = d.data() + 32; double* sums = d.data() + 48;
+        EXPECT(scg_mean_std_moments(f.data(), 2, 4, 4, rec0, scratch, nullptr, nullptr) == SCG_ERR_INVALID);           // no sums
+        EXPECT(scg_mean_std_moments(f.data(), 2, 4, 0, rec0, scratch, sums, nullptr) == SCG_ERR_INVALID);              // empty shard
+        EXPECT(scg_mean_std_moments(f.data(), 2, 3, 4, rec0, scratch, sums, nullptr) == SCG_ERR_INVALID);              // ld < n
+        EXPECT(scg_mean_std_moments(f.data(), 2, 4, 4, rec0, scratch, sums, nullptr) == SCG_OK);
+        EXPECT(scg_mean_std_normalize_sums(f.data(), f.data(), 2, 4, 4, 4, rec0, rec0, sums, 8.0, 10.f, 1e-8, nullptr) == SCG_ERR_INVALID);   // aliasing records
+        EXPECT(scg_mean_std_normalize_sums(f.data(), f.data(), 2, 4, 4, 4, rec0, rec1, sums, 3.0, 10.f, 1e-8, nullptr) == SCG_ERR_INVALID);   // fewer rows than this shard's
+        EXPECT(scg_mean_std_normalize_sums(f.data(), f.data(), 2, 4, 4, 4, rec0, rec1, nullptr, 8.0, 10.f, 1e-8, nullptr) == SCG_ERR_INVALID);
+        EXPECT(scg_mean_std_normalize_sums(f.data(), f.data(), 2, 4, 4, 4, rec0, rec1, sums, 8.0, 10.f, 1e-8, nullptr) == SCG_OK);
+        EXPECT(scg_reward_moments(f.data(), nullptr, f.data(), 8, rec0, scratch, sums, 0.99f, nullptr) == SCG_ERR_INVALID);
+        EXPECT(scg_reward_moments(f.data(), u.data(), f.data(), 8, rec0, scratch, sums, 0.99f, nullptr) == SCG_OK);
+        EXPECT(scg_reward_normalize_sums(f.data(), f.data(), 8, rec0, rec0, sums, 16.0, 10.f, 1e-8, nullptr) == SCG_ERR_INVALID);
+        EXPECT(scg_reward_normalize_sums(f.data(), f.data(), 8, rec0, rec1, sums, 7.0, 10.f, 1e-8, nullptr) == SCG_ERR_INVALID);
+        EXPECT(scg_reward_normalize_sums(f.data(), f.data(), 8, rec0, rec1, sums, 16.0, 10.f, 1e-8, nullptr) == SCG_OK);
+    }
     EXPECT(scg_destroy(h) == SCG_OK);
 }
 

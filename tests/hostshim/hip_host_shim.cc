@@ -121,5 +121,9 @@ hipError_t launch_discretize_exact(const float*, const float*, int, int, float, 
 hipError_t launch_loss(int, const double*, const double*, const float*, const float*, const float*, int64_t, const float*, int64_t, float*, float*, float*, int64_t, int64_t, hipStream_t) { ++g_shim.launches; return hipSuccess; }
 hipError_t launch_mean_std_normalize(const float*, float*, int, int64_t, int64_t, int64_t, const double*, double*, double*, float, double, hipStream_t) { ++g_shim.launches; return hipSuccess; }
 hipError_t launch_reward_normalize(const float*, const uint8_t*, float*, float*, int64_t, const double*, double*, double*, float, float, double, int, hipStream_t) { ++g_shim.launches; return hipSuccess; }
+hipError_t launch_mean_std_moments(const float*, int, int64_t, int64_t, const double*, double*, double*, hipStream_t) { ++g_shim.launches; return hipSuccess; }
+hipError_t launch_mean_std_apply_sums(const float*, float*, int, int64_t, int64_t, int64_t, const double*, double*, const double*, double, float, double, hipStream_t) { ++g_shim.launches; return hipSuccess; }
+hipError_t launch_reward_moments(const float*, const uint8_t*, float*, int64_t, const double*, double*, double*, float, hipStream_t) { ++g_shim.launches; return hipSuccess; }
+hipError_t launch_reward_apply_sums(const float*, float*, int64_t, const double*, double*, const double*, double, float, double, hipStream_t) { ++g_shim.launches; return hipSuccess; }
 hipError_t launch_eval_constraints(int, const ConTable*, const float*, const float*, float*, uint8_t*, int64_t, int64_t, hipStream_t) { ++g_shim.launches; return hipSuccess; }
 }  // namespace scg

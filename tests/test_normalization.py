@@ -188,3 +188,135 @@ def test_running_mean_std_update_methods_match_oracle(gpu):
     assert np.abs(dev.mean.cpu().numpy() - ref.mean).max() <= 1e-6 * max(1.0, np.abs(ref.mean).max())
     assert np.abs(dev.var.cpu().numpy() - ref.var).max() <= 1e-5 * max(1.0, np.abs(ref.var).max())
     assert abs(float(dev.count) - ref.count) <= 1e-9
+
+
+# ------------------------------------------------------------------------------------------------------
+# one tracker, the batch spread over several shards (multi-GPU: one process per GPU, each with a shard of the envs)
+def _split_api_call(lib, x_planes, y_planes, n, rec_in, rec_out, scratch, sums_total, total, clip, eps):
+    import ctypes as C
+    d, ld = x_planes.shape
+    assert lib.scg_mean_std_normalize_sums(x_planes.data_ptr(), y_planes.data_ptr(), d, ld, ld, n, rec_in.data_ptr(), rec_out.data_ptr(),
+                                           sums_total.data_ptr(), C.c_double(total), clip, C.c_double(eps), None) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('d', [1, 12])
+def test_shard_sums_reproduce_the_whole_batch_tracker(gpu, d):
+    """scg_mean_std_moments on each of three uneven shards, the sums added, scg_mean_std_normalize_sums on each shard == one
+    scg_mean_std_normalize over the whole batch: the same record (1e-13: the order of a float64 sum) and the same normalised rows
+    (to an ulp of float32).  Likewise the reward normaliser's split."""
+    import torch
+    from safe_control_gym_amd import _capi
+    lib = _capi.load()
+    rng = np.random.default_rng(d)
+    n, cuts = 50000, (0, 20000, 20007, 50000)
+    ld = n + 64
+    x = torch.as_tensor((rng.normal(size=(d, ld)) * rng.uniform(0.1, 20, size=(d, 1)) + rng.normal(0, 30, size=(d, 1))).astype(np.float32), device='cuda')
+    rec = torch.zeros((2, 2 * d + 1), dtype=torch.float64, device='cuda')
+    rec[:, d:2 * d] = 1.0
+    rec[:, 2 * d] = 1e-4
+    scratch = torch.zeros(max(2 * max(64 * d, 1024), 3072), dtype=torch.float64, device='cuda')
+    whole = torch.empty_like(x)
+    rec_whole = rec.clone()
+    assert lib.scg_mean_std_normalize(x.data_ptr(), whole.data_ptr(), d, ld, ld, n, rec_whole[0].data_ptr(), rec_whole[1].data_ptr(),
+                                      scratch.data_ptr(), 5.0, 1e-8, None) == 0
+    total_sums = torch.zeros(2 * d, dtype=torch.float64, device='cuda')
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        sums = torch.zeros(2 * d, dtype=torch.float64, device='cuda')
+        shard = x[:, lo:]                                  # (planes of the shard: same stride, shifted base; 16-byte alignment not assumed)
+        assert lib.scg_mean_std_moments(shard.data_ptr(), d, ld, hi - lo, rec[0].data_ptr(), scratch.data_ptr(), sums.data_ptr(), None) == 0
+        total_sums += sums
+    parts = torch.empty_like(x)
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        rec_out = rec[1].clone()
+        import ctypes as C
+        assert lib.scg_mean_std_normalize_sums(x[:, lo:].data_ptr(), parts[:, lo:].data_ptr(), d, ld, ld, hi - lo, rec[0].data_ptr(),
+                                               rec_out.data_ptr(), total_sums.data_ptr(), C.c_double(float(n)), 5.0, C.c_double(1e-8), None) == 0
+        assert torch.allclose(rec_out, rec_whole[1], rtol=1e-13, atol=1e-13)                 # every shard writes the whole batch's record
+    assert float((parts[:, :n] - whole[:, :n]).abs().max()) <= 1e-6
+    # the reward normaliser's split
+    rew = torch.as_tensor(rng.normal(-1, 2, size=n).astype(np.float32), device='cuda')
+    done = torch.as_tensor(rng.uniform(size=n) < 0.05, device='cuda')
+    ret0 = torch.as_tensor(rng.normal(size=n).astype(np.float32), device='cuda')
+    r1 = torch.tensor([[0.3, 2.0, 40.0], [0, 0, 0]], dtype=torch.float64, device='cuda')
+    ret_whole, out_whole, r_whole = ret0.clone(), torch.empty_like(rew), r1.clone()
+    assert lib.scg_reward_normalize(rew.data_ptr(), done.data_ptr(), ret_whole.data_ptr(), out_whole.data_ptr(), n, r_whole[0].data_ptr(),
+                                    r_whole[1].data_ptr(), scratch.data_ptr(), 0.97, 4.0, 1e-8, 0, None) == 0
+    ret_parts, out_parts, tot3 = ret0.clone(), torch.empty_like(rew), torch.zeros(3, dtype=torch.float64, device='cuda')
+    cuts4 = (0, 20000, 20008, 50000)                         # (float4 / 4-byte groups: shard bases stay aligned for the vector form too)
+    for lo, hi in zip(cuts4[:-1], cuts4[1:]):
+        s3 = torch.zeros(3, dtype=torch.float64, device='cuda')
+        assert lib.scg_reward_moments(rew[lo:].data_ptr(), done[lo:].data_ptr(), ret_parts[lo:].data_ptr(), hi - lo, r1[0].data_ptr(),
+                                      scratch.data_ptr(), s3.data_ptr(), 0.97, None) == 0
+        tot3 += s3
+    for lo, hi in zip(cuts4[:-1], cuts4[1:]):
+        r_out = r1[1].clone()
+        assert lib.scg_reward_normalize_sums(rew[lo:].data_ptr(), out_parts[lo:].data_ptr(), hi - lo, r1[0].data_ptr(), r_out.data_ptr(),
+                                             tot3.data_ptr(), C.c_double(float(n)), 4.0, C.c_double(1e-8), None) == 0
+        assert torch.allclose(r_out, r_whole[1], rtol=1e-13, atol=1e-13)
+    assert torch.equal(ret_parts, ret_whole) and int(tot3[2]) == int(done.sum())
+    assert float((out_parts - out_whole).abs().max()) <= 1e-6
+
+
+def _sync_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    import torch
+    import torch.distributed as dist
+    from safe_control_gym_amd.math_and_models.normalization import MeanStdNormalizer, RewardStdNormalizer
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    rng = np.random.default_rng(99)                                         # every rank draws the whole batch, keeps its shard
+    d, n_shard, calls = 6, 20000, 4
+    on, rn_ = MeanStdNormalizer(shape=(d,), clip=5.0, sync_statistics=True), RewardStdNormalizer(gamma=0.97, clip=4.0, sync_statistics=True)
+    outs = []
+    for k in range(calls):
+        x = (rng.normal(size=(world * n_shard, d)) * (1 + k) + 10.0 * k).astype(np.float32)
+        rew = rng.normal(-1, 2, size=world * n_shard).astype(np.float32)
+        done = rng.uniform(size=world * n_shard) < 0.05
+        sl = slice(rank * n_shard, (rank + 1) * n_shard)
+        y = on(torch.as_tensor(x[sl], device='cuda'))
+        r = rn_(torch.as_tensor(rew[sl], device='cuda'), torch.as_tensor(done[sl], device='cuda'))
+        outs.append((y.cpu().numpy(), r.cpu().numpy()))
+    q.put((rank, on.rms.mean.cpu().numpy(), on.rms.var.cpu().numpy(), float(on.rms.count), float(rn_.rms.var), outs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_shared_statistics_over_a_two_rank_world(gpu):
+    """MeanStdNormalizer / RewardStdNormalizer(sync_statistics=True) in a torch.distributed world of two ranks (gloo; both processes on
+    this GPU), each rank with its half of the batch: every rank's tracker == a single normaliser fed with the whole batch, every
+    rank's normalised rows == that normaliser's rows of the rank's half (normalization.py:125-133 over ALL envs, as the reference's one
+    process computes it)."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    from safe_control_gym_amd.math_and_models.normalization import MeanStdNormalizer, RewardStdNormalizer
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sync_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(99)
+    d, n_shard, calls = 6, 20000, 4
+    on, rn_ = MeanStdNormalizer(shape=(d,), clip=5.0), RewardStdNormalizer(gamma=0.97, clip=4.0)
+    for k in range(calls):
+        x = (rng.normal(size=(world * n_shard, d)) * (1 + k) + 10.0 * k).astype(np.float32)
+        rew = rng.normal(-1, 2, size=world * n_shard).astype(np.float32)
+        done = rng.uniform(size=world * n_shard) < 0.05
+        y = on(torch.as_tensor(x, device='cuda')).cpu().numpy()
+        r = rn_(torch.as_tensor(rew, device='cuda'), torch.as_tensor(done, device='cuda')).cpu().numpy()
+        for rank in range(world):
+            sl = slice(rank * n_shard, (rank + 1) * n_shard)
+            assert np.abs(got[rank][5][k][0] - y[sl]).max() <= 1e-6 and np.abs(got[rank][5][k][1] - r[sl]).max() <= 1e-6, (k, rank)
+    for rank in range(world):
+        assert np.allclose(got[rank][1], on.rms.mean.cpu().numpy(), rtol=1e-12, atol=1e-12)
+        assert np.allclose(got[rank][2], on.rms.var.cpu().numpy(), rtol=1e-11)
+        assert got[rank][3] == pytest.approx(float(on.rms.count), rel=1e-14)
+        assert got[rank][4] == pytest.approx(float(rn_.rms.var), rel=1e-11)
