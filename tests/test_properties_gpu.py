@@ -934,6 +934,19 @@ def test_all_gather_of_episode_returns_through_rccl(gpu):
             got = pending.wait()
             torch.cuda.synchronize()
             assert torch.equal(got, before) and not torch.equal(env.episode_return, before)
+            # the normalisers' shared statistics (sync_statistics: moments -> all-reduce of the sums -> update + normalise) with the
+            # all-reduce on RCCL, device doubles in place; a world of one rank must reproduce the plain normalisers
+            from safe_control_gym_amd.math_and_models.normalization import MeanStdNormalizer, RewardStdNormalizer
+            obs, rew, done, _ = env.step(env.action_buffer)
+            plain, shared = MeanStdNormalizer(shape=(env.obs_dim,)), MeanStdNormalizer(shape=(env.obs_dim,), sync_statistics='force')
+            rp, rs = RewardStdNormalizer(), RewardStdNormalizer(sync_statistics='force')
+            for _ in range(3):
+                a, b = plain(obs), shared(obs)
+                ra, rb = rp(rew, done), rs(rew, done)
+                assert float((a - b).abs().max()) <= 1e-6 and float((ra - rb).abs().max()) <= 1e-6
+                obs, rew, done, _ = env.step(env.action_buffer)
+            assert torch.allclose(plain.rms.mean, shared.rms.mean, rtol=1e-12, atol=1e-12) and torch.allclose(plain.rms.var, shared.rms.var, rtol=1e-9)
+            assert torch.allclose(rp.rms.var, rs.rms.var, rtol=1e-9) and torch.equal(rp.ret, rs.ret)
             env.close()
         finally:
             dist.destroy_process_group()
