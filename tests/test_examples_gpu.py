@@ -29,3 +29,10 @@ def test_linearize_along_trajectory_example(gpu):
     assert '1200 operating points' in out
     gap = float(out.split('the reference:')[1].split()[0])
     assert gap < 1e-3                                   # a linear model one step from its expansion point
+
+
+def test_collect_trajectories_example(gpu):
+    for fused in (0, 1):                                # per-step launches / the one-launch form
+        out = _run('collect_trajectories.py', 4096, 130, fused)
+        assert 'env-steps/s' in out and 'dataset: obs (130, 4096, 6) reward (130, 4096) done (130, 4096) constraint_values (130, 4096, 6)' in out
+        assert int(out.split('episodes finished: ')[1].split(';')[0]) >= 4096          # 2-s episodes: every env finished one
