@@ -249,6 +249,8 @@ class MeanStdNormalizer(BaseNormalizer):
         xv, ld_x, n = self._planes(x)
         d = self.rms.d
         if n == 0:
+            if not self.read_only and self.shared.world() is not None:
+                raise ValueError('[ERROR] sync_statistics: an empty shard cannot take part in the exchange (every rank makes every call).')
             return xv
         ld_y = (n + 63) // 64 * 64
         if out is None:
@@ -306,6 +308,8 @@ class RewardStdNormalizer(MeanStdNormalizer):
             x = torch.as_tensor(x, dtype=torch.float32, device=dev).reshape(-1).contiguous()
         n = x.shape[0]
         if n == 0:
+            if not self.read_only and self.shared.world() is not None:
+                raise ValueError('[ERROR] sync_statistics: an empty shard cannot take part in the exchange (every rank makes every call).')
             return x
         if not (type(dones) is torch.Tensor and dones.dtype in (torch.bool, torch.uint8) and dones.ndim == 1 and dones.device == dev
                 and dones.is_contiguous()):                    # (the per-step case, env.step()'s rew / done, skips both conversions)
