@@ -174,6 +174,27 @@ def test_kat_out_of_bound_done():
     assert not env.step(env.U_GOAL)[2]
 
 
+# ---- the Euler-rate kinematics (quadrotor.py:671-673) against the rotation they belong to: with the attitude rates the model returns,
+#      the rotation matrix R(phi, theta, psi) = Rz Ry Rx (transformations.py:168-182, pinned to SciPy's extrinsic x-y-z in
+#      tests/test_reference_pins.py) must turn with the body rates, dR/dt = R skew(omega) -- a property of the convention, not of the
+#      matrix the reference wrote down (which _dynamics, the executed pin of the other rigid-body terms, does not state)
+def test_euler_rate_kinematics_turn_the_rotation_with_the_body_rates():
+    rng = np.random.default_rng(11)
+    h = 1e-6
+    for _ in range(40):
+        x = np.zeros(12)
+        x[6:9] = rng.uniform(-1.2, 1.2, size=3)
+        x[9:12] = rng.uniform(-6, 6, size=3)
+        hover = [P.m * P.g / 4] * 4
+        ang_dot = np.array(rm.f_quad3d(list(x), hover, P))[6:9]
+        Rp = np.array(rm.rot_xyz(*(x[6:9] + h * ang_dot)))
+        Rm = np.array(rm.rot_xyz(*(x[6:9] - h * ang_dot)))
+        R = np.array(rm.rot_xyz(*x[6:9]))
+        w = x[9:12]
+        skew = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        assert np.abs((Rp - Rm) / (2 * h) - R @ skew).max() < 1e-7       # central difference: O(h^2) + rounding / h
+
+
 # ---- independent derivation (sympy matrix form) vs the hand-expanded oracle
 @pytest.mark.parametrize('system', [2, 3, 'cartpole'])
 def test_independent_derivation_agrees(system):
