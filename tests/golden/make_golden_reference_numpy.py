@@ -24,6 +24,8 @@ Groups written (inputs and the reference's outputs, float64):
                                                                                  envs/env_wrappers/record_episode_statistics.py:92-169
   discretize     discretize_linear_system (exact and Euler; scipy.linalg.expm is importable)   controllers/mpc/mpc_utils.py:24-54
   normalization  RunningMeanStd, MeanStdNormalizer, RewardStdNormalizer                   math_and_models/normalization.py:17-190
+  rk4            the Runge-Kutta statements of rk_discrete (stages k1 .. k4 and their combination), on NumPy vectors with the oracle's
+                 continuous model as f                      controllers/mpc/mpc_utils.py:93-97
   vehicle        BaseAviary._parse_urdf_parameters on the reference's own assets/cf2x.urdf (xml.etree: stdlib), the "Compute constants"
                  statements of BaseAviary.__init__, and the NumPy statements of the explicit rigid-body model BaseAviary._dynamics
                  (forces, mixer torques, gyroscopic term, J_INV, world-frame acceleration), of _physics (forces, yaw torque), of
@@ -240,6 +242,21 @@ SOURCES += top_level('envs/gym_pybullet_drones/base_aviary.py', ['DroneModel'], 
 SOURCES += methods('envs/gym_pybullet_drones/base_aviary.py', 'BaseAviary', ['_parse_urdf_parameters'], NS)
 
 
+def function_statements(rel, name, pick, fn_name, ns, returns):
+    """A run of statements of the top-level function `name`, wrapped unchanged into ``fn_name()`` (everything they read comes from
+    the namespace) that returns the local `returns`: for functions whose head / tail build CasADi objects around plain arithmetic."""
+    tree, path = _tree(rel)
+    f = _find(tree.body, name)
+    chosen = [st for st in f.body if pick(st)]
+    assert chosen, (rel, name)
+    first, last = chosen[0].lineno, chosen[-1].end_lineno
+    fn = ast.FunctionDef(name=fn_name, args=ast.arguments(posonlyargs=[], args=[], kwonlyargs=[], kw_defaults=[], defaults=[]),
+                         body=chosen + [ast.Return(value=ast.Name(id=returns, ctx=ast.Load()))], decorator_list=[], lineno=first, col_offset=0)
+    ast.fix_missing_locations(fn)
+    _exec_nodes([fn], path, ns)
+    return [(rel, '%s statements' % name, first, last)]
+
+
 def class_assignments(rel, cls, names, ns, prefix):
     """The class-level assignments `names` of class `cls` (its default tables), executed unchanged; the values land in `ns` under
     ``prefix + name``."""
@@ -255,6 +272,11 @@ def class_assignments(rel, cls, names, ns, prefix):
     return out
 
 
+# rk_discrete: the four stages and their combination (the CasADi symbols above them and the cs.Function below are not executed; X, U,
+# f and dt are read from the namespace: NumPy vectors and a plain callable)
+SOURCES += function_statements('controllers/mpc/mpc_utils.py', 'rk_discrete',
+                                lambda st: isinstance(st, ast.Assign) and any(isinstance(t, ast.Name) and t.id in ('k1', 'k2', 'k3', 'k4', 'x_next')
+                                                                              for t in st.targets), 'rk4_statements', NS, 'x_next')
 SOURCES += class_assignments('envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor',
                              ['DISTURBANCE_MODES', 'INERTIAL_PROP_RAND_INFO', 'INIT_STATE_RAND_INFO', 'TASK_INFO'], NS, 'Quadrotor_')
 SOURCES += method_statements('envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor', '__init__', lambda st: _assigns_self(st, 'INIT_STATE_LABELS'),
@@ -870,6 +892,34 @@ def gen_defaults():
              'self.INIT_STATE_LABELS (quadrotor.py:207-212), as the executed statements define them')
 
 
+def gen_rk4():
+    """rk_discrete's Runge-Kutta statements (mpc_utils.py:93-97), executed on NumPy vectors with the ORACLE's continuous model as `f`:
+    what is pinned is the integration rule (stages, weights, zero-order-hold input), for every system and two step sizes."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import ref_model as rm
+    rng = np.random.default_rng(20261006)
+    cases = []
+    for system in (1, 2, 3, 'cartpole'):
+        p = rm.CartPoleParams() if system == 'cartpole' else rm.QuadParams()
+        f = rm.F_BY_SYSTEM[system]
+        nx, nu = rm.NX[system], rm.NU[system]
+        for dt in (1.0 / 60.0, 1.0 / 50.0, 1.0 / 240.0):
+            xs = rng.normal(size=(8, nx)) * 0.4
+            us = rng.uniform(-3, 3, size=(8, nu)) if system == 'cartpole' else rng.uniform(0.03, 0.14, size=(8, nu))
+            out = []
+            for x, u in zip(xs, us):
+                NS['X'], NS['U'], NS['dt'] = x.copy(), u.copy(), dt
+                NS['f'] = lambda X, U: np.asarray(f(list(X), list(U), p), dtype=np.float64)
+                out.append(NS['rk4_statements']())
+            key = 'rk4/%s/%d' % (system, len(cases))
+            put(key + '/x', xs); put(key + '/u', us); put(key + '/x_next', out)
+            cases.append(dict(key=key, system=system, dt=dt))
+    for k in ('X', 'U', 'dt', 'f'):
+        NS.pop(k, None)
+    MANIFEST['groups']['rk4'] = dict(cases=cases, note='x_next = the k1 .. k4 / x_next statements of rk_discrete (mpc_utils.py:93-97) with f = '
+                                                       'oracle.ref_model.F_BY_SYSTEM[system] (nominal parameters), X / U NumPy vectors')
+
+
 def gen_vehicle():
     """The vehicle's constants and its explicit NumPy rigid-body statements, executed."""
     from scipy.spatial.transform import Rotation
@@ -958,6 +1008,7 @@ def main():
     gen_ppo_buffer(np.random.default_rng(77))     # (appended; its own generator)
     gen_vehicle()              # (appended; its own generator)
     gen_defaults()             # (appended; draws nothing)
+    gen_rk4()                  # (appended; its own generator)
     OUT['manifest'] = np.array(json.dumps(MANIFEST))
     np.savez_compressed(os.path.join(HERE, 'reference_numpy.npz'), **OUT)
     print('wrote %d arrays, %d reference symbols executed' % (len(OUT) - 1, len(SOURCES)))

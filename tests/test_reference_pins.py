@@ -39,6 +39,7 @@ def test_manifest_lists_the_executed_reference_symbols():
                  ('safe_control_gym/envs/gym_pybullet_drones/base_aviary.py', 'BaseAviary._parse_urdf_parameters'),
                  ('safe_control_gym/envs/gym_pybullet_drones/base_aviary.py', 'BaseAviary._dynamics statements'),
                  ('safe_control_gym/envs/gym_pybullet_drones/base_aviary.py', 'BaseAviary._physics statements'),
+                 ('safe_control_gym/controllers/mpc/mpc_utils.py', 'rk_discrete statements'),
                  ('safe_control_gym/envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor.INIT_STATE_RAND_INFO (class attribute)'),
                  ('safe_control_gym/envs/gym_pybullet_drones/base_aviary.py', 'BaseAviary._ground_effect statements'),
                  ('safe_control_gym/envs/gym_pybullet_drones/base_aviary.py', 'BaseAviary._drag statements')):
@@ -82,6 +83,20 @@ def test_default_tables_match_the_reference_class_attributes():
     assert {str(int(k)): v for k, v in Quadrotor._LABELS.items()} == d['INIT_STATE_LABELS']
     assert {str(k): v for k, v in ref_env.INIT_STATE_LABELS.items() if k != 'cartpole'} == d['INIT_STATE_LABELS']
     assert set(d['DISTURBANCE_MODES']) == {'observation', 'action', 'dynamics'}     # dims are set at run time (quadrotor.py:808-813)
+
+
+@pytest.mark.parametrize('case', GROUPS['rk4']['cases'], ids=lambda c: '%s_dt%.4f' % (c['system'], c['dt']))
+def test_oracle_rk4_matches_the_reference_rk_discrete_statements(case):
+    """oracle.ref_model.rk4_step == the k1 .. k4 / x_next statements of rk_discrete (controllers/mpc/mpc_utils.py:93-97), executed on
+    NumPy vectors with the same continuous model: stages, weights and the zero-order-hold input of the integration rule."""
+    from oracle import ref_model
+    system = case['system']
+    p = ref_model.CartPoleParams() if system == 'cartpole' else ref_model.QuadParams()
+    f = ref_model.F_BY_SYSTEM[system]
+    xs, us, want = G[case['key'] + '/x'], G[case['key'] + '/u'], G[case['key'] + '/x_next']
+    for x, u, w in zip(xs, us, want):
+        got = np.asarray(ref_model.rk4_step(f, list(x), list(u), p, case['dt']))
+        assert np.abs(got - w).max() <= 1e-14 * max(1.0, np.abs(w).max())
 
 
 def _scaled_err(a, b):
@@ -447,6 +462,22 @@ def test_oracle_normalisers_match_reference_classes():
 # ---------------------------------------------------------------------------------------------------------------------
 # GPU: the HIP path against the reference's output
 # ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [c for c in GROUPS['rk4']['cases'] if abs(c['dt'] - 1 / 60) < 1e-9], ids=lambda c: str(c['system']))
+def test_device_model_step_matches_the_reference_rk_discrete_statements(gpu, case):
+    """env.model_step (the device's f + RK4 over one control step: scg_model_eval) against the executed rk_discrete statements."""
+    import torch
+    import safe_control_gym_amd as scg
+    system = case['system']
+    xs, us, want = G[case['key'] + '/x'], G[case['key'] + '/u'], G[case['key'] + '/x_next']
+    kw = dict(num_envs=xs.shape[0], device='cuda', seed=0, ctrl_freq=60, pyb_freq=240)
+    env = scg.make('cartpole', **kw) if system == 'cartpole' else scg.make('quadrotor', quad_type=system, task='traj_tracking', **kw)
+    env.reset()
+    got = env.model_step(torch.as_tensor(xs, dtype=torch.float32, device='cuda'), torch.as_tensor(us, dtype=torch.float32, device='cuda'))
+    assert rel_err(got.double().cpu().numpy(), want) < RTOL
+    env.close()
+
+
 @pytest.mark.gpu
 def test_device_model_matches_the_reference_explicit_dynamics(gpu):
     """scg_model_eval (the device's f(x, u), csrc/scg_dynamics.h) against BaseAviary._dynamics' executed statements: translational and
