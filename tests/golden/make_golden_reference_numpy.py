@@ -24,6 +24,7 @@ Groups written (inputs and the reference's outputs, float64):
                                                                                  envs/env_wrappers/record_episode_statistics.py:92-169
   discretize     discretize_linear_system (exact and Euler; scipy.linalg.expm is importable)   controllers/mpc/mpc_utils.py:24-54
   normalization  RunningMeanStd, MeanStdNormalizer, RewardStdNormalizer                   math_and_models/normalization.py:17-190
+  quadratic_cost the cost_func statement of Quadrotor._setup_symbolic on NumPy columns              envs/gym_pybullet_drones/quadrotor.py:682
   rk4            the Runge-Kutta statements of rk_discrete (stages k1 .. k4 and their combination), on NumPy vectors with the oracle's
                  continuous model as f                      controllers/mpc/mpc_utils.py:93-97
   vehicle        BaseAviary._parse_urdf_parameters on the reference's own assets/cf2x.urdf (xml.etree: stdlib), the "Compute constants"
@@ -277,6 +278,11 @@ def class_assignments(rel, cls, names, ns, prefix):
 SOURCES += function_statements('controllers/mpc/mpc_utils.py', 'rk_discrete',
                                 lambda st: isinstance(st, ast.Assign) and any(isinstance(t, ast.Name) and t.id in ('k1', 'k2', 'k3', 'k4', 'x_next')
                                                                               for t in st.targets), 'rk4_statements', NS, 'x_next')
+# the quadratic cost of _setup_symbolic (quadrotor.py:682): one statement of operators on X, Xr, Q, U, Ur, R -- no cs.* call in it -- read
+# from the namespace as NumPy column vectors / matrices (the CasADi symbols of the lines above it are not executed)
+SOURCES += method_statements('envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor', '_setup_symbolic',
+                             lambda st: isinstance(st, ast.Assign) and any(isinstance(t, ast.Name) and t.id == 'cost_func' for t in st.targets),
+                             'quadratic_cost_statement', NS, returns='cost_func')
 SOURCES += class_assignments('envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor',
                              ['DISTURBANCE_MODES', 'INERTIAL_PROP_RAND_INFO', 'INIT_STATE_RAND_INFO', 'TASK_INFO'], NS, 'Quadrotor_')
 SOURCES += method_statements('envs/gym_pybullet_drones/quadrotor.py', 'Quadrotor', '__init__', lambda st: _assigns_self(st, 'INIT_STATE_LABELS'),
@@ -920,6 +926,31 @@ def gen_rk4():
                                                        'oracle.ref_model.F_BY_SYSTEM[system] (nominal parameters), X / U NumPy vectors')
 
 
+def gen_quadratic_cost():
+    """cost_func = 0.5 (X - Xr)' Q (X - Xr) + 0.5 (U - Ur)' R (U - Ur) (quadrotor.py:682), executed on NumPy columns: identity, diagonal and
+    full (non-symmetric) weights for every system size."""
+    rng = np.random.default_rng(20261007)
+    cases = []
+    fn = types.MethodType(NS['quadratic_cost_statement'], Holder())
+    for nx, nu in ((2, 1), (6, 2), (12, 4), (4, 1)):
+        for kind in ('identity', 'diagonal', 'full'):
+            Q = np.eye(nx) if kind == 'identity' else (np.diag(rng.uniform(0.1, 5, nx)) if kind == 'diagonal' else rng.normal(size=(nx, nx)))
+            R = np.eye(nu) if kind == 'identity' else (np.diag(rng.uniform(0.1, 5, nu)) if kind == 'diagonal' else rng.normal(size=(nu, nu)))
+            xs, xr, us, ur = rng.normal(size=(8, nx)), rng.normal(size=(8, nx)), rng.normal(size=(8, nu)), rng.normal(size=(8, nu))
+            out = []
+            for k in range(8):
+                NS.update(X=xs[k].reshape(nx, 1), Xr=xr[k].reshape(nx, 1), U=us[k].reshape(nu, 1), Ur=ur[k].reshape(nu, 1), Q=Q, R=R)
+                out.append(float(np.asarray(fn()).reshape(())))
+            key = 'quadratic_cost/%d' % len(cases)
+            for name, v in (('Q', Q), ('R', R), ('x', xs), ('xr', xr), ('u', us), ('ur', ur), ('l', out)):
+                put(key + '/' + name, v)
+            cases.append(dict(key=key, nx=nx, nu=nu, weights=kind))
+    for k in ('X', 'Xr', 'U', 'Ur', 'Q', 'R'):
+        NS.pop(k, None)
+    MANIFEST['groups']['quadratic_cost'] = dict(cases=cases, note='l = the cost_func statement of Quadrotor._setup_symbolic (quadrotor.py:682) on NumPy '
+                                                                  'columns; the reward of cost: quadratic is -l (quadrotor.py:918-930)')
+
+
 def gen_vehicle():
     """The vehicle's constants and its explicit NumPy rigid-body statements, executed."""
     from scipy.spatial.transform import Rotation
@@ -1009,6 +1040,7 @@ def main():
     gen_vehicle()              # (appended; its own generator)
     gen_defaults()             # (appended; draws nothing)
     gen_rk4()                  # (appended; its own generator)
+    gen_quadratic_cost()       # (appended; its own generator)
     OUT['manifest'] = np.array(json.dumps(MANIFEST))
     np.savez_compressed(os.path.join(HERE, 'reference_numpy.npz'), **OUT)
     print('wrote %d arrays, %d reference symbols executed' % (len(OUT) - 1, len(SOURCES)))
