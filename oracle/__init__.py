@@ -33,6 +33,15 @@ Pinning status
   ``safe_control_gym.envs.disturbances``, RUN in the build container with a stub ``np_random`` to record
   ``tests/golden/disturbances.json`` (``tests/golden/make_golden_disturbances.py``); ``ref_disturbances``
   reproduces those recordings to 1e-13.
+* (d) **the reference's own NumPy code, executed**: ``tests/golden/make_golden_reference_numpy.py`` parses the cited reference files
+  with ``ast``, compiles 64 definitions / statement runs unchanged and runs them with NumPy and plain attribute holders (no module is
+  stubbed; nothing that needs casadi / pybullet / gym is executed); ``tests/test_reference_pins.py`` replays this package against the
+  recorded inputs and outputs (<= 1e-12).  Covered: motor map, trajectory generators and projection, X_GOAL assembly, every
+  Constraint class, bounds, randomisation, the step glue, the vector-env wrappers, the PPO buffer and GAE, the normalisers,
+  discretisation, the vehicle constants (URDF parser), the rigid-body terms of the 3-D model (``BaseAviary._dynamics`` /
+  ``_physics``), ground effect and drag, the Runge-Kutta statements of ``rk_discrete``, the quadratic cost statement, the default
+  tables.  NOT covered (CasADi builds them): the Euler-rate kinematics as the reference writes them (checked as a property of the
+  pinned rotation instead), the Jacobians, ``fd_func``.
 * ``ref_linearize`` differentiates the reference's matrix-form dynamics symbolically (the sympy analogue of the
   reference's ``cs.jacobian``) and is cross-checked by central differences; ``ref_normalization`` restates
   ``math_and_models/normalization.py`` (not importable: it imports gym) and is pinned by the identity "Chan's
