@@ -30,7 +30,10 @@ values measure scaling and nothing else:
   * At N = 1 the line also carries sub-records, each a few hundred ms: ``c4_without_episode_stats`` (the bare 125-byte
     step), ``precise_mode`` / ``precise_mode_attitude`` (the <= 1e-5-drift-over-1000-steps modes), ``c3`` and ``c2`` (BASELINE configs 3
     and 2), ``n_sweep`` (the north-star's N in {1k .. 1M}: the bare step at 2^10 .. 2^20 envs through scg_rollout, and beside it the same
-    action sequences through the one-launch open-loop form scg_rollout_fused).
+    action sequences through the one-launch open-loop form scg_rollout_fused), ``feature_tiers`` (C4 with one option changed: default
+    info, goal horizon, constraints, randomised inertial properties, in-kernel noise), ``step_api`` (env.step() from Python with a policy
+    kernel between the steps: plain, pipelined shards, replayed from a HIP graph), ``rl_pipeline`` (policy -> step -> normalisers ->
+    bootstrap -> PPOBuffer rows -> GAE, at 2^20 and at 2^14 envs) and ``north_star_target`` (which record meets which clause).
 Actions are i.i.d. U(a_low, a_high) float32, pre-generated on the device ([300, nu, N]) and reused cyclically; initial /
 reset states are nominal + the reference's uniform offsets (Philox on device).  Inputs are resident in HBM when the
 timed region starts.
@@ -886,6 +889,22 @@ def run_rank(args):
             note="compensated_state='attitude': int16 residual planes (40 significant bits) and double accumulation for attitude + body "
                  'rates only (states 6..11), float32 sin / cos and positions / velocities; same drift bound, measured on hover and on this workload '
                  '(tests/test_parity_gpu.py::test_precise_mode_open_loop_1000_step_drift)')
+        # the configurations a user actually runs, same clock, same rollout() on two queues (us per step of the whole batch only: their byte
+        # counts differ per tier and are not claimed against the roofline here)
+        tiers = {
+            'default_make_info': {'info_level': 'full'},
+            'goal_horizon_rl_reward': {'cost': 'rl_reward', 'obs_goal_horizon': 1},
+            'normalized_actions_rl_reward': {'cost': 'rl_reward', 'normalized_rl_action_space': True},
+            'constraints_14_rows': {'constraints': [{'constraint_form': 'default_constraint', 'constrained_variable': 'input'},
+                                                    {'constraint_form': 'bounded_constraint', 'constrained_variable': 'state', 'active_dims': [0, 2, 4],
+                                                     'lower_bounds': [-3, -3, -0.1], 'upper_bounds': [3, 3, 2]}]},
+            'randomized_inertial_prop': {'randomized_inertial_prop': True},
+            'randomized_inertial_prop_goal_horizon': {'randomized_inertial_prop': True, 'cost': 'rl_reward', 'obs_goal_horizon': 1},
+            'white_action_noise': {'disturbances': {'action': [{'disturbance_func': 'white_noise', 'std': 0.001}]}},
+            'white_observation_noise': {'disturbances': {'observation': [{'disturbance_func': 'white_noise', 'std': 0.01}]}},
+        }
+        out['feature_tiers'] = {'workload': 'C4 with one option changed, %d envs, rollout() on two queues' % n, 'unit': 'us per step',
+                                'us_per_step': {k: sub_record(args, timer, 'c4', n, sub_steps, extra=kw)['us_per_step'] for k, kw in tiers.items()}}
         out['step_api'] = step_api_record(args, n, 300)
         out['rl_pipeline'] = rl_pipeline_record(args, n, 128)
         if n > 1 << 14:
