@@ -507,7 +507,7 @@ def rl_pipeline_record(args, n, T):
     dev = env.device
     w_act = torch.tensor([0.3, -0.2, 0.1, 0.25], device=dev).reshape(nu, 1)
     b_act = torch.tensor([0.05, -0.05, 0.02, 0.0], device=dev).reshape(nu, 1)
-    w0, w1, bias = torch.tensor(0.3, device=dev), torch.tensor(-0.2, device=dev), torch.tensor([0.05], device=dev)
+    w1, bias = torch.tensor(-0.2, device=dev), torch.tensor([0.05], device=dev)       # (the first weight, 0.3, rides in torch.add's alpha)
     zeros = torch.zeros(n, device=dev)
     rec = env._bufs['terminal_record']         # row-major [ld, stride]: the terminal observation of a finishing env in columns 0 .. od - 1
 
