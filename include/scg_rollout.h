@@ -247,7 +247,11 @@ typedef struct scg_step_io {
                                         [obs_dim]     the finished episode's return (float), [obs_dim + 1] its length
                                                       (int32 bits) -- info['episode']['r' / 'l']
                                                       (record_episode_statistics.py:155-158); 0 without ep_return */
-    int64_t terminal_stride;         /* floats per record: a multiple of 4, >= obs_dim + 2 */
+    int64_t terminal_stride;         /* floats per record: a multiple of 4, >= obs_dim + 2.  0: terminal_record is SoA planes
+                                        [obs_dim + 2][ld] instead (plane j = member j of the record; done lanes only) -- for a
+                                        consumer that reads the terminal observations of ALL envs every step (the critic of the
+                                        time-limit bootstrap, controllers/ppo/ppo.py:264-273): 4 obs_dim bytes per env to read
+                                        instead of 4 terminal_stride, paid for by obs_dim + 2 partial-line stores per finished env */
     double* stats;                   /* nullable [SCG_STATS_STRIPES][8] batch sums, accumulated with one f64 atomic per
                                         wave and statistic; the waves spread over the stripes (same-address f64 atomics
                                         serialise at ~40 ns each), the caller adds the stripes up.  Columns:

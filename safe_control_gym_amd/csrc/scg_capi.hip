@@ -708,9 +708,9 @@ static int step_check(const scg_handle* h, const scg_step_io* io, int64_t n, con
         return fail(SCG_ERR_INVALID, "%s: obs_goal_horizon > 0 needs an obs buffer (obs does not alias state)", who);
     if (io->obs_noise && !io->obs)
         return fail(SCG_ERR_INVALID, "%s: obs_noise needs an obs buffer", who);
-    if (io->terminal_record && (io->terminal_stride < h->obs_dim + 2 || (io->terminal_stride & 3)))
-        return fail(SCG_ERR_INVALID, "%s: terminal_stride must be a multiple of 4 and >= obs_dim + 2 = %d (got %lld)", who,
-                    h->obs_dim + 2, (long long)io->terminal_stride);
+    if (io->terminal_record && io->terminal_stride != 0 && (io->terminal_stride < h->obs_dim + 2 || (io->terminal_stride & 3)))
+        return fail(SCG_ERR_INVALID, "%s: terminal_stride must be 0 (planes [obs_dim + 2][ld]) or a multiple of 4 >= obs_dim + 2 = %d (got %lld)",
+                    who, h->obs_dim + 2, (long long)io->terminal_stride);
     if (io->action_rows > 1 || (io->action_rows && (reinterpret_cast<uintptr_t>(io->action) % (4u * h->nu)) != 0))
         return fail(SCG_ERR_INVALID, "%s: row-major actions must be %d-byte aligned (action_rows in {0, 1})", who, 4 * h->nu);
     if (int rc = check_dist_io(h, io, who)) return rc;
@@ -802,7 +802,7 @@ static scg_step_io shifted_io(const scg_step_io& io, int64_t first) {
     s.truncated = u8(io.truncated);
     s.goal_reached = u8(io.goal_reached);
     s.mse = const_cast<float*>(f32(io.mse));
-    s.terminal_record = io.terminal_record ? io.terminal_record + first * io.terminal_stride : nullptr;
+    s.terminal_record = io.terminal_record ? io.terminal_record + first * (io.terminal_stride ? io.terminal_stride : 1) : nullptr;   // records | planes
     return s;
 }
 

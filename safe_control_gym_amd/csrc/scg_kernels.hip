@@ -1214,7 +1214,31 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
 #define SCG_NT_RECORD 1        // 0 (bisect arm): the terminal record leaves as plain stores
 #endif
                     const bool packed_record = !(OBS && p.obs_goal_horizon > 0) && (reinterpret_cast<uintptr_t>(io.terminal_record) & 15u) == 0;
-                    if (packed_record) {
+                    if (io.terminal_stride == 0) {
+                        // SoA planes [obs_dim + 2][ld] (scg_step_io.terminal_stride == 0): the layout for a consumer that reads the terminal
+                        // observations of ALL envs every step (the time-limit bootstrap's critic): 4 obs_dim bytes per env instead of the
+                        // records' 4 terminal_stride; the finishing lanes pay obs_dim + 2 partial-line stores instead of one record
+                        float* base = io.terminal_record;
+#pragma unroll
+                        for (int j = 0; j < NX; ++j) stp(PLS(base, j), i4, ov[j]);
+                        if (OBS && p.obs_goal_horizon > 0) {
+                            if (tracking) {
+                                for (int k = 0; k < p.obs_goal_horizon; ++k) {
+                                    float g[NX];
+                                    load_goal<NX>(p, ref, s_tab, t + 1 + k, g);
+#pragma unroll
+                                    for (int j = 0; j < NX; ++j) stp(PLS(base, NX * (1 + k) + j), i4, g[j]);
+                                }
+                                od = NX * (1 + p.obs_goal_horizon);
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < NX; ++j) stp(PLS(base, NX + j), i4, tb->x_goal[j]);
+                                od = 2 * NX;
+                            }
+                        }
+                        stp(PLS(base, od), i4, epr);
+                        stp(PLS(base, od + 1), i4, __int_as_float(epl));
+                    } else if (packed_record) {
                         typedef float v4 __attribute__((ext_vector_type(4)));
                         constexpr int W4 = (NX + 2 + 3) / 4;
                         float buf[4 * W4];

@@ -305,6 +305,13 @@ class BenchmarkEnv:
         if self._output_ring and self._output_ring < 3:
             raise ValueError('[ERROR] output_ring must be 0 (off) or >= 3.')
         self._ring, self._ring_pos = None, 0
+        # terminal_layout='planes': info['terminal_observation'] / info['episode'] live in SoA planes [obs_dim + 2][ld] instead of one
+        # dense record per env -- for a caller that runs a critic over the terminal observations of ALL envs every step (the
+        # time-limit bootstrap, controllers/ppo/ppo.py:264-273): it then reads 4 obs_dim bytes per env, coalesced, instead of the
+        # records' stride; the envs that finish pay obs_dim + 2 small stores instead of one record
+        self._terminal_planes = {'records': False, 'planes': True}.get(kwargs.get('terminal_layout', 'records'))
+        if self._terminal_planes is None:
+            raise ValueError("[ERROR] terminal_layout must be 'records' or 'planes'.")
 
     # ------------------------------------------------------------------ seeding
     def seed(self, seed=None):
@@ -604,7 +611,8 @@ class BenchmarkEnv:
             b['truncated'] = torch.zeros(ld, dtype=torch.bool, device=dev)
             # one dense row per env: terminal observation | finished-episode return | length (int32 bits), written by
             # the lanes that finish an episode (a multiple of 8 floats: whole 32-byte DRAM sectors)
-            b['terminal_record'] = torch.zeros((ld, (self.obs_dim + 2 + 7) // 8 * 8), dtype=f32, device=dev)
+            b['terminal_record'] = torch.zeros((self.obs_dim + 2, ld) if self._terminal_planes else (ld, (self.obs_dim + 2 + 7) // 8 * 8),
+                                               dtype=f32, device=dev)
             if self.TASK == Task.STABILIZATION and self.COST == Cost.QUADRATIC:
                 b['goal_reached'] = torch.zeros(ld, dtype=torch.bool, device=dev)
         self._bufs = b
@@ -628,9 +636,14 @@ class BenchmarkEnv:
             info['TimeLimit.truncated'] = b['truncated'][:n]
         if 'terminal_record' in b:
             rec, od = b['terminal_record'], self.obs_dim
-            info['terminal_observation'] = rec[:n, :od]
-            if self.TRACK_EPISODE_STATS:
-                info['episode'] = {'r': rec[:n, od], 'l': rec.view(torch.int32)[:n, od + 1]}
+            if self._terminal_planes:
+                info['terminal_observation'] = rec[:od, :n].T                  # [N, obs_dim] zero-copy transpose, as the observation is
+                if self.TRACK_EPISODE_STATS:
+                    info['episode'] = {'r': rec[od, :n], 'l': rec.view(torch.int32)[od + 1, :n]}
+            else:
+                info['terminal_observation'] = rec[:n, :od]
+                if self.TRACK_EPISODE_STATS:
+                    info['episode'] = {'r': rec[:n, od], 'l': rec.view(torch.int32)[:n, od + 1]}
         self._info_views = info
         self._out_views = ((b['obs'] if 'obs' in b else b['state'])[:, :n].T, b['reward'][:n], b['done'][:n])
         self._out_view_cache = {}

@@ -92,7 +92,8 @@ class Engine:
         io = self._io
         io.ld = ld
         rec = bufs.get('terminal_record')
-        io.terminal_stride = rec.shape[1] if rec is not None else 0
+        # row-major records [ld, stride], or SoA planes [obs_dim + 2, ld] (terminal_stride 0)
+        io.terminal_stride = rec.shape[1] if (rec is not None and rec.shape[0] == ld) else 0
         lo = bufs.get('state_lo')
         # [6, ld]: attitude-only residuals, as float32 (kind 1) or int16 (kind 2) planes
         io.state_lo_kind = 0 if (lo is None or lo.shape[0] == self.nx) else (2 if lo.dtype == torch.int16 else 1)

@@ -203,6 +203,8 @@ static void check_step_and_rollout() {
       x.io.state_out = x.io.state; EXPECT(scg_rollout(h, &x.io, 8, 2, 0, 1, nullptr) == SCG_OK); }
     { Buffers x(64); x.io.terminal_record = x.f.data(); x.io.terminal_stride = 13; EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_ERR_INVALID); }
     { Buffers x(64); x.io.terminal_record = x.f.data(); x.io.terminal_stride = 16; EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_OK); }
+    { Buffers x(64); x.io.terminal_record = x.f.data(); x.io.terminal_stride = 0; EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_OK); }   // SoA planes [obs_dim + 2][ld]
+    { Buffers x(64); x.io.terminal_record = x.f.data(); x.io.terminal_stride = 8; EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_ERR_INVALID); }   // a record shorter than obs_dim + 2
     { Buffers x(64); x.io.action_rows = 2; EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_ERR_INVALID); }
     { Buffers x(64); x.io.action_rows = 1; x.io.action = x.f.data() + 1; EXPECT(scg_step(h, &x.io, 8, nullptr) == SCG_ERR_INVALID); }
     { Buffers x((int64_t)1 << 31); EXPECT(scg_step(h, &x.io, ((int64_t)1 << 30) + 1, nullptr) == SCG_ERR_INVALID); }

@@ -173,6 +173,56 @@ def test_asynchronous_step_with_an_adversary_equals_the_plain_step(gpu, mode):
     a_env.close(); b_env.close()
 
 
+PLANE_TIERS = {
+    'info': dict(quad_type=3, task='traj_tracking', cost='quadratic'),
+    'info_constraints_2d': dict(quad_type=2, task='stabilization', cost='rl_reward', constraints=C3_CONSTRAINTS),
+    'goal_horizon': dict(quad_type=2, task='traj_tracking', cost='rl_reward', obs_goal_horizon=2),
+    'stabilisation_goal_in_obs': dict(quad_type=2, task='stabilization', cost='rl_reward', obs_goal_horizon=1),
+    'obs_noise': dict(quad_type=2, task='stabilization', cost='rl_reward', disturbances={'observation': [{'disturbance_func': 'white_noise', 'std': 0.01}]}),
+    'inertial': dict(quad_type=3, task='traj_tracking', cost='quadratic', randomized_inertial_prop=True),
+    'catch_all_drag': dict(quad_type=3, task='traj_tracking', cost='quadratic', physics='pyb_drag'),
+    'cartpole': dict(task='stabilization', cost='quadratic', ctrl_freq=50, pyb_freq=50),
+}
+
+
+@pytest.mark.parametrize('tier', list(PLANE_TIERS))
+def test_terminal_planes_hold_what_the_terminal_records_hold(gpu, tier):
+    """terminal_layout='planes' (scg_step_io.terminal_stride == 0: SoA planes [obs_dim + 2][ld] instead of one dense record per env):
+    for every env that finishes, info['terminal_observation'] / info['episode'] equal the record layout's, everything else equals bit
+    for bit; through step() and through a pipelined shard pair (the shard's planes are the whole batch's, shifted)."""
+    kw = _common(PLANE_TIERS[tier])
+    name = 'cartpole' if tier == 'cartpole' else 'quadrotor'
+    n, steps = 2500, 75
+    a_env = scg.make(name, num_envs=n, **kw)
+    b_env = scg.make(name, num_envs=n, terminal_layout='planes', **kw)
+    venv = make_vec_envs(partial(scg.make, name, terminal_layout='planes', **kw), batch_size=n, num_pipelines=2)
+    policy = _policy(a_env)
+    oa, ob = a_env.reset(), b_env.reset()
+    assert b_env._bufs['terminal_record'].shape == (b_env.obs_dim + 2, b_env.plane_stride)
+    oc = [venv.reset(pipeline=p)[0] for p in range(2)]
+    hits = 0
+    for k in range(steps):
+        act = policy(oa, k)
+        oa, ra, da, ia = a_env.step(act)
+        ob, rb, db, ib = b_env.step(act)
+        for p, (lo, hi) in enumerate(venv.bounds):
+            venv.step_async(act[lo:hi], pipeline=p)
+        outs = [venv.step_wait(pipeline=p) for p in range(2)]
+        _same(ob, oa, 'obs'); _same(rb, ra, 'reward'); _same(db, da, 'done')
+        _same(torch.cat([o[0] for o in outs]), oa, 'shard obs')
+        d = da.bool()
+        if bool(d.any()):
+            hits += int(d.sum())
+            _same(ib['terminal_observation'][d], ia['terminal_observation'][d], 'terminal observation at step %d' % k)
+            _same(torch.cat([o[3]['terminal_observation'] for o in outs])[d], ia['terminal_observation'][d], 'shard terminal observation')
+            if 'episode' in ia:
+                _same(ib['episode']['r'][d], ia['episode']['r'][d], 'episode return'); _same(ib['episode']['l'][d], ia['episode']['l'][d], 'episode length')
+                _same(torch.cat([o[3]['episode']['l'] for o in outs])[d], ia['episode']['l'][d], 'shard episode length')
+        _same(ib['TimeLimit.truncated'], ia['TimeLimit.truncated'], 'truncated')
+    assert hits >= n
+    a_env.close(); b_env.close(); venv.close()
+
+
 SINK_CASES = {
     'c4_lean': ('quadrotor', dict(quad_type=3, task='traj_tracking', cost='quadratic', info_level='minimal')),
     'c3_constraints': ('quadrotor', dict(quad_type=2, task='stabilization', cost='rl_reward', constraints=C3_CONSTRAINTS,
