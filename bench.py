@@ -511,6 +511,9 @@ def rl_pipeline_record(args, n, T):
     w1, bias = torch.tensor(-0.2, device=dev), torch.tensor([0.05], device=dev)       # (the first weight, 0.3, rides in torch.add's alpha)
     zeros = torch.zeros(n, device=dev)
     rec = env._bufs['terminal_record']         # terminal_layout='planes': [od + 2, ld], plane j = observed state j of the envs that finished
+    # (planes: the bootstrap's critic reads 4 od bytes per env instead of a 112-byte record; every env that finishes pays od + 2 partial-line
+    # stores for it, so the layout wins while fewer than ~2 % of the envs finish per step -- this stand-in policy keeps them flying to the
+    # time limit; profiles/r04/terminal_planes_ab.txt has the other end, i.i.d. random actions: +10 us on the step)
 
     def actor(obs, out):                       # obs [n, od] is a transposed view of planes; out = the buffer's action planes [nu, ld]: ONE
         torch.addcmul(b_act, obs.T[:nu], w_act, out=out[:, :n])          # kernel, coalesced (the env clips the normalised action itself)
