@@ -599,7 +599,8 @@ def rl_pipeline_record(args, n, T):
     wall_graph = (time.perf_counter() - t0) / reps
     rec = {'workload': 'Quadrotor-3D tracking, rl_reward, normalised actions, default make() info (time-limit bootstrap); %d envs x %d steps per '
                        'rollout: stand-in policy + critic -> env.step -> MeanStdNormalizer -> RewardStdNormalizer -> terminal value -> '
-                       'PPOBuffer(env=...) rows -> scg_gae + advantage normalisation' % (n, T),
+                       'PPOBuffer(env=...) rows -> scg_gae + advantage normalisation; terminal_layout=planes (the bootstrap reads the terminal observations '
+                       'as planes; records: +18 us per step)' % (n, T),
            'envs': n, 'rollout_steps': T, 'value': n * T / wall, 'unit': 'env-steps/s', 'us_per_step': wall / T * 1e6,
            'replayed_from_a_hip_graph': {'value': n * T / wall_graph, 'us_per_step': wall_graph / T * 1e6,
                                          'note': 'the T steps of a rollout (policy, step, normalisers, bootstrap) recorded once by capture_loop() and '
