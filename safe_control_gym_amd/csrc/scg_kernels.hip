@@ -675,6 +675,9 @@ enum Feat : uint32_t {
     FT_INFO = 8u,    // the per-step info outputs of the default API (info_level='full'): mse / goal_reached /
                      // truncated / terminal_record (terminal obs = the state: obs aliases it in this tier).  A tier of its
                      // own because it is what make() gives by default: 43 us in the EXTRA tier at 2^20 envs.
+    FT_ADV = 128u,   // an adversary's planes (set_adversary_control, benchmark_env.py:256-266: action_disturbance added to the clipped thrust,
+                     // quadrotor.py:835-838, or dynamics_force, the world-frame force of :529-548) on top of the lean / FT_INFO / FT_GOAL
+                     // tiers: what robust-RL training (RARL / RAP) steps with -- in the catch-all tier until round 4.  One-env-per-lane form.
     FT_INERT = 64u,  // per-env inertial properties (randomized_inertial_prop: the (M, Ixx, Iyy, Izz) planes read every step, redrawn at
                      // every reset) on top of the lean / FT_INFO / FT_GOAL / FT_DIST tiers -- the one "extra" that robust-RL runs (and the
                      // competition's levels) switch on by itself: 40.6 us in the catch-all tier at 2^20 envs, 47.7 with a goal horizon
@@ -702,6 +705,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
     constexpr int NX = Dim<SYS>::NX, NU = Dim<SYS>::NU, NV = NX + NU;
     constexpr bool EXTRA = (FT & FT_EXTRA) != 0;
     constexpr bool INERT = (FT & (FT_EXTRA | FT_INERT)) != 0;                   // per-env inertial properties
+    constexpr bool ADV = (FT & (FT_EXTRA | FT_ADV)) != 0;                       // the adversary's action / force planes
     constexpr bool DIST = (FT & (FT_EXTRA | FT_DIST)) != 0;                     // in-kernel disturbances
     constexpr bool OBS = (FT & (FT_EXTRA | FT_DIST | FT_GOAL)) != 0;            // an obs buffer (goal horizon and / or observation noise)
     constexpr bool INFO = (FT & (FT_EXTRA | FT_INFO | FT_DIST | FT_GOAL)) != 0;
@@ -787,7 +791,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
         // steps since the last reset) -- 8 bytes of read-modify-write per env-step that need not exist
         L.epl = io.ep_length ? ldp(io.ep_length, b4) : L.t;
         L.fx = L.fy = L.fz = 0.f;
-        if (EXTRA && io.dynamics_force) {
+        if (ADV && io.dynamics_force) {
             L.fx = ldp(PL(io.dynamics_force, 0), b4); L.fy = ldp(PL(io.dynamics_force, 1), b4);
             L.fz = ldp(PL(io.dynamics_force, 2), b4);
         }
@@ -955,7 +959,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                     const double ad = (double)a_raw[j];
                     th = (RT)fmin(fmax(ad, tb->act_low_d[j]), tb->act_high_d[j]);
                 }
-                if (EXTRA && io.action_disturbance) th += (RT)ldp(PL(io.action_disturbance, j), i4);   // :835-838
+                if (ADV && io.action_disturbance) th += (RT)ldp(PL(io.action_disturbance, j), i4);   // :835-838
                 if (DIST) th += (RT)act_noise[j];
                 if (motor_map) {
                     if constexpr (sizeof(RT) == 8) th = th > ph.th_min ? (th < ph.th_max ? th : ph.th_max) : ph.th_min;   // (NaN -> th_min)
@@ -977,7 +981,7 @@ __global__ SCG_BOUNDS void scg_step_kernel(const KParams p, const scg_step_io io
                     make_inputs<SYS, RT>(ph, u, efx, efy, efz, in);
                 }
             };
-            if (!aero) make_inputs<SYS, RT, DIST>(ph, u, efx, efy, efz, in);     // forces exist from the disturbance tier on
+            if (!aero) make_inputs<SYS, RT, DIST || ADV>(ph, u, efx, efy, efz, in);     // forces exist from the disturbance / adversary tiers on
             if constexpr (COMP == 2) {
                 // attitude precise mode: float translational chain, double rotational chain (no aero terms in this mode)
                 float xt[6];
@@ -1571,13 +1575,17 @@ LaunchGeom step_geometry(const KParams& p, int system, int64_t n, int num_cus) {
 
 // Which instantiation covers this call.
 static uint32_t features_needed(const KParams& p, const scg_step_io& io) {
-    const bool extra = io.action_disturbance || io.dynamics_force || io.obs_noise || io.stats ||
+    const bool extra = io.obs_noise || io.stats ||
                        (p.flags & (F_GND | F_DRAG | F_RAND_GENERAL)) || !(p.flags & F_Q_DIAG);
     if (extra) return FT_TRACK | FT_CON | FT_EXTRA;
     uint32_t ft = 0;
     if (p.dist || io.episode_id) ft |= FT_DIST;                           // in-kernel disturbances only: their own tier
     else if (io.obs) ft |= FT_GOAL;                                       // an obs buffer without them (goal horizon)
     else if (io.truncated || io.goal_reached || io.mse || io.terminal_record) ft |= FT_INFO;
+    if (io.action_disturbance || io.dynamics_force) {
+        if (io.inertial || (ft & FT_DIST)) return FT_TRACK | FT_CON | FT_EXTRA;   // next to per-env inertia / in-kernel noise: the catch-all tier
+        ft |= FT_ADV;
+    }
     if (io.inertial) ft |= FT_INERT;
     if (p.flags & F_TRACKING) ft |= FT_TRACK;
     if (p.n_con_rows > 0) ft |= FT_CON;
@@ -1633,6 +1641,13 @@ static bool launch_step_ft(uint32_t ft, const LaunchGeom& g, const KParams& p, c
         SCG_INERT_CASE(FT_GOAL) SCG_INERT_CASE(FT_GOAL | FT_TRACK) SCG_INERT_CASE(FT_GOAL | FT_CON) SCG_INERT_CASE(FT_GOAL | FT_TRACK | FT_CON)
         SCG_INERT_CASE(FT_DIST) SCG_INERT_CASE(FT_DIST | FT_TRACK) SCG_INERT_CASE(FT_DIST | FT_CON) SCG_INERT_CASE(FT_DIST | FT_TRACK | FT_CON)
 #undef SCG_INERT_CASE
+        // the adversary's planes on top of the lean / info / goal-horizon tiers (same rule)
+#define SCG_ADV_CASE(BASE)                                                                                \
+        case FT_ADV | (BASE): if constexpr (COMP == 0) { if (exact_cover) { SCG_LAUNCH_SINGLE(FT_ADV | (BASE)); break; } } goto catch_all;
+        SCG_ADV_CASE(0u) SCG_ADV_CASE(FT_TRACK) SCG_ADV_CASE(FT_CON) SCG_ADV_CASE(FT_TRACK | FT_CON)
+        SCG_ADV_CASE(FT_INFO) SCG_ADV_CASE(FT_INFO | FT_TRACK) SCG_ADV_CASE(FT_INFO | FT_CON) SCG_ADV_CASE(FT_INFO | FT_TRACK | FT_CON)
+        SCG_ADV_CASE(FT_GOAL) SCG_ADV_CASE(FT_GOAL | FT_TRACK) SCG_ADV_CASE(FT_GOAL | FT_CON) SCG_ADV_CASE(FT_GOAL | FT_TRACK | FT_CON)
+#undef SCG_ADV_CASE
         default:
         catch_all:
             // the attitude-only precise mode is built for the lean and info tiers (no disturbances / aero / per-env inertia)
@@ -1659,7 +1674,7 @@ static bool launch_step_sys(LaunchGeom g, const KParams& p, const scg_step_io& i
 
 // Fused multi-step rollout: lean tiers, float state, table gathered from global memory, exact-cover grid.
 bool fused_rollout_ok(const KParams& p, const scg_step_io& io) {
-    return !(features_needed(p, io) & (FT_EXTRA | FT_INFO | FT_DIST | FT_GOAL | FT_INERT)) && !io.state_lo && !(p.flags & F_REF_IN_LDS);
+    return !(features_needed(p, io) & (FT_EXTRA | FT_INFO | FT_DIST | FT_GOAL | FT_INERT | FT_ADV)) && !io.state_lo && !(p.flags & F_REF_IN_LDS);
 }
 
 template <int SYS>
