@@ -17,7 +17,7 @@ import torch  # noqa: E402
 import safe_control_gym_amd as scg  # noqa: E402
 from safe_control_gym_amd.envs.env_wrappers.vectorized_env import make_vec_envs  # noqa: E402
 
-TIERS = {'lean': dict(info_level='minimal'), 'default': dict()}
+TIERS = {'lean': dict(info_level='minimal'), 'default': dict(), 'ring4': dict(output_ring=4)}
 
 
 class AffinePolicy:
