@@ -476,13 +476,31 @@ def step_api_record(args, n, steps):
         env.close()
         small['2^%d' % e] = {'plain': eager, 'plain_replayed_from_a_hip_graph': captured(lean, m)}
     rec['lean_small_batches'] = small
+    # the reference's own configuration (a plain make(): full info, fresh outputs) at the reference's scale, where the HOST is the
+    # bound: the recycled output sets (output_pool, the default) against one allocation + three views per output and step
+    dsmall = {}
+    for label, extra in (('output_pool', {}), ('allocating', dict(output_pool=0))):
+        env = scg.make('quadrotor', num_envs=1 << 12, **dict(base, **extra))
+        pol = _AffinePolicy(env)
+        box = [env.reset()]
+
+        def loop(k, env=env, pol=pol, box=box):
+            obs = box[0]
+            for _ in range(k):
+                obs = env.step(pol(obs))[0]
+            box[0] = obs
+        dsmall[label] = timed(loop)
+        env.close()
+    rec['default_make_2^12'] = dsmall
     rec['note'] = ('step_only = env.step() with a fixed action tensor (no policy kernel); plain = policy(obs) -> env.step(act), one dependent '
                    'chain; pipelined_P = make_vec_envs(num_pipelines=P): P shards, per shard step_wait -> policy -> step_async on the shard\'s own '
                    'queue.  Each shard is still a dependent chain policy -> step -> policy with ~3 us between dependent kernels, so two shards '
                    'overlap one chain\'s gaps and policy with the other\'s step kernel but do not reach the two-queue rollout\'s rate, where a '
                    'queue carries step kernels only (profiles/r04/step_api_timeline.txt); plain_replayed_from_a_hip_graph = the plain loop recorded once by '
                    'capture_loop() (50 steps per replay, results bit-identical to eager stepping): it takes the host out of the loop, which is what '
-                   'bounds the small batches (lean_small_batches), not 2^20 envs')
+                   'bounds the small batches (lean_small_batches), not 2^20 envs; default_make_2^12 = the plain loop of a default make() at '
+                   '4096 envs with step() recycling its output sets (output_pool, the default: a set is reused once the caller holds no '
+                   'reference to it) and with output_pool=0 (three torch.empty and three views per step)')
     return rec
 
 

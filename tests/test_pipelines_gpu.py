@@ -299,21 +299,28 @@ def test_trajectory_buffer_argument_checks(gpu):
     env.close(); other.close()
 
 
-def test_output_ring_reproduces_the_fresh_output_loop(gpu):
-    """output_ring=K: step() cycles through K pre-allocated output sets instead of allocating one per step -- the same numbers;
-    a tensor handed out is overwritten K steps later (the documented, opt-in change of ownership)."""
-    kw = _common(dict(quad_type=3, task='traj_tracking', cost='quadratic'))
-    a_env = scg.make('quadrotor', num_envs=1000, **kw)
-    b_env = scg.make('quadrotor', num_envs=1000, output_ring=3, **kw)
+@pytest.mark.parametrize('n, extra', [
+    (1000, {}),                                     # state ping-pong, plane stride != n
+    (1024, {}),                                     # ... plane stride == n (the views are plain transposes)
+    (1000, dict(obs_goal_horizon=1)),               # goal rows behind the state: the slot's state rows are a view of its planes
+    (1024, dict(disturbances={'observation': [{'disturbance_func': 'white_noise', 'std': 0.01}]})),   # a kernel-written obs buffer
+])
+def test_output_ring_reproduces_the_fresh_output_loop(gpu, n, extra):
+    """output_ring=K: step() cycles through K pre-allocated output sets (whose views are made once) instead of allocating one per
+    step -- the same numbers; a tensor handed out is overwritten K steps later (the documented, opt-in change of ownership)."""
+    kw = _common(dict(quad_type=3, task='traj_tracking', cost='quadratic', **extra))
+    a_env = scg.make('quadrotor', num_envs=n, **kw)
+    b_env = scg.make('quadrotor', num_envs=n, output_ring=3, **kw)
     with pytest.raises(ValueError, match='output_ring'):
         scg.make('quadrotor', num_envs=8, output_ring=2, **kw)
     a_env.reset(); b_env.reset()
-    act = torch.as_tensor(a_env.action_space.sample(1000), device='cuda', dtype=torch.float32)
+    act = torch.as_tensor(a_env.action_space.sample(n), device='cuda', dtype=torch.float32)
     kept = []
     for k in range(70):
         o1, r1, d1, _ = a_env.step(act)
         o2, r2, d2, _ = b_env.step(act)
-        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+        assert o1.shape == o2.shape == (n, a_env.obs_dim)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(a_env.state, b_env.state)
         kept.append((o2, o2.clone()))
         if k >= 2:
             assert torch.equal(kept[k - 1][0], kept[k - 1][1]) and torch.equal(kept[k - 2][0], kept[k - 2][1])   # K - 1 steps of validity
@@ -321,6 +328,11 @@ def test_output_ring_reproduces_the_fresh_output_loop(gpu):
             assert kept[k - 3][0].data_ptr() == o2.data_ptr()                                                   # ... then reused
     b_env.reset()                                      # an in-place writer first takes a private copy of what was handed out
     assert torch.equal(kept[-1][0], kept[-1][1])
+    a_env.reset()
+    for k in range(5):                                 # ... and the ring carries on behind it
+        o1, r1, d1, _ = a_env.step(act)
+        o2, r2, d2, _ = b_env.step(act)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(a_env.state, b_env.state)
     a_env.close(); b_env.close()
 
 
@@ -606,3 +618,89 @@ def test_round4_forms_at_baseline_sizes(gpu, case):
     for e in (plain, sunk, fused):
         e.close()
     venv.close()
+
+
+@pytest.mark.parametrize('extra', [{}, dict(obs_goal_horizon=1),
+                                   dict(disturbances={'observation': [{'disturbance_func': 'white_noise', 'std': 0.01}]})])
+def test_output_pool_recycles_only_what_nobody_holds(gpu, extra):
+    """output_pool (default of the fresh-output mode): step() recycles an output set once the caller holds no reference to any of it
+    -- same numbers as allocating per step, and a tensor that anybody can still read (the object itself, a view derived from it,
+    ``info['n']``'s ``done``) is never written again; a caller that keeps everything falls back to allocation."""
+    n = 1000
+    kw = _common(dict(quad_type=3, task='traj_tracking', cost='quadratic', **extra))
+    a_env = scg.make('quadrotor', num_envs=n, output_pool=0, **kw)
+    b_env = scg.make('quadrotor', num_envs=n, **kw)
+    with pytest.raises(ValueError, match='output_pool'):
+        scg.make('quadrotor', num_envs=8, output_pool=2, **kw)
+    a_env.reset(); b_env.reset()
+    assert a_env._pool is None and b_env._pool is not None
+    act = torch.as_tensor(a_env.action_space.sample(n), device='cuda', dtype=torch.float32)
+    seen = set()
+    for k in range(30):                                                # a loop that holds one step's outputs at a time
+        o1 = a_env.step(act)[0]
+        o2, r2, d2, info = b_env.step(act)
+        assert torch.equal(o1, o2)
+        seen.add(o2.data_ptr())
+    assert len(b_env._pool) <= 3 and len(seen) <= 3                    # ... lives on two or three sets
+    del o2, r2, d2, info
+    kept, ptrs = [], set()
+    prev = None
+    for k in range(90):
+        o1, r1, d1, _ = a_env.step(act)
+        o2, r2, d2, info = b_env.step(act)
+        assert o2.shape == (n, a_env.obs_dim) and r2.shape == (n,) and d2.shape == (n,) and d2.dtype == torch.bool
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(a_env.state, b_env.state)
+        ptrs.add(o2.data_ptr())
+        if prev is not None:
+            assert prev[0].data_ptr() != o2.data_ptr() and torch.equal(prev[0], prev[1])      # the usual loop: obs, then next_obs
+        prev = (o2, o2.clone())
+        if k % 9 == 0:
+            kept.append(('obs', o2, o2.clone()))                       # the object itself
+        elif k % 9 == 1:
+            kept.append(('view', o2[:, :3], o2[:, :3].clone()))        # only a view derived from it (the object is dropped)
+        elif k % 9 == 2:
+            kept.append(('reward', r2, r2.clone()))                    # only the reward
+        elif k % 9 == 3:
+            kept.append(('info', info, d2.clone()))                    # only info: info['n'] reads this step's done
+        del o2, r2, d2, info
+    for kind, held, copy in kept:
+        assert torch.equal(held['n']._done if kind == 'info' else held, copy), kind
+    assert len(b_env._pool) <= 8
+    assert len(ptrs) < 60                                              # sets were recycled (40 of the 90 steps pinned theirs)
+    # a caller that keeps everything: nothing is overwritten, step() allocates again
+    hoard = []
+    for k in range(40):
+        o1 = a_env.step(act)[0]
+        o2, r2, d2, _ = b_env.step(act)
+        assert torch.equal(o1, o2)
+        hoard.append((o2, r2, d2, o2.clone(), r2.clone(), d2.clone()))
+    for o, r, d, oc, rc, dc in hoard:
+        assert torch.equal(o, oc) and torch.equal(r, rc) and torch.equal(d, dc)
+    assert len({h[0].data_ptr() for h in hoard}) == 40
+    del hoard, kept, prev
+    a_env.reset(); b_env.reset()                                       # in-place writers take private copies first
+    for k in range(40):
+        o1, r1, d1, _ = a_env.step(act)
+        o2, r2, d2, _ = b_env.step(act)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+    a_env.close(); b_env.close()
+
+
+def test_output_pool_with_asynchronous_steps(gpu):
+    """step_async / step_wait in the fresh-output mode: what the pending kernel reads and writes stays referenced until the join."""
+    n = 512
+    kw = _common(dict(quad_type=3, task='traj_tracking', cost='quadratic'))
+    a_env = scg.make('quadrotor', num_envs=n, output_pool=0, **kw)
+    b_env = scg.make('quadrotor', num_envs=n, **kw)
+    a_env.reset(); b_env.reset()
+    act = torch.as_tensor(a_env.action_space.sample(n), device='cuda', dtype=torch.float32)
+    last = None
+    for k in range(50):
+        o1, r1, d1, _ = a_env.step(act)
+        b_env.step_async(act)
+        o2, r2, d2, _ = b_env.step_wait()
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+        if last is not None:
+            assert torch.equal(last[0], last[1])
+        last = (o2, o2.clone())
+    a_env.close(); b_env.close()
