@@ -12,6 +12,7 @@ NumPy arrays.
 Observations are taken zero-copy when they are the engine's own ``[N, d]`` view of SoA planes
 (``env.step()``'s obs: stride (1, ld)); any other tensor is transposed into planes first.
 """
+import functools
 import math
 import weakref
 
@@ -19,6 +20,7 @@ import numpy as np
 import torch
 
 from safe_control_gym_amd import _capi
+from safe_control_gym_amd.utils.recycle import RecyclingPool
 
 
 def normalize_angle(x):
@@ -143,6 +145,35 @@ def _launch(device, fn, name, *args):
         _capi.check(status, name)
 
 
+def _new_plane_set(d, ld, n, device):
+    """A normalised-observation set for the recycling pool: [d, ld] planes and the [n, d] view of them that is returned."""
+    out = torch.empty((d, ld), dtype=torch.float32, device=device)
+    view = out.T if ld == n else out[:, :n].T
+    return (out, view), (out, view), out.untyped_storage()
+
+
+def _new_row_set(n, device):
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    return out, (out,), out.untyped_storage()
+
+
+class _FreshOutputs:
+    """The fresh result tensor of a normaliser call, recycled once the caller holds no reference to the last ones (utils/recycle.py:
+    the reference returns a new array per call, normalization.py:125-133, and its loops keep the previous one).  One pool per batch
+    size (the last one seen); up to 8 sets within 64 MiB, else plain allocation."""
+
+    __slots__ = ('key', 'pool')
+
+    def __init__(self):
+        self.key, self.pool = None, None
+
+    def take(self, key, set_bytes, factory, *args):
+        if key != self.key:
+            cap = min(8, (64 << 20) // max(1, set_bytes))
+            self.key, self.pool = key, (RecyclingPool(functools.partial(factory, *args), cap) if cap >= 4 else None)
+        return None if self.pool is None else self.pool.take()
+
+
 class BaseNormalizer:
     """Template / default normaliser: identity (normalization.py:65-104)."""
 
@@ -217,6 +248,7 @@ class MeanStdNormalizer(BaseNormalizer):
         self.shared = _SharedStatistics(sync_statistics, process_group)
         self._sums = None
         self.device = self.rms.device
+        self._fresh = _FreshOutputs()
 
     def _planes(self, x):
         """(planes pointer tensor, ld, n): zero copy for an [N, d] view of SoA planes, else one transposing copy."""
@@ -253,8 +285,14 @@ class MeanStdNormalizer(BaseNormalizer):
                 raise ValueError('[ERROR] sync_statistics: an empty shard cannot take part in the exchange (every rank makes every call).')
             return xv
         ld_y = (n + 63) // 64 * 64
+        view = None
         if out is None:
-            out = torch.empty((d, ld_y), dtype=torch.float32, device=self.device)
+            got = self._fresh.take((d, n), 4 * d * ld_y, _new_plane_set, d, ld_y, n, self.device)
+            if got is not None:
+                out, view = got
+                got = None
+            else:
+                out = torch.empty((d, ld_y), dtype=torch.float32, device=self.device)
         elif not (isinstance(out, torch.Tensor) and out.dtype == torch.float32 and out.is_contiguous() and out.ndim == 2
                   and out.shape[0] == d and out.shape[1] >= n and out.device == xv.device):
             raise ValueError('[ERROR] out must be a contiguous float32 (%d, ld >= %d) device tensor' % (d, n))
@@ -271,10 +309,10 @@ class MeanStdNormalizer(BaseNormalizer):
             self.shared.add_up(dist, self._sums)
             _launch(self.device, self.lib.scg_mean_std_normalize_sums, 'scg_mean_std_normalize_sums', xv.data_ptr(), out.data_ptr(), d,
                     ld_x, ld_y, n, state_in, state_out, self._sums.data_ptr(), total, float(self.clip), float(self.epsilon))
-            return out[:, :n].T
+            return view if view is not None else out[:, :n].T
         _launch(self.device, self.lib.scg_mean_std_normalize, 'scg_mean_std_normalize', xv.data_ptr(), out.data_ptr(), d, ld_x, ld_y, n,
                 state_in, state_out, self.rms._moments_ptr, float(self.clip), float(self.epsilon))
-        return out[:, :n].T
+        return view if view is not None else out[:, :n].T
 
     def state_dict(self):
         return {'mean': self.rms.mean.cpu().numpy(), 'var': self.rms.var.cpu().numpy()}
@@ -320,7 +358,9 @@ class RewardStdNormalizer(MeanStdNormalizer):
         if not self.read_only and self.ret is None:
             self.ret = torch.zeros(n, dtype=torch.float32, device=self.device)
         if out is None:
-            out = torch.empty(n, dtype=torch.float32, device=self.device)
+            out = self._fresh.take(n, 4 * n, _new_row_set, n, self.device)
+            if out is None:
+                out = torch.empty(n, dtype=torch.float32, device=self.device)
         elif not (isinstance(out, torch.Tensor) and out.dtype == torch.float32 and out.ndim == 1 and out.is_contiguous()
                   and out.shape[0] >= n and out.device == x.device):
             raise ValueError('[ERROR] out must be a contiguous float32 (>= %d,) device tensor' % n)

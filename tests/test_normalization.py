@@ -81,6 +81,44 @@ def test_mean_std_normalizer_matches_oracle(gpu, d):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('n', [1000, 4096])
+def test_normalizers_recycle_only_results_nobody_holds(gpu, n):
+    """The normalisers return a FRESH tensor per call (normalization.py:125-133); the buffers behind them are recycled once the
+    caller dropped the result (utils/recycle.py).  A hoarding caller and a dropping caller get the same numbers, every result that
+    is still referenced -- itself or through a view -- keeps its values, and the dropping caller lives on a few buffers."""
+    import torch
+    from safe_control_gym_amd.math_and_models.normalization import MeanStdNormalizer, RewardStdNormalizer
+    g = torch.Generator(device='cuda').manual_seed(5)
+    d = 12
+    obs_a, obs_b = MeanStdNormalizer(shape=(d,)), MeanStdNormalizer(shape=(d,))
+    rew_a, rew_b = RewardStdNormalizer(gamma=0.9), RewardStdNormalizer(gamma=0.9)
+    hoard, kept, ptrs_o, ptrs_r = [], [], set(), set()
+    for k in range(20):                                                      # results dropped at once: one or two buffers do
+        x, r = torch.randn((n, d), generator=g, device='cuda'), torch.randn(n, generator=g, device='cuda')
+        done = torch.rand(n, generator=g, device='cuda') < 0.05
+        obs_a(x); rew_a(r, done)
+        ptrs_o.add(obs_b(x).data_ptr()); ptrs_r.add(rew_b(r, done).data_ptr())
+    assert len(ptrs_o) <= 2 and len(ptrs_r) <= 2
+    for k in range(60):
+        x = torch.randn((n, d), generator=g, device='cuda') * 3.0 + 1.0
+        r = torch.randn(n, generator=g, device='cuda')
+        done = torch.rand(n, generator=g, device='cuda') < 0.05
+        ya, ra = obs_a(x), rew_a(r, done)
+        hoard.append((ya, ra, ya.clone(), ra.clone()))                       # A: keeps every result
+        yb, rb = obs_b(x), rew_b(r, done)                                    # B: drops them (but for a few)
+        assert yb.shape == (n, d) and rb.shape == (n,)
+        assert torch.equal(ya, yb) and torch.equal(ra, rb)
+        if k % 10 == 0:
+            kept.append((yb, rb, yb.clone(), rb.clone()))
+        elif k % 10 == 1:
+            kept.append((yb[:, 2:5], rb[10:20], yb[:, 2:5].clone(), rb[10:20].clone()))      # only views derived from them
+        del ya, ra, yb, rb
+    for a, b, ac, bc in hoard + kept:
+        assert torch.equal(a, ac) and torch.equal(b, bc)
+    assert len({h[0].data_ptr() for h in hoard}) == 60 and len({h[1].data_ptr() for h in hoard}) == 60
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('n', [777, 16384, 20011], ids=['one_launch', 'one_launch_full', 'two_launches'])
 @pytest.mark.parametrize('legacy', [False, True])
 def test_reward_std_normalizer_matches_oracle(gpu, legacy, n):
