@@ -185,7 +185,7 @@ class PipelinedDeviceVecEnv(VecEnv):
         obs, rew, done = (self._cat([o[q] for o in outs]) for q in range(3))
         info = {k: self._cat([o[3][k] for o in outs]) for k in outs[0][3] if k != 'n'}
         if 'n' in outs[0][3]:
-            info['n'] = LazyInfoList(info, done)
+            info['n'] = LazyInfoList(dict(info), done)        # (a copy: info -> info['n'] -> info would be a reference cycle)
         return obs, rew, done, info
 
     def step(self, actions, pipeline=None):
