@@ -443,6 +443,22 @@ int scg_gae(const float* rew, const float* val, const float* mask, const uint8_t
 int scg_normalize_advantages(float* adv, const double* stats, int32_t T, int64_t n, int64_t ld, float eps,
                              void* stream);
 
+/* PPOBuffer.push (controllers/ppo/ppo_utils.py:338-346: `self.__dict__[k][self.t] = v` for every key of the step's batch, six or
+ * seven device-to-device copies per step) as ONE launch: segment j copies a rows x cols float32 matrix, element (i, k) from
+ * src[i * src_row_stride + k * src_col_stride] to dst[i * dst_row_stride + k * dst_col_stride] (strides in ELEMENTS, so a
+ * row-major [N, d] tensor, an [N, d] view of SoA planes and the planes themselves are all addressable: pushing row-major actions
+ * into action planes is the transposing case).  1 <= count <= SCG_MAX_COPY_SEGMENTS; the segment array is HOST memory (it
+ * travels as kernel arguments); segments must not overlap each other's destinations.  Handle-free: runs on the current device. */
+#define SCG_MAX_COPY_SEGMENTS 8
+typedef struct scg_copy_segment {
+    const float* src;
+    float* dst;
+    int64_t rows, cols;
+    int64_t src_row_stride, src_col_stride;
+    int64_t dst_row_stride, dst_col_stride;
+} scg_copy_segment;
+int scg_copy_segments(const scg_copy_segment* segments, int32_t count, void* stream);
+
 /* ---- next row: batched prior-model queries ------------------------------------
  * scg_linearize replaces SymbolicModel.df_func (math_and_models/symbolic_systems.py:77-92: dfdx = d f / d x,
  * dfdu = d f / d u of the continuous dynamics) for n (x, u) pairs in one launch.  state [nx][ld] and input

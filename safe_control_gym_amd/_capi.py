@@ -122,10 +122,19 @@ class ScgDisturbance(C.Structure):
     ]
 
 
+SCG_MAX_COPY_SEGMENTS = 8
+
+
+class ScgCopySegment(C.Structure):
+    """``scg_copy_segment`` (include/scg_rollout.h): one strided rows x cols float32 copy of ``scg_copy_segments``."""
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('rows', C.c_int64), ('cols', C.c_int64),
+                ('src_row_stride', C.c_int64), ('src_col_stride', C.c_int64), ('dst_row_stride', C.c_int64), ('dst_col_stride', C.c_int64)]
+
+
 EXPORTS = (
     'scg_create', 'scg_destroy', 'scg_set_reference', 'scg_set_constraints', 'scg_set_disturbances', 'scg_reset', 'scg_step', 'scg_rollout', 'scg_rollout_fused',
     'scg_step_async', 'scg_step_wait', 'scg_step_queue', 'scg_rollout_trajectory', 'scg_sizeof_trajectory_sink',
-    'scg_eval_constraints', 'scg_gae', 'scg_normalize_advantages', 'scg_model_eval', 'scg_model_flow', 'scg_linearize', 'scg_fc_linear', 'scg_discretize_exact', 'scg_quadratic_loss', 'scg_mean_std_normalize', 'scg_reward_normalize', 'scg_mean_std_moments', 'scg_mean_std_normalize_sums', 'scg_reward_moments', 'scg_reward_normalize_sums', 'scg_num_constraints', 'scg_obs_dim', 'scg_kernel_info', 'scg_rollout_graph_info', 'scg_last_error',
+    'scg_eval_constraints', 'scg_gae', 'scg_normalize_advantages', 'scg_copy_segments', 'scg_model_eval', 'scg_model_flow', 'scg_linearize', 'scg_fc_linear', 'scg_discretize_exact', 'scg_quadratic_loss', 'scg_mean_std_normalize', 'scg_reward_normalize', 'scg_mean_std_moments', 'scg_mean_std_normalize_sums', 'scg_reward_moments', 'scg_reward_normalize_sums', 'scg_num_constraints', 'scg_obs_dim', 'scg_kernel_info', 'scg_rollout_graph_info', 'scg_last_error',
     'scg_version', 'scg_sizeof_config', 'scg_sizeof_step_io', 'scg_sizeof_constraint_row', 'scg_sizeof_disturbance',
 )
 
@@ -181,6 +190,7 @@ def load():
     lib.scg_eval_constraints.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, C.c_int64, C.c_int64, C.c_void_p]
     lib.scg_gae.argtypes = [_fp] * 10 + [_i32, C.c_int64, C.c_int64, C.c_float, C.c_float, _i32, C.c_void_p]
     lib.scg_normalize_advantages.argtypes = [_fp, _fp, _i32, C.c_int64, C.c_int64, C.c_float, C.c_void_p]
+    lib.scg_copy_segments.argtypes = [C.POINTER(ScgCopySegment), _i32, C.c_void_p]
     lib.scg_model_eval.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int64, C.c_void_p]
     lib.scg_model_flow.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_double, C.c_double, C.c_double, _i32, _fp, _fp, _fp, _fp,
                                    C.c_int64, C.c_int64, C.c_void_p]

@@ -13,6 +13,8 @@ import torch
 
 from safe_control_gym_amd import _capi
 
+_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
 
 class PPOBuffer:
     """(T, N, ...) float32 device tensors under the reference's keys (ppo_utils.py:308-336).
@@ -40,6 +42,7 @@ class PPOBuffer:
         }
         self.keys = list(self.scheme.keys())
         self.planes = env is not None
+        self._lib = None
         if self.planes:
             if env.num_envs != N or len(obs_dim) != 1 or obs_dim[0] != env.obs_dim:
                 raise ValueError('[ERROR] PPOBuffer(env=...): batch_size / obs_space do not match the env.')
@@ -49,6 +52,7 @@ class PPOBuffer:
     _ENGINE_KEYS = ('obs', 'rew', 'mask')
 
     def reset(self):
+        self._push_rows, self._push_plans = {}, {}
         for k, info in self.scheme.items():
             if self.planes and (k in self._ENGINE_KEYS or k == 'act'):
                 continue
@@ -76,6 +80,7 @@ class PPOBuffer:
             self._done_rows, self._act_rows = self.done_planes.unbind(0), self.act_planes.unbind(0)
             self._obs_views = [row[:, :N].T for row in self._obs_rows]
             self._step_outs = {}
+        self._dev = self.__dict__['v'].device                   # with its index, as a policy's tensors carry it
         self.t = 0
 
     # ---- the engine-written rows (env=...) ---------------------------------------------------------------------------
@@ -137,17 +142,87 @@ class PPOBuffer:
             self._step_outs[key] = out
         return out
 
+    def _row(self, k, t):
+        """Row t of key k's (T, N, ...) tensor as a ready-made view (indexing a tensor costs 2-3 us of host time, a push has six or
+        seven keys); remembered per tensor OBJECT: ``buf.ret = ...`` (controllers/ppo/ppo_utils.py:443-444 assigns) makes new ones."""
+        assert k in self.keys
+        if self.planes and k in self._ENGINE_KEYS:
+            raise KeyError('[ERROR] PPOBuffer(env=...): %r is written by the step kernel (env.step(act, out=buf.step_out())), '
+                           'not pushed.' % k)
+        name = '_mask' if k == 'mask' else k
+        data = self.__dict__[name]
+        rows = self._push_rows.get(name)
+        if rows is None or rows[0] is not data:
+            rows = self._push_rows[name] = (data, data.unbind(0))
+        return name, data, rows[1][t]
+
+    def _push_plan(self, t, keys):
+        """Row t's destinations for this key order as the dst half of a ``scg_copy_segment`` array (the src half is filled per push):
+        (keys, [(name, tensor object)], segment array or None, its elements, [(N, d)])."""
+        owners, segs, elems, shapes = [], None, [], []
+        rows = []
+        for k in keys:
+            name, data, row = self._row(k, t)
+            owners.append((name, data))
+            rows.append(row)
+        if 1 <= len(keys) <= _capi.SCG_MAX_COPY_SEGMENTS and all(r.ndim == 2 and min(r.stride()) >= 0 for r in rows):
+            segs = (_capi.ScgCopySegment * len(keys))()
+            for j, row in enumerate(rows):
+                g = segs[j]
+                g.dst, g.rows, g.cols = row.data_ptr(), row.shape[0], row.shape[1]
+                g.dst_row_stride, g.dst_col_stride = row.stride()
+                elems.append(g)
+                shapes.append((row.shape[0], row.shape[1]))
+        return keys, owners, segs, elems, shapes
+
     def push(self, batch):
         """One step of data: values are [N, ...] tensors (or arrays); no host round trip for tensors.  With ``env=...`` the
-        engine-written keys (``obs``, ``rew``, ``mask``) are refused here: they arrive through ``step_out()``."""
+        engine-written keys (``obs``, ``rew``, ``mask``) are refused here: they arrive through ``step_out()``.
+
+        The per-step case -- every value a float32 tensor on the buffer's device, [N, d] (any strides: a policy's output, the
+        [N, obs_dim] view of SoA planes that ``env.step()`` returns) or [N] for a (T, N, 1) key -- is ONE launch
+        (``scg_copy_segments``: up to 8 strided copies whose descriptors travel as kernel arguments) instead of one ``copy_`` per
+        key; anything else (host arrays, other dtypes or shapes) takes the per-key path."""
+        t = self.t
+        keys = tuple(batch)
+        plan = self._push_plans.get(t)
+        if plan is None or plan[0] != keys or any(self.__dict__[name] is not data for name, data in plan[1]):
+            plan = self._push_plans[t] = self._push_plan(t, keys)
+        dev = self._dev
+        if plan[2] is not None and _RAW_STREAM is not None and dev.type == 'cuda' and torch.cuda.current_device() == dev.index:
+            f32, elems, shapes = torch.float32, plan[3], plan[4]
+            j = 0
+            for v in batch.values():
+                if type(v) is not torch.Tensor or v.dtype != f32 or v.device != dev:
+                    break
+                n, d = shapes[j]
+                sh = v.shape
+                if len(sh) == 2 and sh[0] == n and sh[1] == d:
+                    rs, cs = v.stride()
+                elif len(sh) == 1 and d == 1 and sh[0] == n:
+                    rs, cs = v.stride(0), 1
+                else:
+                    break
+                if rs < 0 or cs < 0:
+                    break
+                g = elems[j]
+                g.src, g.src_row_stride, g.src_col_stride = v.data_ptr(), rs, cs
+                j += 1
+            else:
+                if self._lib is None:
+                    self._lib = _capi.load()
+                status = self._lib.scg_copy_segments(plan[2], j, _RAW_STREAM(dev.index))
+                if status != 0:
+                    _capi.check(status, 'scg_copy_segments')
+                self.t = (t + 1) % self.max_length
+                return
         for k, v in batch.items():
-            assert k in self.keys
-            if self.planes and k in self._ENGINE_KEYS:
-                raise KeyError('[ERROR] PPOBuffer(env=...): %r is written by the step kernel (env.step(act, out=buf.step_out())), '
-                               'not pushed.' % k)
-            shape = self.scheme[k]['vshape'][1:]
-            self.__dict__['_mask' if k == 'mask' else k][self.t].copy_(torch.as_tensor(v, dtype=torch.float32, device=self.device).reshape(shape))
-        self.t = (self.t + 1) % self.max_length
+            row = self._row(k, t)[2]
+            if type(v) is torch.Tensor and v.dtype == torch.float32 and v.device == dev:
+                row.copy_(v if v.shape == row.shape else v.reshape(row.shape))
+            else:
+                row.copy_(torch.as_tensor(v, dtype=torch.float32, device=self.device).reshape(row.shape))
+        self.t = (t + 1) % self.max_length
 
     def _flat(self, k):
         info = self.scheme[k]

@@ -1098,6 +1098,26 @@ int scg_normalize_advantages(float* adv, const double* stats, int32_t T, int64_t
     return SCG_OK;
 }
 
+int scg_copy_segments(const scg_copy_segment* segments, int32_t count, void* stream) {
+    if (!segments) return fail(SCG_ERR_INVALID, "scg_copy_segments: null argument");
+    if (count < 1 || count > SCG_MAX_COPY_SEGMENTS)
+        return fail(SCG_ERR_INVALID, "scg_copy_segments: count %d is not in 1 .. %d", (int)count, SCG_MAX_COPY_SEGMENTS);
+    for (int j = 0; j < count; ++j) {
+        const scg_copy_segment& g = segments[j];
+        if (g.rows < 0 || g.cols < 0 || g.rows > ((int64_t)1 << 40) || g.cols > ((int64_t)1 << 40) ||
+            (g.cols > 0 && g.rows > ((int64_t)1 << 40) / g.cols))
+            return fail(SCG_ERR_INVALID, "scg_copy_segments: segment %d: rows / cols out of range", j);
+        if (g.rows * g.cols > 0 && (!g.src || !g.dst)) return fail(SCG_ERR_INVALID, "scg_copy_segments: segment %d: null pointer", j);
+        if (g.src_row_stride < 0 || g.src_col_stride < 0 || g.dst_row_stride < 0 || g.dst_col_stride < 0)
+            return fail(SCG_ERR_INVALID, "scg_copy_segments: segment %d: negative stride", j);
+        // a destination whose elements alias (a zero stride over more than one element) has no defined result
+        if ((g.rows > 1 && g.dst_row_stride == 0) || (g.cols > 1 && g.dst_col_stride == 0))
+            return fail(SCG_ERR_INVALID, "scg_copy_segments: segment %d: destination stride 0", j);
+    }
+    HIP_TRY(launch_copy_segments(segments, count, (hipStream_t)stream));
+    return SCG_OK;
+}
+
 int scg_model_eval(scg_handle* h, const float* state, const float* input, const float* inertial, float* xdot,
                    float* xnext, int64_t ld, int64_t n, void* stream) {
     if (!h) return fail(SCG_ERR_INVALID, "scg_model_eval: null handle");

@@ -193,6 +193,7 @@ hipError_t launch_gae(const float* rew, const float* val, const float* mask, con
                       const float* last_val, float* ret, float* adv, float* rew_out, double* stats, int T, int64_t n,
                       int64_t ld, float gamma, float lam, int use_gae, hipStream_t s);
 hipError_t launch_normalize(float* adv, const double* stats, int T, int64_t n, int64_t ld, float eps, hipStream_t s);
+hipError_t launch_copy_segments(const scg_copy_segment* seg, int count, hipStream_t s);
 hipError_t launch_model_eval(int system, const KParams& p, const KTables* tb, const float* state, const float* input,
                              const float* inertial, float* xdot, float* xnext, int64_t ld, int64_t n, hipStream_t s);
 hipError_t launch_model_flow(int system, const PhysT<double>& ph, const double* state, const double* input,

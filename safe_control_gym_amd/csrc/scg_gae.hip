@@ -257,4 +257,55 @@ hipError_t launch_normalize(float* adv, const double* stats, int T, int64_t n, i
     return hipGetLastError();
 }
 
+// ---- PPOBuffer.push in one launch (scg_copy_segments): up to 8 strided rows x cols float32 copies ------------------------------
+// The segments travel by value (kernel arguments): no table in device memory, nothing to keep alive.  grid.y = segment; a segment
+// that is dense on both sides (the usual pushed key: a contiguous policy output into a contiguous buffer row) moves as 16-byte
+// units, anything else -- the [N, d] view of SoA planes that env.step() returns, row-major actions into action planes -- element by
+// element, consecutive threads along the SOURCE's fastest dimension so that the reads coalesce.
+struct CopySegments {
+    scg_copy_segment seg[SCG_MAX_COPY_SEGMENTS];
+};
+
+__global__ __launch_bounds__(256) void scg_copy_segments_kernel(const CopySegments cs) {
+    const scg_copy_segment& g = cs.seg[blockIdx.y];
+    const int64_t total = g.rows * g.cols;
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, step = (int64_t)gridDim.x * 256;
+    const bool dense = g.src_col_stride == 1 && g.dst_col_stride == 1 && g.src_row_stride == g.cols && g.dst_row_stride == g.cols;
+    if (dense && ((reinterpret_cast<uintptr_t>(g.src) | reinterpret_cast<uintptr_t>(g.dst)) & 15u) == 0) {
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        const int64_t units = total >> 2;
+        for (int64_t q = tid; q < units; q += step) reinterpret_cast<v4*>(g.dst)[q] = reinterpret_cast<const v4*>(g.src)[q];
+        for (int64_t e = (units << 2) + tid; e < total; e += step) g.dst[e] = g.src[e];
+        return;
+    }
+    if (g.src_col_stride <= g.src_row_stride || g.rows == 1) {
+        // columns are the source's fast dimension (row-major rows)
+        for (int64_t e = tid; e < total; e += step) {
+            const int64_t i = e / g.cols, k = e - i * g.cols;
+            g.dst[i * g.dst_row_stride + k * g.dst_col_stride] = g.src[i * g.src_row_stride + k * g.src_col_stride];
+        }
+    } else {
+        // rows are the source's fast dimension (an [N, d] view of planes): walk plane by plane
+        for (int64_t e = tid; e < total; e += step) {
+            const int64_t k = e / g.rows, i = e - k * g.rows;
+            g.dst[i * g.dst_row_stride + k * g.dst_col_stride] = g.src[i * g.src_row_stride + k * g.src_col_stride];
+        }
+    }
+}
+
+hipError_t launch_copy_segments(const scg_copy_segment* seg, int count, hipStream_t s) {
+    CopySegments cs{};
+    int64_t most = 0;
+    for (int j = 0; j < count; ++j) {
+        cs.seg[j] = seg[j];
+        const int64_t total = seg[j].rows * seg[j].cols;
+        most = total > most ? total : most;
+    }
+    if (most == 0) return hipSuccess;
+    int64_t blocks = (most + 1023) / 1024;                   // ~4 elements per thread, grid-stride beyond 2048 workgroups per segment
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(scg_copy_segments_kernel, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, s, cs);
+    return hipGetLastError();
+}
+
 }  // namespace scg

@@ -608,6 +608,29 @@ static void check_next_row_entry_points() {
         EXPECT(scg_reward_normalize_sums(f.data(), f.data(), 8, rec0, rec1, sums, 7.0, 10.f, 1e-8, nullptr) == SCG_ERR_INVALID);
         EXPECT(scg_reward_normalize_sums(f.data(), f.data(), 8, rec0, rec1, sums, 16.0, 10.f, 1e-8, nullptr) == SCG_OK);
     }
+    {
+        // scg_copy_segments (PPOBuffer.push in one launch): count bounds, null pointers, negative / aliasing strides, empty segments
+        scg_copy_segment seg[SCG_MAX_COPY_SEGMENTS + 1] = {};
+        for (auto& g : seg) g = scg_copy_segment{f.data(), f.data() + 32, 4, 2, 2, 1, 2, 1};
+        EXPECT(scg_copy_segments(nullptr, 1, nullptr) == SCG_ERR_INVALID);
+        EXPECT(scg_copy_segments(seg, 0, nullptr) == SCG_ERR_INVALID);
+        EXPECT(scg_copy_segments(seg, SCG_MAX_COPY_SEGMENTS + 1, nullptr) == SCG_ERR_INVALID);
+        EXPECT(scg_copy_segments(seg, SCG_MAX_COPY_SEGMENTS, nullptr) == SCG_OK);
+        seg[1].dst = nullptr;
+        EXPECT(scg_copy_segments(seg, 2, nullptr) == SCG_ERR_INVALID);
+        seg[1].rows = 0;                                                      // ... an empty segment may carry null pointers
+        EXPECT(scg_copy_segments(seg, 2, nullptr) == SCG_OK);
+        seg[0].src_row_stride = -2;
+        EXPECT(scg_copy_segments(seg, 1, nullptr) == SCG_ERR_INVALID);
+        seg[0].src_row_stride = 0;                                            // a broadcast source is fine
+        EXPECT(scg_copy_segments(seg, 1, nullptr) == SCG_OK);
+        seg[0].dst_row_stride = 0;                                            // an aliasing destination is not
+        EXPECT(scg_copy_segments(seg, 1, nullptr) == SCG_ERR_INVALID);
+        seg[0].dst_row_stride = 2; seg[0].rows = -1;
+        EXPECT(scg_copy_segments(seg, 1, nullptr) == SCG_ERR_INVALID);
+        seg[0].rows = (int64_t)1 << 41;
+        EXPECT(scg_copy_segments(seg, 1, nullptr) == SCG_ERR_INVALID);
+    }
     EXPECT(scg_destroy(h) == SCG_OK);
 }
 

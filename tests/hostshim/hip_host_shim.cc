@@ -113,6 +113,7 @@ hipError_t launch_rollout_fused(int, const KParams&, const scg_step_io&, const K
 hipError_t launch_reset(int, const KParams&, const KTables*, float*, float*, int32_t*, float*, int32_t*, float*, const uint8_t*, const float*, float*, uint32_t*, const float*, uint32_t, int64_t, int64_t, hipStream_t) { ++g_shim.launches; return hipSuccess; }
 hipError_t launch_gae(const float*, const float*, const float*, const uint8_t*, const float*, const float*, float*, float*, float*, double*, int, int64_t, int64_t, float, float, int, hipStream_t) { ++g_shim.launches; return hipSuccess; }
 hipError_t launch_normalize(float*, const double*, int, int64_t, int64_t, float, hipStream_t) { ++g_shim.launches; return hipSuccess; }
+hipError_t launch_copy_segments(const scg_copy_segment*, int, hipStream_t) { ++g_shim.launches; return hipSuccess; }
 hipError_t launch_model_eval(int, const KParams&, const KTables*, const float*, const float*, const float*, float*, float*, int64_t, int64_t, hipStream_t) { ++g_shim.launches; return hipSuccess; }
 hipError_t launch_model_flow(int, const PhysT<double>&, const double*, const double*, const double*, double, double, double, int, double*, double*, double*, int32_t*, int64_t, int64_t, hipStream_t) { ++g_shim.launches; return hipSuccess; }
 hipError_t launch_linearize(int, const PhysT<float>&, const float*, const float*, const float*, float*, float*, float, int64_t, int64_t, hipStream_t) { ++g_shim.launches; return hipSuccess; }

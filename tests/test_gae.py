@@ -57,6 +57,94 @@ def test_gae_kernel_matches_oracle(gpu, use_gae, T, N):
 
 
 @pytest.mark.gpu
+def test_copy_segments_through_the_c_abi(gpu):
+    """scg_copy_segments (PPOBuffer.push in one launch): dense segments (the 16-byte path, with and without a tail, aligned and
+    not), row-major rows, an [N, d] view of planes as source, row-major actions transposed into planes, a broadcast source, an
+    empty segment -- all in one call and bit-exact; argument errors return SCG_ERR_INVALID (-1) with a message."""
+    import ctypes
+    import torch
+    from safe_control_gym_amd import _capi
+    lib = _capi.load()
+    g = torch.Generator(device='cuda').manual_seed(3)
+    N = 1003
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def seg(src, dst, rows, cols, ss, ds):
+        s = _capi.ScgCopySegment()
+        s.src, s.dst, s.rows, s.cols = src.data_ptr(), dst.data_ptr(), rows, cols
+        s.src_row_stride, s.src_col_stride, s.dst_row_stride, s.dst_col_stride = ss[0], ss[1], ds[0], ds[1]
+        return s
+
+    cases, want = [], []
+    a_src, a_dst = torch.randn(N, 12, generator=g, device='cuda'), torch.zeros(N, 12, device='cuda')          # dense, 16-byte units + no tail
+    cases.append(seg(a_src, a_dst, N, 12, a_src.stride(), a_dst.stride())); want.append((a_dst, a_src))
+    b_src, b_dst = torch.randn(N, device='cuda', generator=g), torch.zeros(N, 1, device='cuda')               # [N] -> [N, 1], tail of 3
+    cases.append(seg(b_src, b_dst, N, 1, (1, 1), b_dst.stride())); want.append((b_dst[:, 0], b_src))
+    c_store = torch.randn(N * 5 + 1, device='cuda', generator=g)
+    c_src, c_dst = c_store[1:].view(N, 5), torch.zeros(N, 5, device='cuda')                                   # dense but 4-byte aligned
+    cases.append(seg(c_src, c_dst, N, 5, c_src.stride(), c_dst.stride())); want.append((c_dst, c_src))
+    planes = torch.randn(12, 1024, device='cuda', generator=g)
+    d_src, d_dst = planes[:, :N].T, torch.zeros(N, 12, device='cuda')                                         # an [N, d] view of SoA planes
+    cases.append(seg(d_src, d_dst, N, 12, d_src.stride(), d_dst.stride())); want.append((d_dst, d_src))
+    e_src, e_planes = torch.randn(N, 4, device='cuda', generator=g), torch.zeros(4, 1024, device='cuda')      # rows into planes (transposing)
+    e_dst = e_planes[:, :N].T
+    cases.append(seg(e_src, e_dst, N, 4, e_src.stride(), e_dst.stride())); want.append((e_dst, e_src))
+    f_src, f_dst = torch.randn(1, 3, device='cuda', generator=g), torch.zeros(N, 3, device='cuda')            # one row broadcast over N
+    cases.append(seg(f_src, f_dst, N, 3, (0, 1), f_dst.stride())); want.append((f_dst, f_src.expand(N, 3)))
+    h_dst = torch.full((4, 4), 7.0, device='cuda')
+    cases.append(seg(a_src, h_dst, 0, 4, (4, 1), (4, 1)))                                                       # empty: nothing written
+    arr = (_capi.ScgCopySegment * len(cases))(*cases)
+    assert lib.scg_copy_segments(arr, len(cases), stream) == 0, lib.scg_last_error()
+    torch.cuda.synchronize()
+    for got, ref in want:
+        assert torch.equal(got, ref)
+    assert bool((h_dst == 7).all()) and bool((e_planes[:, N:] == 0).all())
+    # a large dense segment and a large transposing one (grid-stride loops)
+    big_src, big_dst = torch.randn(1 << 20, 12, device='cuda', generator=g), torch.empty(1 << 20, 12, device='cuda')
+    big_planes = torch.zeros(12, (1 << 20) + 64, device='cuda')
+    arr2 = (_capi.ScgCopySegment * 2)(seg(big_src, big_dst, 1 << 20, 12, (12, 1), (12, 1)),
+                                      seg(big_src, big_planes, 1 << 20, 12, (12, 1), (1, big_planes.stride(0))))
+    assert lib.scg_copy_segments(arr2, 2, stream) == 0
+    assert torch.equal(big_dst, big_src) and torch.equal(big_planes[:, :1 << 20].T, big_src)
+    # argument errors
+    bad = (_capi.ScgCopySegment * 1)(seg(a_src, a_dst, N, 12, (12, 1), (0, 1)))
+    for args, word in (((None, 1, stream), b'null'), ((arr, 0, stream), b'count'), ((arr, 9, stream), b'count'), ((bad, 1, stream), b'stride')):
+        assert lib.scg_copy_segments(*args) == -1 and word in lib.scg_last_error()
+    neg = (_capi.ScgCopySegment * 1)(seg(a_src, a_dst, -1, 12, (12, 1), (12, 1)))
+    assert lib.scg_copy_segments(neg, 1, stream) == -1
+
+
+@pytest.mark.gpu
+def test_push_rows_take_every_input_form_and_follow_reassigned_tensors(gpu):
+    """PPOBuffer.push keeps its per-step row views (made once per key): device tensors of either shape, host arrays and scalars
+    per env land in row t, and a key whose tensor the caller replaced (``rollouts.ret = ...``, ppo_utils.py:443-444) is not
+    written through a stale view."""
+    import torch
+    from types import SimpleNamespace
+    from safe_control_gym_amd.controllers.ppo.ppo_utils import PPOBuffer
+    T, N = 5, 16
+    buf = PPOBuffer(SimpleNamespace(shape=(3,)), SimpleNamespace(shape=(2,)), T, N)
+    for t in range(2 * T):                                     # twice around: the views of a row are reused
+        buf.push({'obs': torch.full((N, 3), float(t), device='cuda'), 'act': np.full((N, 2), t + 0.5),
+                  'rew': torch.full((N,), 2.0 * t, device='cuda'),                     # [N] for a [N, 1] row
+                  'v': torch.full((N, 1), 3.0 * t, device='cuda'), 'mask': (np.arange(N) % 2).astype(np.float64),
+                  'logp': torch.full((N, 1), -1.0 * t, device='cuda', dtype=torch.float64)})      # another dtype: converted
+        row = t % T
+        assert buf.t == (t + 1) % T
+        assert bool((buf.obs[row] == t).all()) and bool((buf.act[row] == t + 0.5).all()) and bool((buf.rew[row] == 2.0 * t).all())
+        assert bool((buf.v[row] == 3.0 * t).all()) and bool((buf.logp[row] == -1.0 * t).all())
+        assert torch.equal(buf.mask[row, :, 0].cpu(), torch.arange(N).remainder(2).float())
+    old_v = buf.v
+    buf.v = torch.zeros_like(old_v)                            # the caller replaces a key's tensor
+    keep = old_v.clone()
+    buf.push({'v': torch.ones((N, 1), device='cuda')})
+    assert bool((buf.v[0] == 1).all()) and bool((buf.v[1:] == 0).all()) and torch.equal(old_v, keep)
+    buf.reset()
+    buf.push({'v': torch.full((N, 1), 7.0, device='cuda')})
+    assert buf.t == 1 and bool((buf.v[0] == 7).all()) and bool((buf.v[1:] == 0).all())
+
+
+@pytest.mark.gpu
 def test_rollout_buffer_feeds_gae_from_the_env(gpu):
     """env.step -> PPOBuffer.push (device to device) -> GAE, with the reference's time-limit bootstrap
     (ppo.py:264-273: terminal_v = V(terminal_observation) where TimeLimit.truncated)."""
