@@ -1301,8 +1301,7 @@ class BenchmarkEnv:
         elif self._fresh_outputs:
             # copy_outputs: this step's outputs get tensors of their own, written by the kernel (no clone afterwards)
             f32 = torch.float32
-            slot_views = None
-            slot = None
+            slot_views = slot = None
             if self._ring is not None:
                 fresh, rew_t, done_t, state_rows, slot_views = self._ring[self._ring_pos]
                 self._ring_pos = (self._ring_pos + 1) % len(self._ring)
@@ -1339,7 +1338,7 @@ class BenchmarkEnv:
             if 'obs' in b:
                 b['obs'] = new_state
             if state_rows is not None:
-                b['state'] = state_rows                          # output ring: the slot's view, made once
+                b['state'] = state_rows                          # output pool / ring: the set's own view, made once
             else:
                 b['state'] = new_state if new_state.shape[0] == self.state_dim else new_state[:self.state_dim]
         if self._bound_dirty:
@@ -1353,7 +1352,7 @@ class BenchmarkEnv:
         new_state, outs = launched
         b = self._bufs
         if outs is not None and len(outs) > 3 and outs[3] is not None:
-            obs, rew, done = outs[3][0], outs[3][1], outs[3][2]   # output ring: the slot's views, made once
+            obs, rew, done = outs[3][0], outs[3][1], outs[3][2]   # output pool / ring: the set's own views, made once
         elif outs is not None:
             src = new_state if new_state is not None else outs[0]
             if src is None:
