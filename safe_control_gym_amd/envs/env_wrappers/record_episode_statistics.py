@@ -53,14 +53,16 @@ class VecRecordEpisodeStatistics(VecEnvWrapper):
         if 'episode' in info:
             idx = torch.nonzero(done).flatten()
             if idx.numel():
-                self.return_queue.extend(info['episode']['r'][idx].tolist())
-                self.length_queue.extend(info['episode']['l'][idx].tolist())
+                # a bounded deque keeps the LAST deque_size entries of what it is extended with: only those cross to the host (at 2^20
+                # envs tens of thousands of episodes end per step; a queue of 100 needs 100 of them)
+                tail = idx if self.deque_size is None or idx.numel() <= self.deque_size else idx[-self.deque_size:]
+                self.return_queue.extend(info['episode']['r'][tail].tolist())
+                self.length_queue.extend(info['episode']['l'][tail].tolist())
                 for key, acc in self.episode_stats.items():
-                    vals = acc[idx]
                     if key in self.accumulated_stats:
-                        self.accumulated_stats[key] += float(vals.sum())
+                        self.accumulated_stats[key] += float(acc[idx].sum())
                     if key in self.queued_stats:
-                        self.queued_stats[key].extend(vals.tolist())
+                        self.queued_stats[key].extend(acc[tail].tolist())
                     acc[idx] = 0
         return obs, reward, done, info
 

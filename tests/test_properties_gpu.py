@@ -245,14 +245,25 @@ def test_vec_env_protocol_and_episode_statistics(gpu):
                        constraints=[{'constraint_form': 'default_constraint', 'constrained_variable': 'state'}])
     venv = VecRecordEpisodeStatistics(make_vec_envs(env_func, batch_size=512, n_processes=4, seed=3), deque_size=10000)
     venv.add_tracker('constraint_violation', 0, mode='queue')
+    short = VecRecordEpisodeStatistics(make_vec_envs(env_func, batch_size=512, n_processes=4, seed=3), deque_size=7)   # fewer than finish per step
+    short.add_tracker('constraint_violation', 0, mode='queue')
+    short.add_tracker('mse', 0, mode='accumulate')
+    venv.add_tracker('mse', 0, mode='accumulate')
+    short.reset()
     obs, _ = venv.reset()
     assert obs.shape == (512, 6) and venv.num_envs == 512
     a = torch.as_tensor(venv.action_space.sample(512), device='cuda')
     total_done = 0
     for k in range(70):
         obs, rew, done, info = venv.step(a)
+        short.step(a)
         total_done += int(done.sum())
     assert len(venv.return_queue) == total_done == len(venv.length_queue) and total_done >= 512
+    # a short queue holds what the tail of the long one holds (only its last entries cross to the host), the accumulators agree
+    assert list(short.return_queue) == list(venv.return_queue)[-7:] and list(short.length_queue) == list(venv.length_queue)[-7:]
+    assert list(short.queued_stats['constraint_violation']) == list(venv.queued_stats['constraint_violation'])[-7:]
+    assert short.accumulated_stats['mse'] == pytest.approx(venv.accumulated_stats['mse'], rel=1e-6) and venv.accumulated_stats['mse'] > 0
+    short.close()
     assert max(venv.length_queue) <= 60 and len(venv.queued_stats['constraint_violation']) == total_done
     assert venv.get_attr('CTRL_FREQ')[0] == 60 and len(venv.get_attr('CTRL_FREQ')) == 512
     per_env = info['n'][0]
