@@ -846,7 +846,7 @@ def run_rank(args):
                          'per-step roofline above (its algorithmic bytes are 4*nu per env-step); VALU-bound'}
 
     queues = 1 if args.queues == 1 else 2
-    two_queues = queues == 2 and (n // 2) // 256 * 256 >= (env.ROLLOUT_SPLIT_MIN or 131072) and args.steps >= 2
+    two_queues = queues == 2 and (n // 2) // 256 * 256 >= (env.ROLLOUT_SPLIT_MIN or 131072 + 256) and args.steps >= 2
     out = None
     if rank == 0:
         step_us = ms_per_step * 1e3

@@ -468,7 +468,7 @@ def test_row_major_actions_are_read_in_place(gpu):
 
 @pytest.mark.parametrize('tier', ['lean', 'full_info', 'extra'])
 def test_two_queue_rollout_is_bit_identical_to_the_step_loop(gpu, tier):
-    """scg_rollout cuts batches of >= 2^18 envs in two halves that advance on two HIP streams (the tail of one half's
+    """scg_rollout cuts batches of more than 2^18 envs in two halves that advance on two HIP streams (the tail of one half's
     kernel overlaps the body of the other's).  Per env nothing changes: same arithmetic, same Philox counters (global env
     index) -- so the buffers after K steps equal those of K single-stream env.step() calls bit for bit.  Odd n: the second
     half is ragged."""
