@@ -304,6 +304,9 @@ def sub_record(args, timer, workload, n, steps, track=False, extra=None, note=No
            'us_per_step': us, 'us_per_step_min_max': [m['ms_min'] * 1e3 / steps, m['ms_max'] * 1e3 / steps],
            'moved_bytes_per_env_step': moved, 'survey_bytes_per_env_step': survey,
            'achieved_GBs': moved * n / (us * 1e-6) / 1e9, 'frac': moved * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    two = env.ROLLOUT_QUEUES != 1 and (n // 2) // 256 * 256 >= (env.ROLLOUT_SPLIT_MIN or 131072 + 256)
+    rec['launch'] = ('scg_rollout: two half-batch kernels per step on two HIP streams' if two else
+                     'scg_rollout: one kernel per step on one queue' + (', replayed from the library\'s hipGraph' if env.ROLLOUT_GRAPH >= 0 and steps >= 8 else ''))
     if note:
         rec['note'] = note
     if fused_too:
