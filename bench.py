@@ -304,7 +304,7 @@ def sub_record(args, timer, workload, n, steps, track=False, extra=None, note=No
            'us_per_step': us, 'us_per_step_min_max': [m['ms_min'] * 1e3 / steps, m['ms_max'] * 1e3 / steps],
            'moved_bytes_per_env_step': moved, 'survey_bytes_per_env_step': survey,
            'achieved_GBs': moved * n / (us * 1e-6) / 1e9, 'frac': moved * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
-    two = env.ROLLOUT_QUEUES != 1 and (n // 2) // 256 * 256 >= (env.ROLLOUT_SPLIT_MIN or 131072 + 256)
+    two = env.ROLLOUT_QUEUES != 1 and (n // 2) // 256 * 256 >= (env.ROLLOUT_SPLIT_MIN or 262144)
     rec['launch'] = ('scg_rollout: two half-batch kernels per step on two HIP streams' if two else
                      'scg_rollout: one kernel per step on one queue' + (', replayed from the library\'s hipGraph' if env.ROLLOUT_GRAPH >= 0 and steps >= 8 else ''))
     if note:
@@ -849,7 +849,7 @@ def run_rank(args):
                          'per-step roofline above (its algorithmic bytes are 4*nu per env-step); VALU-bound'}
 
     queues = 1 if args.queues == 1 else 2
-    two_queues = queues == 2 and (n // 2) // 256 * 256 >= (env.ROLLOUT_SPLIT_MIN or 131072 + 256) and args.steps >= 2
+    two_queues = queues == 2 and (n // 2) // 256 * 256 >= (env.ROLLOUT_SPLIT_MIN or 262144) and args.steps >= 2
     out = None
     if rank == 0:
         step_us = ms_per_step * 1e3

@@ -134,7 +134,7 @@ typedef struct scg_config {
     /* Launch policy of THIS handle (no process-wide switches: two handles in one process may differ).
      * rollout_queues: 0 = default (2), 1 = everything on the caller's stream, 2 = scg_rollout cuts batches whose half is
      *   >= rollout_split_min envs in two halves advancing on two HIP streams.
-     * rollout_split_min: 0 = default (131328 envs per half: batches of more than 2^18 envs; at 2^18 the graph replay is steadier).
+     * rollout_split_min: 0 = default (262144 envs per half: batches of at least 2^19 envs; below, the graph replay is level or ahead).
      * ref_in_lds: stage the X_GOAL table in LDS once per workgroup instead of gathering it through L1/L2.
      * grid_cap_per_cu: 0 = one lane per env (no grid-stride loop); > 0 caps the grid at that many workgroups per CU.
      * rollout_graph: 0 = default (on), 1 = on, -1 = off.  On: scg_rollout captures the launches of a single-queue rollout

@@ -926,10 +926,11 @@ static int rollout_launches(scg_handle* h, const scg_step_io* io, const scg_traj
     // kernel overlaps the body of the other's (measured 24.9 vs 29.0 us per step of the whole batch; four queues are
     // slower again).  Per env the arithmetic, the Philox counters and therefore the results are unchanged.
     const int queues = h->cfg.rollout_queues == 1 ? 1 : 2;
-    // Default: batches of MORE than 2^18 envs.  At exactly 2^18 (C3) the two queues are host-bound -- two launches of a ~4 us kernel
-    // per step -- and land anywhere between 7.6 and 10.1 us per step by box and by run; one queue replayed from the graph below holds
-    // 7.9-8.0 (profiles/r04/c3_queues_ab.txt); at 2^19 the two queues win by 19 %.
-    const int64_t split_min = h->cfg.rollout_split_min > 0 ? h->cfg.rollout_split_min : (int64_t)131072 + 256;
+    // Default: batches of at least 2^19 envs.  At 2^18 (C3) the two queues are host-bound -- two launches of a ~4 us kernel per
+    // step -- and land anywhere between 7.6 and 10.1 us per step by box and by run, where one queue replayed from the graph below
+    // holds 7.9-8.0; up to 393216 envs the graph is level or ahead for the 2-D and the 3-D quadrotor; at 2^19 the two queues win
+    // by 19 % (profiles/r04/c3_queues_ab.txt).
+    const int64_t split_min = h->cfg.rollout_split_min > 0 ? h->cfg.rollout_split_min : (int64_t)262144;
     const int64_t half = (n / 2) / 256 * 256;
     if (queues == 2 && steps >= 2 && half >= split_min && half > 0) {
         if (int rc = ensure_aux_queue(h, who)) return rc;

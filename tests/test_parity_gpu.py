@@ -647,7 +647,7 @@ def test_precise_modes_teacher_forced_parity_resets_and_queues(gpu, mode, info_l
     # two launch queues: bit-identical to the step loop in this mode too
     big = 300001
     kw2 = dict(quad_type=3, num_envs=big, device='cuda', seed=4, randomized_init=True, task='traj_tracking', cost='quadratic',
-               episode_len_sec=0.25, compensated_state=mode, info_level=info_level)
+               episode_len_sec=0.25, compensated_state=mode, info_level=info_level, rollout_split_min=131072)
     a, b = scg.make('quadrotor', **kw2), scg.make('quadrotor', **kw2)
     a.reset(), b.reset()
     g = torch.Generator(device='cuda'); g.manual_seed(8)

@@ -468,13 +468,13 @@ def test_row_major_actions_are_read_in_place(gpu):
 
 @pytest.mark.parametrize('tier', ['lean', 'full_info', 'extra'])
 def test_two_queue_rollout_is_bit_identical_to_the_step_loop(gpu, tier):
-    """scg_rollout cuts batches of more than 2^18 envs in two halves that advance on two HIP streams (the tail of one half's
+    """scg_rollout cuts batches of at least 2^19 envs (here: rollout_split_min lowered) in two halves that advance on two HIP streams (the tail of one half's
     kernel overlaps the body of the other's).  Per env nothing changes: same arithmetic, same Philox counters (global env
     index) -- so the buffers after K steps equal those of K single-stream env.step() calls bit for bit.  Odd n: the second
     half is ragged."""
     n = 300001
     kw = dict(quad_type=3, num_envs=n, device='cuda', seed=21, randomized_init=True, task='traj_tracking', cost='quadratic',
-              episode_len_sec=0.25)
+              episode_len_sec=0.25, rollout_split_min=131072)
     if tier == 'lean':
         kw.update(info_level='minimal')
     elif tier == 'extra':
@@ -893,7 +893,7 @@ def test_two_handles_in_one_process_may_differ_in_launch_policy(gpu):
     n = 300001
     kw = dict(quad_type=3, num_envs=n, device='cuda', seed=5, randomized_init=True, task='traj_tracking', cost='quadratic',
               episode_len_sec=0.25, info_level='minimal')
-    envs = [scg.make('quadrotor', **kw), scg.make('quadrotor', rollout_queues=1, **kw),
+    envs = [scg.make('quadrotor', rollout_split_min=131072, **kw), scg.make('quadrotor', rollout_queues=1, **kw),
             scg.make('quadrotor', rollout_queues=2, rollout_split_min=1024, ref_in_lds=1, **kw),
             scg.make('quadrotor', rollout_queues=1, grid_cap_per_cu=2, **kw)]
     g = torch.Generator(device='cuda'); g.manual_seed(8)
